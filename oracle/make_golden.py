@@ -1,0 +1,200 @@
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz by running the REFERENCE's own Python.
+
+Run only in the development container (needs /root/reference):
+
+    python oracle/make_golden.py
+
+Inputs are never stored: every fixture records the generator call
+(``imageanalysis3_amd.synth``; bit-stable integer-hash generator) and the reference outputs.
+The reference is loaded file-by-file via ``oracle/ref_loader.py``.
+"""
+import os
+import sys
+import io
+import json
+import zlib
+import contextlib
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader  # noqa: E402
+from imageanalysis3_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def samples(a, n=4096, seed=99):
+    idx = (synth.uniform01(seed, 11, np.arange(n)) * a.size).astype(np.int64)
+    return idx, a.reshape(-1)[idx].copy()
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def case_image(spec):
+    """spec -> stack; mirrored by tests/conftest.py::build_case."""
+    im, c, h = synth.make_fov(tuple(spec["shape"]), spec["n"], spec["seed"], layout=spec["layout"],
+                              dtype=np.dtype(spec["dtype"]),
+                              **{k: spec[k] for k in ("n_territories", "min_sep", "margin") if k in spec})
+    if spec.get("hot_columns"):
+        for (x, y, v) in spec["hot_columns"]:
+            im[:, x, y] = v
+    return im
+
+
+CASES = {
+    "c1_f32": dict(shape=[30, 128, 128], n=50, seed=1, layout="isolated", dtype="float32"),
+    "c1_u16": dict(shape=[30, 128, 128], n=50, seed=1, layout="isolated", dtype="uint16"),
+    "m_f32": dict(shape=[50, 256, 256], n=150, seed=2, layout="isolated", dtype="float32"),
+    "edge_f32": dict(shape=[12, 40, 56], n=8, seed=4, layout="isolated", dtype="float32", min_sep=10.0,
+                     margin=[1, 3, 3]),
+    "clu_f32": dict(shape=[30, 128, 128], n=80, seed=5, layout="clustered", dtype="float32",
+                    n_territories=6),
+    "hot_u16": dict(shape=[30, 128, 128], n=30, seed=6, layout="isolated", dtype="uint16",
+                    hot_columns=[[40, 41, 9000], [90, 17, 12000]]),
+}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R = ref_loader.load_reference()
+    fit, F4 = R.fitting, R.F4
+    meta = {"cases": CASES, "numpy": np.__version__}
+    import scipy
+    meta["scipy"] = scipy.__version__
+
+    # ---------------- seeding + fitting tables --------------------------------------------
+    for name, spec in CASES.items():
+        im = case_image(spec)
+        d = {}
+        d["seeds_h"] = fit.get_seeds(im, th_seed=600, return_h=True)
+        d["seeds_nodyn"] = fit.get_seeds(im, th_seed=600, use_dynamic_th=False, return_h=True)
+        d["seeds_hi_th"] = fit.get_seeds(im, th_seed=9000, return_h=True, min_dynamic_seeds=5)
+        d["seeds_nohot"] = fit.get_seeds(im, th_seed=600, remove_hot_pixel=False, return_h=True)
+        d["seeds_top10"] = fit.get_seeds(im, th_seed=600, max_num_seeds=10, return_h=True)
+        cen = [s // 2 for s in spec["shape"]]
+        d["sel_center"] = np.array(cen)
+        d["seeds_sel"] = fit.get_seeds(im, th_seed=600, sel_center=cen, seed_radius=20, return_h=True)
+        d["seeds_edge0"] = fit.get_seeds(im, th_seed=600, min_edge_distance=0, return_h=True)
+        # fitting
+        seeds = fit.get_seeds(im, th_seed=600)
+        fitter = F4.iter_fit_seed_points(im, seeds.T, radius_fit=5)
+        quiet(fitter.firstfit)
+        d["first_ps"] = np.array(fitter.ps, dtype=np.float32)
+        d["first_nvox"] = np.array([len(g[0]) for g in fitter.gparms])
+        quiet(fitter.repeatfit)
+        d["final_ps"] = np.array(fitter.ps, dtype=np.float32)
+        d["n_iter"] = np.array(fitter.n_iter)
+        d["table"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+        d["table_max20"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=20, verbose=False)
+        d["centers"] = quiet(fit.get_centers, im, th_seed=600)
+        d["sparse"] = fit.select_sparse_centers(d["centers"], distance_th=25)
+        # a few voxel sets (Voronoi cells) of the first fit
+        for k in range(min(3, len(fitter.gparms))):
+            d["gp%d_X" % k] = np.array(fitter.gparms[k][1])
+            d["gp%d_im" % k] = np.array(fitter.gparms[k][0])
+        np.savez_compressed(os.path.join(OUT, "fit_%s.npz" % name), **d)
+        print(name, "seeds", len(d["seeds_h"]), "table", d["table"].shape, "n_iter", fitter.n_iter)
+
+    # ---------------- single-spot known answer (GaussianFit) --------------------------------
+    shape = (30, 64, 64)
+    c0 = np.array([[14.3, 30.6, 33.2]])
+    im64 = np.full(shape, 100.0)
+    synth.add_spots(im64, c0, np.array([2000.0]))
+    im1 = im64.astype(np.float32)
+    f1 = F4.iter_fit_seed_points(im1, np.array([[14.0], [31.0], [33.0]]), radius_fit=5)
+    quiet(f1.firstfit)
+    quiet(f1.repeatfit)
+    np.savez_compressed(os.path.join(OUT, "single_spot.npz"), ps=np.array(f1.ps, dtype=np.float32),
+                        n_iter=np.array(f1.n_iter), center=c0, shape=np.array(shape))
+
+    # ---------------- filters: high-pass, hot pixels ----------------------------------------
+    d = {}
+    for name in ("c1_f32", "c1_u16", "hot_u16"):
+        im = case_image(CASES[name])
+        for sg, tr in ((3, 2), (5, 2)):
+            hp = R.filter.gaussian_high_pass_filter(im, sg, tr)
+            idx, val = samples(hp)
+            d["hp_%s_s%d_crc" % (name, sg)] = crc(hp)
+            d["hp_%s_s%d_idx" % (name, sg)] = idx
+            d["hp_%s_s%d_val" % (name, sg)] = val
+            d["hp_%s_s%d_sum" % (name, sg)] = np.float64(hp.astype(np.float64).sum())
+        rh = R.filter.Remove_Hot_Pixels(im, dtype=im.dtype)
+        d["rhp_%s_crc" % name] = crc(rh)
+        d["rhp_%s_ndiff" % name] = np.int64((rh != im).sum())
+        idx, val = samples(rh)
+        d["rhp_%s_idx" % name] = idx
+        d["rhp_%s_val" % name] = val
+    np.savez_compressed(os.path.join(OUT, "filters.npz"), **d)
+
+    # ---------------- warp --------------------------------------------------------------------
+    d = {}
+    drift = np.array([0.37, -2.6, 4.25])
+    for name in ("c1_f32", "c1_u16"):
+        im = case_image(CASES[name])[:, :96, :80]
+        Z, X, Y = im.shape
+        zz, xx, yy = np.meshgrid(np.arange(Z), np.arange(X), np.arange(Y), indexing="ij")
+        field = np.stack([0.002 * (xx - X / 2), 0.01 * (yy - Y / 2) + 0.2, -0.008 * (xx - X / 2) + 0.005 * zz])
+        for order, mode in ((1, "constant"), (3, "nearest"), (1, "nearest")):
+            for use_field in (False, True):
+                w = R.translate.warp_3d_image(im, drift, chromatic_profile=field if use_field else None,
+                                              warp_order=order, border_mode=mode)
+                key = "warp_%s_o%d_%s_f%d" % (name, order, mode, int(use_field))
+                idx, val = samples(w)
+                d[key + "_crc"] = crc(w)
+                d[key + "_idx"] = idx
+                d[key + "_val"] = val
+    d["drift"] = drift
+    np.savez_compressed(os.path.join(OUT, "warp.npz"), **d)
+
+    # ---------------- drift: crops, fft3d_from2d, bead-path align_image, pairing --------------
+    d = {}
+    for k, size in enumerate(([30, 2048, 2048], [50, 2048, 2048], [30, 256, 256], [12, 100, 60])):
+        d["crops_%d_size" % k] = np.array(size)
+        d["crops_%d" % k] = R.alignment.generate_drift_crops(size)
+    bshape = (30, 256, 256)
+    true_d = np.array([1.3, -4.6, 7.25])
+    ref, src, bc, bh = synth.make_bead_pair(bshape, 120, 21, true_d)
+    d["bead_shape"] = np.array(bshape)
+    d["bead_true_d"] = true_d
+    d["fft3d"] = R.alignment_tools.fft3d_from2d(src, ref, gb=0, max_disp=128)
+    d["fft3d_F4style_xy"] = np.array(R.alignment_tools.fftalign_2d(np.max(src, 0), np.max(ref, 0), max_disp=50))
+    drift, flag = quiet(R.alignment.align_image, src, ref, use_autocorr=False,
+                        correction_args={"single_im_size": list(bshape)}, verbose=False)
+    d["align_beads_drift"] = np.array(drift)
+    d["align_beads_flag"] = np.array(flag)
+    # pairing on fitted centres of one crop
+    crop = R.alignment.generate_drift_crops(list(bshape))[0]
+    s = tuple(slice(*c) for c in crop)
+    fa = dict(th_seed=300, use_dynamic_th=True, min_dynamic_seeds=10, max_num_seeds=200)
+    ss = quiet(fit.fit_fov_image, src[s], "488", verbose=False, **fa)
+    rs = quiet(fit.fit_fov_image, ref[s], "488", verbose=False, **fa)
+    sc = fit.select_sparse_centers(ss[:, 1:4], 2.)
+    rc = fit.select_sparse_centers(rs[:, 1:4], 2.)
+    d["pair_src_cts"], d["pair_ref_cts"] = sc, rc
+    rough = R.alignment_tools.fft3d_from2d(src[s], ref[s], gb=0, max_disp=np.max(src[s].shape) / 2)
+    d["pair_rough"] = rough
+    dr, pt, pr = R.matching.find_paired_centers(sc, rc, rough, cutoff=2.)
+    d["pair_drift"], d["pair_tar"], d["pair_ref"] = dr, pt, pr
+    if len(pr) > 3:
+        dr2, pt2, pr2 = R.matching.check_paired_centers(pt, pr, outlier_sigma=1.5)
+        d["check_drift"], d["check_tar"], d["check_ref"] = dr2, pt2, pr2
+    np.savez_compressed(os.path.join(OUT, "drift.npz"), **d)
+
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

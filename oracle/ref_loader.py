@@ -1,0 +1,105 @@
+"""TEST INFRASTRUCTURE ONLY — loader for the upstream reference's hot-path files.
+
+Runs only where ``/root/reference`` exists (the development container).  It is
+used by ``oracle/make_golden.py`` to produce the committed fixtures under
+``tests/golden/`` and by the optional ``tests/test_oracle_vs_reference.py``
+(skipped when the reference tree is absent, e.g. on the GPU box).
+
+Nothing in the product package imports this module.  It contains no reference
+code: it only wires ``importlib`` so the reference's own files can be executed
+file-by-file (``import ImageAnalysis3`` as a package is impossible because its
+``__init__`` eagerly imports cv2 / skimage / h5py / pyfftw, all absent here).
+Recipe: SURVEY.md Appendix A.
+"""
+import os
+import sys
+import types
+import importlib.util
+import warnings
+
+REF = os.environ.get("IA3_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REF, "External", "Fitting_v4.py"))
+
+
+_loaded = None
+
+
+def load_reference():
+    """Return a namespace with the reference modules (cached)."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF)
+    warnings.filterwarnings("ignore")
+    import numpy as np
+    import scipy.signal
+    import matplotlib
+    matplotlib.use("Agg")
+    for n, t in (("int", int), ("bool", bool), ("float", float)):  # removed in numpy>=1.24
+        if not hasattr(np, n):
+            setattr(np, n, t)
+    if not hasattr(scipy.signal, "gaussian"):
+        scipy.signal.gaussian = scipy.signal.windows.gaussian
+
+    def stub(name, **kw):
+        m = types.ModuleType(name)
+        m.__dict__.update(kw)
+        sys.modules[name] = m
+        return m
+
+    def load(modname, path):
+        spec = importlib.util.spec_from_file_location(modname, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        spec.loader.exec_module(m)
+        return m
+
+    pfn = stub("pyfftw.interfaces.numpy_fft", rfftn=np.fft.rfftn, irfftn=np.fft.irfftn)
+    stub("pyfftw", interfaces=stub("pyfftw.interfaces", numpy_fft=pfn))
+    stub("cv2")
+    stub("skimage", morphology=None, restoration=None, measure=None)
+    stub("skimage.segmentation", random_walker=None)
+
+    def _no_pcc(*a, **k):
+        raise RuntimeError("scikit-image not installed")
+
+    stub("skimage.registration", phase_cross_correlation=_no_pcc)
+    G = dict(_correction_folder="", _temp_folder="", _distance_zxy=[200, 108, 108],
+             _sigma_zxy=[1.35, 1.9, 1.9],
+             _allowed_colors=["750", "647", "561", "488", "405"],
+             _image_size=[30, 2048, 2048], _corr_channels=["750", "647", "561"],
+             _num_buffer_frames=0, _num_empty_frames=0, _image_dtype=np.uint16)
+    root = stub("IA3", **G)
+    root.__path__ = []
+    ext = stub("IA3.External")
+    ext.__path__ = []
+    F4 = load("IA3.External.Fitting_v4", REF + "/External/Fitting_v4.py")
+    ext.Fitting_v4 = F4
+    ext.Fitting_v3 = F4
+    vt = stub("IA3.visual_tools", get_seed_points_base=F4.get_seed_points_base,
+              translate_spot_coordinates=None)
+    root.visual_tools = vt
+    root.get_img_info = stub("IA3.get_img_info")
+    root.corrections = stub("IA3.corrections")
+    st = stub("IA3.spot_tools", _seed_th={"750": 600, "647": 600, "561": 600}, **G)
+    st.__path__ = []
+    fitting = load("IA3.spot_tools.fitting", REF + "/spot_tools/fitting.py")
+    ct = stub("IA3.correction_tools")
+    ct.__path__ = []
+    filt = load("IA3.correction_tools.filter", REF + "/correction_tools/filter.py")
+    trans = load("IA3.correction_tools.translate", REF + "/correction_tools/translate.py")
+    at = load("IA3.alignment_tools", REF + "/alignment_tools.py")
+    root.alignment_tools = at
+    matching = load("IA3.spot_tools.matching", REF + "/spot_tools/matching.py")
+    st.matching = matching
+    stub("IA3.io_tools").__path__ = []
+    stub("IA3.io_tools.load", correct_fov_image=None)
+    align = load("IA3.correction_tools.alignment", REF + "/correction_tools/alignment.py")
+    ns = types.SimpleNamespace(F4=F4, fitting=fitting, filter=filt, translate=trans,
+                               alignment_tools=at, matching=matching, alignment=align)
+    _loaded = ns
+    return ns

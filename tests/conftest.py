@@ -1,0 +1,55 @@
+import os
+import sys
+import json
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _meta():
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        return json.load(f)
+
+
+def build_case(name):
+    """Regenerate the input stack of a golden case (mirror of oracle/make_golden.py::case_image)."""
+    from imageanalysis3_amd import synth
+    spec = _meta()["cases"][name]
+    im, c, h = synth.make_fov(tuple(spec["shape"]), spec["n"], spec["seed"], layout=spec["layout"],
+                              dtype=np.dtype(spec["dtype"]),
+                              **{k: spec[k] for k in ("n_territories", "min_sep", "margin") if k in spec})
+    for (x, y, v) in spec.get("hot_columns", []):
+        im[:, x, y] = v
+    return im
+
+
+def load_golden(fname):
+    return dict(np.load(os.path.join(GOLDEN, fname), allow_pickle=False))
+
+
+def golden_samples_idx(size, n=4096, seed=99):
+    from imageanalysis3_amd import synth
+    return (synth.uniform01(seed, 11, np.arange(n)) * size).astype(np.int64)
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def cases():
+    return _meta()["cases"]

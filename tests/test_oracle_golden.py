@@ -1,0 +1,154 @@
+"""CPU: the NumPy oracle against fixtures produced by the reference's own Python
+(oracle/make_golden.py).  This is what "parity pinned" rests on."""
+import zlib
+import numpy as np
+import pytest
+from conftest import build_case, load_golden
+import np_oracle as O
+
+FIT_CASES = ["c1_f32", "c1_u16", "m_f32", "edge_f32", "clu_f32", "hot_u16"]
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+@pytest.mark.parametrize("name", FIT_CASES)
+def test_get_seeds_variants(name):
+    g = load_golden("fit_%s.npz" % name)
+    im = build_case(name)
+    assert np.array_equal(O.get_seeds(im, th_seed=600, return_h=True), g["seeds_h"])
+    assert np.array_equal(O.get_seeds(im, th_seed=600, use_dynamic_th=False, return_h=True), g["seeds_nodyn"])
+    assert np.array_equal(O.get_seeds(im, th_seed=9000, return_h=True, min_dynamic_seeds=5), g["seeds_hi_th"])
+    assert np.array_equal(O.get_seeds(im, th_seed=600, remove_hot_pixel=False, return_h=True), g["seeds_nohot"])
+    assert np.array_equal(O.get_seeds(im, th_seed=600, max_num_seeds=10, return_h=True), g["seeds_top10"])
+    assert np.array_equal(O.get_seeds(im, th_seed=600, sel_center=list(g["sel_center"]), seed_radius=20,
+                                      return_h=True), g["seeds_sel"])
+    assert np.array_equal(O.get_seeds(im, th_seed=600, min_edge_distance=0, return_h=True), g["seeds_edge0"])
+
+
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "edge_f32", "clu_f32", "hot_u16"])
+def test_fit_tables_bit_exact(name):
+    """Same MINPACK, same arithmetic order -> the oracle reproduces the reference bit for bit."""
+    g = load_golden("fit_%s.npz" % name)
+    im = build_case(name)
+    seeds = O.get_seeds(im, th_seed=600)
+    f = O.iter_fit_seed_points(im, seeds.T, radius_fit=5)
+    f.firstfit()
+    assert np.array_equal(np.array(f.ps, dtype=np.float32), g["first_ps"], equal_nan=True)
+    assert np.array_equal(np.array([len(x[0]) for x in f.gparms]), g["first_nvox"])
+    for k in range(3):
+        if "gp%d_X" % k in g:
+            assert np.array_equal(f.gparms[k][1], g["gp%d_X" % k])
+            assert np.array_equal(f.gparms[k][0], g["gp%d_im" % k])
+    f.repeatfit()
+    assert np.array_equal(np.array(f.ps, dtype=np.float32), g["final_ps"], equal_nan=True)
+    assert f.n_iter == int(g["n_iter"])
+    assert np.array_equal(O.fit_fov_image(im, "647", th_seed=600, max_num_seeds=None), g["table"])
+    assert np.array_equal(O.fit_fov_image(im, "647", th_seed=600, max_num_seeds=20), g["table_max20"])
+
+
+def test_centers_and_sparse():
+    g = load_golden("fit_c1_f32.npz")
+    im = build_case("c1_f32")
+    c = O.get_centers(im, th_seed=600)
+    assert np.array_equal(c, g["centers"])
+    assert np.array_equal(O.select_sparse_centers(c, distance_th=25), g["sparse"])
+
+
+def test_lowest_index_voronoi_equals_ckdtree_when_isolated():
+    g = load_golden("fit_c1_f32.npz")
+    im = build_case("c1_f32")
+    t = O.fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, voronoi="lowest_index")
+    assert np.array_equal(t, g["table"])
+
+
+def test_single_spot_known_answer():
+    g = load_golden("single_spot.npz")
+    from imageanalysis3_amd import synth
+    im64 = np.full(tuple(g["shape"]), 100.0)
+    synth.add_spots(im64, g["center"], np.array([2000.0]))
+    im = im64.astype(np.float32)
+    f = O.iter_fit_seed_points(im, np.array([[14.0], [31.0], [33.0]]), radius_fit=5)
+    f.firstfit()
+    f.repeatfit()
+    ps = np.array(f.ps, dtype=np.float32)
+    assert np.array_equal(ps, g["ps"])
+    # and the physics: recovers the injected spot
+    assert np.allclose(ps[0, 1:4], g["center"][0], atol=2e-3)
+    assert abs(ps[0, 0] - 2000) < 1 and abs(ps[0, 4] - 100) < 0.1
+    assert np.allclose(ps[0, 5:8], [1.35, 1.9, 1.9], atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "hot_u16"])
+def test_highpass_and_hot_pixels(name):
+    g = load_golden("filters.npz")
+    im = build_case(name)
+    for sg in (3, 5):
+        hp = O.gaussian_high_pass_filter(im, sg, 2)
+        assert hp.dtype == im.dtype
+        assert crc(hp) == g["hp_%s_s%d_crc" % (name, sg)]
+        assert np.array_equal(hp.reshape(-1)[g["hp_%s_s%d_idx" % (name, sg)]], g["hp_%s_s%d_val" % (name, sg)])
+    rh = O.remove_hot_pixels(im, dtype=im.dtype)
+    assert crc(rh) == g["rhp_%s_crc" % name]
+    assert int((rh != im).sum()) == int(g["rhp_%s_ndiff" % name])
+
+
+def test_hot_pixel_case_really_has_hot_columns():
+    g = load_golden("filters.npz")
+    assert int(g["rhp_hot_u16_ndiff"]) > 0
+
+
+def test_drift_crops():
+    g = load_golden("drift.npz")
+    for k in range(4):
+        assert np.array_equal(O.generate_drift_crops(list(g["crops_%d_size" % k])), g["crops_%d" % k])
+
+
+def test_fft3d_and_bead_alignment():
+    from imageanalysis3_amd import synth
+    g = load_golden("drift.npz")
+    ref, src, bc, bh = synth.make_bead_pair(tuple(g["bead_shape"]), 120, 21, g["bead_true_d"])
+    assert np.array_equal(O.fft3d_from2d(src, ref, gb=0, max_disp=128), g["fft3d"])
+    drift, flag = O.align_image(src, ref, use_autocorr=False)
+    assert flag == int(g["align_beads_flag"])
+    assert np.allclose(drift, g["align_beads_drift"], rtol=0, atol=1e-12)
+    # sign convention: beads at c+d in src -> drift ~ -d
+    assert np.allclose(drift, -g["bead_true_d"], atol=0.02)
+
+
+def test_pairing():
+    g = load_golden("drift.npz")
+    dr, pt, pr = O.find_paired_centers(g["pair_src_cts"], g["pair_ref_cts"], g["pair_rough"], cutoff=2.)
+    assert np.array_equal(pt, g["pair_tar"]) and np.array_equal(pr, g["pair_ref"])
+    assert np.allclose(dr, g["pair_drift"], atol=1e-12)
+    if "check_drift" in g:
+        dr2, pt2, pr2 = O.check_paired_centers(pt, pr, outlier_sigma=1.5)
+        assert np.array_equal(pt2, g["check_tar"])
+        assert np.allclose(dr2, g["check_drift"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16"])
+def test_warp(name):
+    g = load_golden("warp.npz")
+    im = build_case(name)[:, :96, :80]
+    Z, X, Y = im.shape
+    zz, xx, yy = np.meshgrid(np.arange(Z), np.arange(X), np.arange(Y), indexing="ij")
+    field = np.stack([0.002 * (xx - X / 2), 0.01 * (yy - Y / 2) + 0.2, -0.008 * (xx - X / 2) + 0.005 * zz])
+    for order, mode in ((1, "constant"), (3, "nearest"), (1, "nearest")):
+        for use_field in (False, True):
+            w = O.warp_3d_image(im, g["drift"], field if use_field else None, order, mode)
+            key = "warp_%s_o%d_%s_f%d" % (name, order, mode, int(use_field))
+            assert crc(w) == g[key + "_crc"], key
+
+
+def test_phase_xcorr_known_answer():
+    """PARITY UNPINNED (scikit-image absent): known-answer test on an analytically shifted stack."""
+    from imageanalysis3_amd import synth
+    d = np.array([0.7, -3.25, 5.5])
+    ref, src, _, _ = synth.make_bead_pair((20, 96, 96), 20, 3, d, margin=(5, 12, 12), min_sep=12.0)
+    for norm in ("phase", None):
+        shift, err, ph = O.phase_cross_correlation(ref, src, upsample_factor=100, normalization=norm)
+        assert np.allclose(shift, -d, atol=0.06), (norm, shift)
+    shift, _, _ = O.phase_cross_correlation(ref, src, upsample_factor=1)
+    assert np.array_equal(shift, np.round(-d + 1e-9)) or np.allclose(shift, -d, atol=0.51)
