@@ -1,0 +1,227 @@
+"""ctypes binding of libia3.so (C ABI declared in include/ia3.h).
+
+The library is the product: there is no CPU fallback.  Importing this module without a built
+``libia3.so`` raises ImportError; calling into it without a HIP device raises RuntimeError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libia3.so")
+
+IA3_U16, IA3_F32 = 0, 1
+IA3_OK, IA3_EINVAL, IA3_EHIP, IA3_ENOMEM, IA3_ECAPACITY, IA3_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+MODE_REFLECT, MODE_NEAREST, MODE_CONSTANT = 0, 1, 2
+
+EXPORTS = [
+    "ia3_init", "ia3_last_error", "ia3_version", "ia3_device_name", "ia3_sync", "ia3_stream",
+    "ia3_release_workspace",
+    "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
+    "ia3_stack_free",
+    "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
+    "ia3_remove_hot_pixels",
+    "ia3_dog_seed", "ia3_dog_seed_dev",
+    "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_results", "ia3_fit_stats",
+    "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev",
+]
+
+
+class SeedParams(C.Structure):
+    _fields_ = [("th_seed", C.c_double), ("gfilt_size", C.c_double), ("background_gfilt_size", C.c_double),
+                ("filt_size", C.c_int), ("min_edge_distance", C.c_int), ("use_dynamic_th", C.c_int),
+                ("dynamic_niters", C.c_int), ("min_dynamic_seeds", C.c_int), ("remove_hot_pixel", C.c_int),
+                ("hot_pixel_th", C.c_int), ("max_num_seeds", C.c_int), ("th_compare_f32", C.c_int),
+                ("w_front", C.POINTER(C.c_double)), ("r_front", C.c_int),
+                ("w_back", C.POINTER(C.c_double)), ("r_back", C.c_int)]
+
+
+class FitParams(C.Structure):
+    _fields_ = [("radius_fit", C.c_int), ("min_delta_center", C.c_double), ("max_delta_center", C.c_double),
+                ("n_max_iter", C.c_int), ("max_dist_th", C.c_double), ("min_w", C.c_double),
+                ("max_w", C.c_double), ("init_w", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libia3.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                "imageanalysis3_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C imageanalysis3_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ia3_last_error.restype = C.c_char_p
+        L.ia3_version.restype = C.c_char_p
+        L.ia3_stream.restype = C.c_void_p
+        L.ia3_stack_free.restype = None
+        L.ia3_fit_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+class IA3Error(RuntimeError):
+    pass
+
+
+def check(rc, allow=()):
+    if rc == IA3_OK or rc in allow:
+        return rc
+    msg = lib().ia3_last_error().decode("utf-8", "replace")
+    if rc == IA3_EINVAL:
+        raise ValueError(msg)
+    if rc == IA3_ENOMEM:
+        raise MemoryError(msg)
+    if rc == IA3_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise IA3Error("libia3 error %d: %s" % (rc, msg))
+
+
+def dtype_code(arr):
+    if arr.dtype == np.uint16:
+        return IA3_U16
+    if arr.dtype == np.float32:
+        return IA3_F32
+    raise TypeError("imageanalysis3_amd kernels take uint16 or float32 stacks, got %s" % arr.dtype)
+
+
+def as_stack_array(im):
+    """C-contiguous uint16/float32 3-D view/copy of ``im`` (the caller's array is never modified)."""
+    if not isinstance(im, np.ndarray):
+        raise TypeError("image given should be a numpy.ndarray, but %s is given." % type(im))
+    if im.ndim != 3:
+        raise IndexError("a 3-D (z,x,y) stack is required, got ndim=%d" % im.ndim)
+    if im.dtype == np.uint8:
+        im = im.astype(np.uint16)
+    dtype_code(im)
+    return np.ascontiguousarray(im)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DeviceStack(object):
+    """A (Z,X,Y) stack resident in HBM (owner of an ``ia3_stack`` handle)."""
+
+    def __init__(self, handle, shape, dtype, keepalive=None):
+        self._h = handle
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self._keep = keepalive
+
+    @classmethod
+    def upload(cls, im):
+        a = as_stack_array(im)
+        h = C.c_void_p()
+        check(lib().ia3_stack_upload(ptr(a), dtype_code(a), a.shape[0], a.shape[1], a.shape[2], C.byref(h)))
+        return cls(h, a.shape, a.dtype)
+
+    @classmethod
+    def empty(cls, shape, dtype):
+        dt = np.dtype(dtype)
+        code = dtype_code(np.empty(0, dt))
+        h = C.c_void_p()
+        check(lib().ia3_stack_alloc(code, int(shape[0]), int(shape[1]), int(shape[2]), C.byref(h)))
+        return cls(h, shape, dt)
+
+    @classmethod
+    def wrap_torch(cls, t):
+        """Borrow the memory of a contiguous CUDA/HIP torch tensor (uint16 as int16/uint16, or float32)."""
+        import torch
+        if not t.is_cuda or not t.is_contiguous() or t.dim() != 3:
+            raise ValueError("need a contiguous 3-D device tensor")
+        if t.dtype == torch.float32:
+            dt = np.float32
+        elif t.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)):
+            dt = np.uint16
+        else:
+            raise TypeError("unsupported tensor dtype %s" % t.dtype)
+        h = C.c_void_p()
+        code = IA3_F32 if dt == np.float32 else IA3_U16
+        check(lib().ia3_stack_wrap(C.c_void_p(t.data_ptr()), code, t.shape[0], t.shape[1], t.shape[2], C.byref(h)))
+        return cls(h, tuple(t.shape), dt, keepalive=t)
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().ia3_stack_download(self._h, ptr(out)))
+        return out
+
+    def free(self):
+        if self._h is not None:
+            lib().ia3_stack_free(self._h)
+            self._h = None
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+
+def gaussian_taps(sigma, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(order=0) — the taps SciPy would use, from NumPy on
+    this host, handed to the kernels verbatim."""
+    sigma = float(sigma)
+    radius = int(float(truncate) * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return np.ascontiguousarray(phi / phi.sum(), dtype=np.float64), radius
+
+
+def make_seed_params(th_seed, gfilt_size=0.75, background_gfilt_size=7.5, filt_size=3, min_edge_distance=2,
+                     use_dynamic_th=True, dynamic_niters=10, min_dynamic_seeds=1, remove_hot_pixel=True,
+                     hot_pixel_th=3, max_num_seeds=None):
+    """Build an ia3_seed_params (+ the arrays it points to, which the caller must keep alive)."""
+    keep = []
+    p = SeedParams()
+    p.th_seed = float(th_seed)
+    # NumPy >= 2 promotion: a Python float/int threshold is a weak scalar (compare in float32), a
+    # NumPy float64 scalar is strong (compare in float64); float32/16 scalars compare in float32.
+    strong64 = isinstance(th_seed, np.floating) and np.dtype(type(th_seed)).itemsize >= 8
+    p.th_compare_f32 = 0 if strong64 else 1
+    p.gfilt_size = float(gfilt_size) if gfilt_size else 0.0
+    p.background_gfilt_size = float(background_gfilt_size) if background_gfilt_size else 0.0
+    p.filt_size = int(filt_size)
+    p.min_edge_distance = int(np.ceil(min_edge_distance)) if min_edge_distance > 0 else 0
+    p.use_dynamic_th = 1 if use_dynamic_th else 0
+    p.dynamic_niters = int(dynamic_niters)
+    p.min_dynamic_seeds = int(min_dynamic_seeds)
+    p.remove_hot_pixel = 1 if remove_hot_pixel else 0
+    p.hot_pixel_th = int(hot_pixel_th)
+    p.max_num_seeds = int(max_num_seeds) if (max_num_seeds is not None and max_num_seeds > 0) else 0
+    if p.gfilt_size > 0:
+        w, r = gaussian_taps(p.gfilt_size)
+        keep.append(w)
+        p.w_front, p.r_front = dptr(w), r
+    if p.background_gfilt_size > 0:
+        w, r = gaussian_taps(p.background_gfilt_size)
+        keep.append(w)
+        p.w_back, p.r_back = dptr(w), r
+    return p, keep
+
+
+def make_fit_params(radius_fit=5, min_delta_center=1., max_delta_center=2.5, n_max_iter=10, max_dist_th=0.1,
+                    min_w=0.5, max_w=4, init_w=1.5):
+    p = FitParams()
+    p.radius_fit = int(radius_fit)
+    p.min_delta_center = float(min_delta_center)
+    p.max_delta_center = float(max_delta_center)
+    p.n_max_iter = int(n_max_iter)
+    p.max_dist_th = float(max_dist_th)
+    p.min_w, p.max_w, p.init_w = float(min_w), float(max_w), float(init_w)
+    return p

@@ -1,0 +1,74 @@
+// Internal runtime of libia3.so: lazy per-process HIP context, error reporting, cached device
+// scratch, stack handles.  One HIP stream per process (SURVEY.md §8b "Threading").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/ia3.h"
+
+struct ia3_stack {
+  void* d;        // device pointer
+  int dtype, Z, X, Y;
+  bool owned;
+  size_t bytes;
+};
+
+namespace ia3rt {
+
+int set_error(int code, const char* fmt, ...);
+int ensure_init();
+hipStream_t stream();
+inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
+
+// Cached device scratch: get(bytes) returns a buffer that stays valid until put(); buffers are
+// reused across calls (hipMalloc of ~GB blocks costs milliseconds).
+void* ws_get(size_t bytes);
+void ws_put(void* p);
+void ws_release_all();
+
+struct Scratch {  // RAII
+  void* p;
+  explicit Scratch(size_t bytes) : p(ws_get(bytes)) {}
+  ~Scratch() { if (p) ws_put(p); }
+  Scratch(const Scratch&) = delete;
+  Scratch& operator=(const Scratch&) = delete;
+  template <class T> T* as() const { return (T*)p; }
+};
+
+#define IA3_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return ia3rt::set_error(IA3_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                              __FILE__, __LINE__);                                         \
+  } while (0)
+
+#define IA3_KCHECK()                                                                       \
+  do {                                                                                     \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e != hipSuccess)                                                                  \
+      return ia3rt::set_error(IA3_EHIP, "kernel launch failed: %s (%s:%d)",                \
+                              hipGetErrorString(_e), __FILE__, __LINE__);                  \
+  } while (0)
+
+// scipy.ndimage._gaussian_kernel1d(order 0) incl. NumPy's pairwise summation order
+void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& radius);
+
+}  // namespace ia3rt
+
+// ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
+namespace ia3k {
+// separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.
+int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w, int radius, int mode,
+               void* dst, void* tmp);
+// out = im - low ; out[low > im] = 0   (correction_tools/filter.py:17-18)
+int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out);
+// get_seeds on a resident stack (seed.hip)
+struct SeedOut {
+  std::vector<double> zxyh;  // n x 4 [z,x,y,h], brightest first
+  double th_used;
+};
+int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out);
+}  // namespace ia3k

@@ -1,0 +1,194 @@
+// libia3.so runtime: context, errors, scratch cache, stack handles (host side of the C ABI).
+#include "ia3_rt.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <unistd.h>
+#include <mutex>
+
+namespace ia3rt {
+
+static thread_local char g_err[1024] = "";
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static pid_t g_pid = 0;
+static std::mutex g_mu;
+
+struct WsEntry { void* p; size_t bytes; bool busy; };
+static std::vector<WsEntry> g_ws;
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static int do_init(int device) {
+  // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
+  if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
+  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_device = -1; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(IA3_EHIP, "no HIP device available (%s); libia3 has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+  if (device < 0) {
+    const char* lr = getenv("LOCAL_RANK");
+    device = lr ? atoi(lr) % n : 0;
+  }
+  if (device >= n) return set_error(IA3_EINVAL, "device %d out of range (%d devices)", device, n);
+  IA3_HIP(hipSetDevice(device));
+  if (g_stream && g_pid == getpid()) { hipStreamDestroy(g_stream); g_stream = nullptr; }
+  IA3_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = device;
+  g_pid = getpid();
+  return IA3_OK;
+}
+
+int ensure_init() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return do_init(-1);
+}
+hipStream_t stream() { return g_stream; }
+
+void* ws_get(size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int best = -1;
+  for (size_t i = 0; i < g_ws.size(); ++i)
+    if (!g_ws[i].busy && g_ws[i].p && g_ws[i].bytes >= bytes &&
+        (best < 0 || g_ws[i].bytes < g_ws[best].bytes))
+      best = (int)i;
+  if (best >= 0 && g_ws[best].bytes <= 2 * bytes + (1 << 20)) { g_ws[best].busy = true; return g_ws[best].p; }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    for (auto& e : g_ws) if (!e.busy && e.p) { hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
+  }
+  for (auto& e : g_ws) if (!e.p) { e = {p, bytes, true}; return p; }
+  g_ws.push_back({p, bytes, true});
+  return p;
+}
+void ws_put(void* p) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& e : g_ws) if (e.p == p) { e.busy = false; return; }
+}
+void ws_release_all() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& e : g_ws) if (!e.busy && e.p) { hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+}
+
+// NumPy's pairwise sum for a contiguous double vector (numpy/_core/src/umath/loops_utils.h.src)
+static double np_pairwise(const double* a, int n) {
+  if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& radius) {
+  radius = (int)(truncate * sigma + 0.5);
+  double s2 = sigma * sigma;
+  w.resize(2 * radius + 1);
+  for (int i = -radius; i <= radius; ++i) w[i + radius] = exp(-0.5 / s2 * (double)(i * i));
+  double tot = np_pairwise(w.data(), (int)w.size());
+  for (auto& v : w) v = v / tot;
+}
+
+}  // namespace ia3rt
+
+using namespace ia3rt;
+
+extern "C" {
+
+int ia3_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return do_init(device);
+}
+const char* ia3_last_error(void) { return g_err; }
+const char* ia3_version(void) { return "ia3-mi355x 0.1.0 (gfx950)"; }
+int ia3_device_name(char* buf, int len) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  IA3_HIP(hipGetDeviceProperties(&prop, g_device));
+  snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return IA3_OK;
+}
+int ia3_sync(void) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  IA3_HIP(hipStreamSynchronize(g_stream));
+  return IA3_OK;
+}
+void* ia3_stream(void) { return ensure_init() ? nullptr : (void*)g_stream; }
+int ia3_release_workspace(void) { ws_release_all(); return IA3_OK; }
+
+static int check_shape(int dtype, int Z, int X, int Y) {
+  if (dtype != IA3_U16 && dtype != IA3_F32) return set_error(IA3_EINVAL, "unsupported dtype code %d", dtype);
+  if (Z <= 0 || X <= 0 || Y <= 0) return set_error(IA3_EINVAL, "bad stack shape (%d,%d,%d)", Z, X, Y);
+  return IA3_OK;
+}
+
+int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  rc = check_shape(dtype, Z, X, Y); if (rc) return rc;
+  size_t bytes = (size_t)Z * X * Y * esize(dtype);
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes};
+  return IA3_OK;
+}
+int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out) {
+  if (!host) return set_error(IA3_EINVAL, "null host pointer");
+  int rc = ia3_stack_alloc(dtype, Z, X, Y, out); if (rc) return rc;
+  hipError_t e = hipMemcpyAsync((*out)->d, host, (*out)->bytes, hipMemcpyHostToDevice, g_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+  if (e != hipSuccess) {
+    ia3_stack_free(*out); *out = nullptr;
+    return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+  }
+  return IA3_OK;
+}
+int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  rc = check_shape(dtype, Z, X, Y); if (rc) return rc;
+  if (!devptr) return set_error(IA3_EINVAL, "null device pointer");
+  *out = new ia3_stack{devptr, dtype, Z, X, Y, false, (size_t)Z * X * Y * esize(dtype)};
+  return IA3_OK;
+}
+int ia3_stack_download(const ia3_stack* s, void* host) {
+  if (!s || !host) return set_error(IA3_EINVAL, "null argument");
+  IA3_HIP(hipMemcpyAsync(host, s->d, s->bytes, hipMemcpyDeviceToHost, g_stream));
+  IA3_HIP(hipStreamSynchronize(g_stream));
+  return IA3_OK;
+}
+int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void** devptr) {
+  if (!s) return set_error(IA3_EINVAL, "null stack");
+  if (dtype) *dtype = s->dtype;
+  if (Z) *Z = s->Z;
+  if (X) *X = s->X;
+  if (Y) *Y = s->Y;
+  if (devptr) *devptr = s->d;
+  return IA3_OK;
+}
+void ia3_stack_free(ia3_stack* s) {
+  if (!s) return;
+  if (s->owned && s->d) hipFree(s->d);
+  delete s;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// DoG local-maximum seeding (reference: spot_tools/fitting.py:20-165 get_seeds) for gfx950.
+//
+//   max_im = G_front(im), min_im = G_back(im)            (gauss.hip, exact ndimage arithmetic)
+//   mask   = (maxfilt_s(max_im) == max_im) & (minfilt_s(min_im) != min_im)      fitting.py:95,102
+//   diff   = float32(max_im) - float32(min_im)                                  fitting.py:106
+//   keep   diff >= th_i, d <= c <= size-d on every axis                         fitting.py:113-125,156-165
+// One pass produces the candidate list at the LOWEST dynamic threshold level, so the
+// dynamic-threshold loop (pick the first level with enough seeds) needs no second sweep.
+// Candidates are sparse (~1e-5 of the voxels): a wave ballots its hits, one lane reserves
+// space with a single atomic and the hits are written by prefix rank (wavefront ballot +
+// prefix-sum compaction).  The rest (np.where order, hot-column vote, sort by height,
+// truncation: fitting.py:131-150) runs on a few thousand records on the host.
+//
+// HBM traffic: the two filtered stacks are read once (8 B/voxel for f32); the 3x3x3 windows are
+// served by a rolling three-plane register pipeline along z plus L1/L2 hits for the in-plane
+// neighbours.
+#include "ia3_rt.h"
+#include <algorithm>
+#include <math.h>
+#include <string.h>
+
+namespace {
+
+struct Cand { int z, x, y; float h; };
+
+constexpr int MAXLEV = 64;
+struct Levels { double th[MAXLEV]; int n; };
+
+struct SeedCtl {            // device-resident counters
+  unsigned int n_cand;      // candidates found (may exceed capacity)
+  unsigned int overflow;
+};
+
+template <class T> __device__ __forceinline__ T ldc(const T* p, int z, int x, int y, int X, int Y) {
+  return p[((size_t)z * X + x) * Y + y];
+}
+
+// in-plane window max/min over [x+LO, x+HI] x [y+LO, y+HI] clipped to the image.  Clipping equals
+// scipy's default 'reflect' border for a rank filter: every reflected index is already in the window.
+template <class T, bool IS_MAX, int LO, int HI>
+__device__ __forceinline__ T plane_ext(const T* p, int z, int x, int y, int X, int Y) {
+  T r = ldc(p, z, x, y, X, Y);
+#pragma unroll
+  for (int dx = LO; dx <= HI; ++dx) {
+    int xx = min(max(x + dx, 0), X - 1);
+#pragma unroll
+    for (int dy = LO; dy <= HI; ++dy) {
+      int yy = min(max(y + dy, 0), Y - 1);
+      T v = ldc(p, z, xx, yy, X, Y);
+      r = IS_MAX ? (v > r ? v : r) : (v < r ? v : r);
+    }
+  }
+  return r;
+}
+
+// ZC output planes per thread; window of W taps [LO, HI] along every axis (W=3 -> -1..1).
+template <class T, int ZC, int W>
+__global__ __launch_bounds__(256) void seed_detect(const T* __restrict__ mx, const T* __restrict__ mn,
+                                                   int Z, int X, int Y, int edge, double th_low,
+                                                   Cand* __restrict__ out, unsigned capacity,
+                                                   SeedCtl* __restrict__ ctl) {
+  constexpr int LO = -(W / 2), HI = W - W / 2 - 1;
+  const int y = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int x = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int z0 = blockIdx.z * ZC;
+  const bool inside = (x < X) && (y < Y);
+  const int xs = inside ? x : 0, ys = inside ? y : 0;
+  T pmax[W], pmin[W];  // plane extrema for z+LO .. z+HI (rolling, statically indexed)
+#pragma unroll
+  for (int k = 0; k < W - 1; ++k) {
+    int zz = min(max(z0 + LO + k, 0), Z - 1);
+    pmax[k] = plane_ext<T, true, LO, HI>(mx, zz, xs, ys, X, Y);
+    pmin[k] = plane_ext<T, false, LO, HI>(mn, zz, xs, ys, X, Y);
+  }
+  for (int z = z0; z < z0 + ZC && z < Z; ++z) {
+    int zz = min(z + HI, Z - 1);
+    pmax[W - 1] = plane_ext<T, true, LO, HI>(mx, zz, xs, ys, X, Y);
+    pmin[W - 1] = plane_ext<T, false, LO, HI>(mn, zz, xs, ys, X, Y);
+    T vmax = pmax[0], vmin = pmin[0];
+#pragma unroll
+    for (int k = 1; k < W; ++k) { vmax = pmax[k] > vmax ? pmax[k] : vmax; vmin = pmin[k] < vmin ? pmin[k] : vmin; }
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) { pmax[k] = pmax[k + 1]; pmin[k] = pmin[k + 1]; }
+    const T cmax = ldc(mx, z, xs, ys, X, Y), cmin = ldc(mn, z, xs, ys, X, Y);
+    const float diff = (float)cmax - (float)cmin;
+    bool hit = inside && (vmax == cmax) && (vmin != cmin) && ((double)diff >= th_low);
+    if (edge > 0)
+      hit = hit && z >= edge && z <= Z - edge && x >= edge && x <= X - edge && y >= edge && y <= Y - edge;
+    const unsigned long long ballot = __ballot(hit);
+    if (ballot) {  // wave-uniform: ballot + prefix-rank compaction, one atomic per wave
+      const int lane = threadIdx.x & 63;
+      unsigned basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&ctl->n_cand, (unsigned)__popcll(ballot));
+      basepos = __shfl(basepos, 0);
+      if (hit) {
+        unsigned pos = basepos + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
+        if (pos < capacity) out[pos] = Cand{z, x, y, diff};
+        else ctl->overflow = 1;
+      }
+    }
+  }
+}
+
+template <class T>
+void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, int edge, double th_low,
+                   Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s) {
+  constexpr int ZC = 10;
+  dim3 g((unsigned)((Y + 63) / 64), (unsigned)((X + 3) / 4), (unsigned)((Z + ZC - 1) / ZC));
+#define IA3_SEED_CASE(WW)                                                                              \
+  case WW:                                                                                             \
+    hipLaunchKernelGGL((seed_detect<T, ZC, WW>), g, dim3(256), 0, s, (const T*)mx, (const T*)mn, Z, X, Y, \
+                       edge, th_low, out, capacity, ctl);                                              \
+    break;
+  switch (W) {
+    IA3_SEED_CASE(1) IA3_SEED_CASE(2) IA3_SEED_CASE(3) IA3_SEED_CASE(4)
+    IA3_SEED_CASE(5) IA3_SEED_CASE(6) IA3_SEED_CASE(7) IA3_SEED_CASE(8)
+  }
+#undef IA3_SEED_CASE
+}
+
+}  // namespace
+
+using namespace ia3rt;
+
+namespace ia3k {
+
+// Host tail of get_seeds: np.where order, level pick, hot columns, sort, truncate.
+static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed_params& p, int Y,
+                         SeedOut& o) {
+  // dynamic threshold: first level whose (edge-filtered) count reaches min_dynamic_seeds,
+  // else the last level (fitting.py:113-125: the loop variable keeps its last value)
+  int chosen = lev.n - 1;
+  for (int i = 0; i < lev.n; ++i) {
+    long long cnt = 0;
+    for (auto& k : c) cnt += ((double)k.h >= lev.th[i]);
+    if (cnt >= (long long)p.min_dynamic_seeds) { chosen = i; break; }
+  }
+  o.th_used = lev.th[chosen];
+  std::vector<Cand> s;
+  s.reserve(c.size());
+  for (auto& k : c) if ((double)k.h >= lev.th[chosen]) s.push_back(k);
+  std::sort(s.begin(), s.end(), [](const Cand& a, const Cand& b) {
+    if (a.z != b.z) return a.z < b.z;
+    if (a.x != b.x) return a.x < b.x;
+    return a.y < b.y;
+  });
+  if (p.remove_hot_pixel && !s.empty()) {  // fitting.py:131-138: drop (x,y) seen in >= hot_pixel_th planes
+    std::vector<long long> key(s.size());
+    for (size_t i = 0; i < s.size(); ++i) key[i] = (long long)s[i].x * (Y + 1) + s[i].y;
+    std::vector<long long> sorted(key);
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<Cand> kept;
+    for (size_t i = 0; i < s.size(); ++i) {
+      auto r = std::equal_range(sorted.begin(), sorted.end(), key[i]);
+      if ((r.second - r.first) < p.hot_pixel_th) kept.push_back(s[i]);
+    }
+    s.swap(kept);
+  }
+  // np.flipud(np.argsort(h)): ascending by h then reversed.  NumPy's quicksort is not stable, so
+  // the order inside groups of equal h is implementation-defined there; here: ties come out in
+  // descending np.where order (stable ascending sort, then flip).
+  std::stable_sort(s.begin(), s.end(), [](const Cand& a, const Cand& b) { return a.h < b.h; });
+  std::reverse(s.begin(), s.end());
+  if (p.max_num_seeds > 0 && (size_t)p.max_num_seeds <= s.size()) s.resize(p.max_num_seeds);
+  o.zxyh.resize(s.size() * 4);
+  for (size_t i = 0; i < s.size(); ++i) {
+    o.zxyh[4 * i + 0] = s[i].z; o.zxyh[4 * i + 1] = s[i].x; o.zxyh[4 * i + 2] = s[i].y; o.zxyh[4 * i + 3] = (double)s[i].h;
+  }
+}
+
+int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
+  hipStream_t s = stream();
+  const int Z = im->Z, X = im->X, Y = im->Y;
+  const size_t bytes = im->bytes;
+  if (p.filt_size < 1 || p.filt_size > 8) return set_error(IA3_EUNSUPPORTED, "filt_size %d not in 1..8", p.filt_size);
+  int niter = p.use_dynamic_th ? p.dynamic_niters : 1;
+  if (niter < 1) niter = 1;  // range(0) would leave _coords undefined in the reference
+  if (niter > MAXLEV) return set_error(IA3_EUNSUPPORTED, "dynamic_niters > %d", MAXLEV);
+  Levels lev;
+  lev.n = niter;
+  for (int i = 0; i < niter; ++i) {
+    double t = p.th_seed * (1 - (double)i / (double)niter);
+    lev.th[i] = p.th_compare_f32 ? (double)(float)t : t;
+  }
+  // filtered stacks
+  Scratch a(bytes), b(bytes), tmp(bytes);
+  if (!a.p || !b.p || !tmp.p) return IA3_ENOMEM;
+  const void* maxim = im->d;
+  const void* minim = im->d;
+  std::vector<double> w; int R, rc;
+  if (p.gfilt_size > 0) {
+    if (p.w_front) { w.assign(p.w_front, p.w_front + 2 * p.r_front + 1); R = p.r_front; }
+    else gaussian_taps(p.gfilt_size, 4.0, w, R);
+    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp.p);
+    if (rc) return rc;
+    maxim = a.p;
+  }
+  if (p.background_gfilt_size > 0) {
+    if (p.w_back) { w.assign(p.w_back, p.w_back + 2 * p.r_back + 1); R = p.r_back; }
+    else gaussian_taps(p.background_gfilt_size, 4.0, w, R);
+    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, b.p, tmp.p);
+    if (rc) return rc;
+    minim = b.p;
+  }
+  double th_low = lev.th[0];
+  for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
+  unsigned capacity = 1u << 20;
+  std::vector<Cand> cand;
+  SeedCtl hctl;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    Scratch ctl(sizeof(SeedCtl)), buf((size_t)capacity * sizeof(Cand));
+    if (!ctl.p || !buf.p) return IA3_ENOMEM;
+    IA3_HIP(hipMemsetAsync(ctl.p, 0, sizeof(SeedCtl), s));
+    if (im->dtype == IA3_F32)
+      launch_detect<float>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, buf.as<Cand>(),
+                           capacity, ctl.as<SeedCtl>(), s);
+    else
+      launch_detect<uint16_t>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, buf.as<Cand>(),
+                              capacity, ctl.as<SeedCtl>(), s);
+    IA3_KCHECK();
+    IA3_HIP(hipMemcpyAsync(&hctl, ctl.p, sizeof(SeedCtl), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipStreamSynchronize(s));
+    if (hctl.n_cand <= capacity) {
+      cand.resize(hctl.n_cand);
+      if (hctl.n_cand) {
+        IA3_HIP(hipMemcpyAsync(cand.data(), buf.p, (size_t)hctl.n_cand * sizeof(Cand), hipMemcpyDeviceToHost, s));
+        IA3_HIP(hipStreamSynchronize(s));
+      }
+      break;
+    }
+    if (attempt == 1) return set_error(IA3_ECAPACITY, "more than %u seed candidates", capacity);
+    capacity = hctl.n_cand + 1024;  // exact size known now; one retry
+  }
+  finish_seeds(cand, lev, p, Y, out);
+  return IA3_OK;
+}
+
+}  // namespace ia3k
+
+extern "C" {
+
+int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p, double* out_zxyh, int capacity,
+                     int* n_out, double* th_used) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !p || !n_out) return set_error(IA3_EINVAL, "null argument");
+  ia3k::SeedOut o;
+  rc = ia3k::dog_seed(im, *p, o); if (rc) return rc;
+  int n = (int)(o.zxyh.size() / 4);
+  *n_out = n;
+  if (th_used) *th_used = o.th_used;
+  if (n > capacity) return set_error(IA3_ECAPACITY, "seed buffer too small: need %d rows", n);
+  if (n && !out_zxyh) return set_error(IA3_EINVAL, "null output");
+  if (n) memcpy(out_zxyh, o.zxyh.data(), o.zxyh.size() * sizeof(double));
+  return IA3_OK;
+}
+
+int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_params* p,
+                 double* out_zxyh, int capacity, int* n_out, double* th_used) {
+  ia3_stack* a = nullptr;
+  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &a); if (rc) return rc;
+  rc = ia3_dog_seed_dev(a, p, out_zxyh, capacity, n_out, th_used);
+  ia3_stack_free(a);
+  return rc;
+}
+
+}  // extern "C"

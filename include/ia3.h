@@ -1,0 +1,146 @@
+/* ia3.h — C ABI of libia3.so: MI355X-native kernels for ImageAnalysis3's per-FOV spot-calling path.
+ *
+ * The reference has no FFI on this path (pure Python); these entry points are what
+ * thin ctypes shims carrying the reference's dotted names bind.  Each entry cites the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - stacks are C-order (Z, X, Y) ("z, x, y" = array axes 0,1,2), dtype IA3_U16 or IA3_F32;
+ *   - host pointers are borrowed for the duration of the call; outputs are caller-allocated;
+ *   - every function returns 0 on success or a negative IA3_E* code; ia3_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - device state is created lazily by the first call in a process (safe after fork);
+ *   - `ia3_stack` handles keep a stack resident in HBM so filter -> seed -> fit chain without
+ *     host round trips.
+ */
+#ifndef IA3_H
+#define IA3_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IA3_U16 0
+#define IA3_F32 1
+
+#define IA3_OK 0
+#define IA3_EINVAL (-1)   /* bad argument (shim raises ValueError / IndexError as the reference does) */
+#define IA3_EHIP (-2)     /* HIP runtime / kernel failure */
+#define IA3_ENOMEM (-3)
+#define IA3_ECAPACITY (-4) /* caller-provided output buffer too small; *n_out holds the needed size */
+#define IA3_EUNSUPPORTED (-5)
+
+#define IA3_MODE_REFLECT 0  /* scipy.ndimage 'reflect' (half-sample symmetric) */
+#define IA3_MODE_NEAREST 1  /* scipy.ndimage 'nearest' (edge replicate) */
+#define IA3_MODE_CONSTANT 2 /* map_coordinates 'constant' (cval) */
+
+typedef struct ia3_stack ia3_stack;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int ia3_init(int device);                 /* select device (default: LOCAL_RANK or 0); idempotent */
+const char* ia3_last_error(void);
+const char* ia3_version(void);
+int ia3_device_name(char* buf, int len);
+int ia3_sync(void);                       /* hipStreamSynchronize on the library stream */
+void* ia3_stream(void);                   /* hipStream_t the kernels are launched on */
+int ia3_release_workspace(void);          /* drop cached device scratch buffers */
+
+/* ---- device-resident stacks ----------------------------------------------------------------- */
+int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out);
+int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out);
+int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out); /* borrow device memory */
+int ia3_stack_download(const ia3_stack* s, void* host);
+int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void** devptr);
+void ia3_stack_free(ia3_stack* s);
+
+/* ---- filters ---------------------------------------------------------------------------------
+ * scipy.ndimage.gaussian_filter semantics: per axis 0,1,2 a 1-D correlation accumulated in
+ * float64 in NI_Correlate1D's order, re-quantised to the stack dtype after every axis (float32
+ * rounds, uint16 truncates).  `weights` (2*radius+1 doubles) may be NULL, then they are
+ * computed from (sigma, truncate) as scipy does.
+ * Replaces: scipy.ndimage.gaussian_filter as called at spot_tools/fitting.py:92,99 and
+ * correction_tools/filter.py:16. */
+int ia3_gaussian_filter(const void* im, int dtype, int Z, int X, int Y, double sigma, double truncate,
+                        int mode, const double* weights, int radius, void* out);
+int ia3_gaussian_filter_dev(const ia3_stack* im, double sigma, double truncate, int mode,
+                            const double* weights, int radius, ia3_stack* out);
+
+/* correction_tools/filter.py:14-19 gaussian_high_pass_filter(image, sigma=5, truncate=2):
+ * out = image - lowpass(nearest); out[lowpass > image] = 0, in the stack dtype. */
+int ia3_gaussian_highpass(const void* im, int dtype, int Z, int X, int Y, double sigma, double truncate,
+                          const double* weights, int radius, void* out);
+int ia3_gaussian_highpass_dev(const ia3_stack* im, double sigma, double truncate,
+                              const double* weights, int radius, ia3_stack* out);
+
+/* correction_tools/filter.py:22-42 Remove_Hot_Pixels (and its twin corrections.py:490-510):
+ * z-vote of im > hot_th * mean(4 rolled neighbours) -> column replaced by its 4-neighbour mean. */
+int ia3_remove_hot_pixels(const void* im, int dtype, int Z, int X, int Y, double hot_pix_th, double hot_th,
+                          void* out, int* n_hot);
+
+/* ---- seeding: spot_tools/fitting.py:20-154 get_seeds ------------------------------------------ */
+typedef struct ia3_seed_params {
+  double th_seed;               /* threshold on max_im - min_im */
+  double gfilt_size;            /* 0.75 ; 0 = no front filter */
+  double background_gfilt_size; /* 7.5  ; 0 = no background filter */
+  int filt_size;                /* 3 */
+  int min_edge_distance;        /* 2 */
+  int use_dynamic_th;           /* 1 */
+  int dynamic_niters;           /* 10 */
+  int min_dynamic_seeds;        /* 1 */
+  int remove_hot_pixel;         /* 1 */
+  int hot_pixel_th;             /* 3 */
+  int max_num_seeds;            /* <=0: unlimited */
+  int th_compare_f32;           /* 1: each threshold level is rounded to float32 before the compare
+                                   (NumPy>=2 weak-scalar rule for a Python-float th_seed, which is
+                                   what fit_fov_image's float(th_seed) produces); 0: float64 compare
+                                   (np.float64 th_seed, e.g. the percentile path) */
+  const double* w_front; int r_front; /* optional explicit taps (NULL: from sigma, truncate 4) */
+  const double* w_back;  int r_back;
+} ia3_seed_params;
+
+/* out_zxyh: capacity x 4 doubles [z,x,y,h], brightest first. */
+int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_params* p,
+                 double* out_zxyh, int capacity, int* n_out, double* th_used);
+int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p,
+                     double* out_zxyh, int capacity, int* n_out, double* th_used);
+
+/* ---- fitting: External/Fitting_v4.py:559-683 iter_fit_seed_points (+ GaussianFit :165-396) ---- */
+typedef struct ia3_fit_params {
+  int radius_fit;            /* 5 */
+  double min_delta_center;   /* 1.0  (firstfit) */
+  double max_delta_center;   /* 2.5  (repeatfit) */
+  int n_max_iter;            /* 10 */
+  double max_dist_th;        /* 0.1 */
+  double min_w, max_w, init_w; /* 0.5, 4, 1.5 */
+} ia3_fit_params;
+
+typedef struct ia3_fitter ia3_fitter;
+
+/* centers_zxy: n x 3 doubles (the reference's `centers.T`).  The stack must stay alive until
+ * ia3_fit_destroy. */
+int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const ia3_fit_params* p,
+                   ia3_fitter** out);
+int ia3_fit_first(ia3_fitter* f);                 /* .firstfit()  */
+int ia3_fit_repeat(ia3_fitter* f, int* n_iter);   /* .repeatfit() */
+/* ps: n x 11 float32 rows [h,z,x,y,bk,sz,sx,sy,sin_t,sin_p,eps] (NaN rows for failed fits);
+ * success: n bytes; nvox: n ints (voxels used by the last fit of each seed); any may be NULL. */
+int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox);
+int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev);
+void ia3_fit_destroy(ia3_fitter* f);
+
+/* one call: upload + firstfit + repeatfit */
+int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* centers_zxy, int n,
+                  const ia3_fit_params* p, float* out_ps, uint8_t* success, int* n_iter);
+
+/* seed + fit chained on a resident stack (the bench's hot path): fit_fov_image
+ * (spot_tools/fitting.py:169-262) without the optional normalisation.  out_rows: capacity x 11
+ * float32, NaN rows and out-of-image centres removed (fitting.py:232-237). */
+int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
+                    float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IA3_H */

@@ -494,26 +494,26 @@ class iter_fit_seed_points(object):
 # ----------------------------------------------------------------------------------------------
 
 
-def find_image_background(im, dtype=np.uint16, bin_size=10, make_plot=False, max_iter=10):
-    """io_tools/load.py:642-687 — histogram-peak background (first prominent peak)."""
+def find_image_background(im, dtype=np.uint16, bin_size=10, max_iter=10):
+    """io_tools/load.py:642-687 — histogram-peak background: highest peak found by
+    scipy.signal.find_peaks with a height threshold halved from size/50 until a peak exists."""
     from scipy.signal import find_peaks
     if dtype is None:
         dtype = im.dtype
-    cnt, bins = np.histogram(im, bins=np.arange(np.iinfo(dtype).min, np.iinfo(dtype).max, bin_size))
+    cts, bins = np.histogram(im, bins=np.arange(np.iinfo(dtype).min, np.iinfo(dtype).max, bin_size))
     peaks = []
-    prom = 0.3
+    height = np.size(im) / 50
     it = 0
     while len(peaks) == 0:
-        prom = prom * 0.5
+        height = height / 2
+        peaks, params = find_peaks(cts, height=height)
         it += 1
-        peaks, _ = find_peaks(cnt, prominence=np.max(cnt) * prom, width=2, height=np.max(cnt) * 0.5)
         if it > max_iter:
             break
-    if len(peaks) == 0:
-        peaks = np.array([np.argmax(cnt)])
-    sel = np.argmax(cnt[peaks])
-    sel_peak = peaks[sel]
-    return (bins[sel_peak] + bins[sel_peak + 1]) / 2
+    if it > max_iter:
+        return np.nanmedian(im)
+    sel = peaks[np.argmax(params['peak_heights'])]
+    return (bins[sel] + bins[sel + 1]) / 2
 
 
 def fit_fov_image(im, channel=None, seeds=None, seed_mask=None, max_num_seeds=500, th_seed=300,

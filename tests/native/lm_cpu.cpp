@@ -1,0 +1,53 @@
+// TEST INFRASTRUCTURE — host build of the product's LM core (csrc/ia3_lm.h + ia3_model.h) so the
+// solver logic can be checked against scipy.optimize.leastsq (MINPACK) on the CPU, without a GPU.
+// Not shipped, not a fallback: the product path (libia3.so) only runs the HIP kernels.
+#include <algorithm>
+#include <vector>
+#include <cmath>
+#include "../../imageanalysis3_amd/csrc/ia3_lm.h"
+#include "../../imageanalysis3_amd/csrc/ia3_init.h"
+
+using namespace ia3;
+
+struct CpuEval {
+  const float* im; const double* cz; const double* cx; const double* cy; int n; FitCfg cfg;
+  double eval(const double* x, double* A, double* g) {
+    Geom gm; make_geom(x, cfg, gm);
+    double ss = 0;
+    if (A) { for (int k = 0; k < NTRI; ++k) A[k] = 0; for (int k = 0; k < NP; ++k) g[k] = 0; }
+    for (int v = 0; v < n; ++v) {
+      double J[NP];
+      double F = A ? model_jac(gm, cz[v], cx[v], cy[v], J) : model_f0(gm, cz[v], cx[v], cy[v]);
+      double r = (gm.ebk_f + F) - (double)im[v];
+      ss += r * r;
+      if (A) {
+        for (int i = 0; i < NP; ++i) { g[i] += J[i] * r; for (int j = i; j < NP; ++j) A[tri(i, j)] += J[i] * J[j]; }
+      }
+    }
+    return sqrt(ss);
+  }
+};
+
+extern "C" int ia3cpu_gaussfit(const double* vals, const int* coords, int n, const double* center,
+                               double delta, double min_w, double max_w, double init_w, int kind,
+                               float* p_out, double* x_out, int* info_nfev) {
+  if (n < NP) return 1;
+  std::vector<float> im(n); std::vector<double> cz(n), cx(n), cy(n), sorted(vals, vals + n);
+  for (int v = 0; v < n; ++v) { im[v] = (float)vals[v]; cz[v] = coords[3 * v]; cx[v] = coords[3 * v + 1]; cy[v] = coords[3 * v + 2]; }
+  std::sort(sorted.begin(), sorted.end());
+  CpuEval ev; ev.im = im.data(); ev.cz = cz.data(); ev.cx = cx.data(); ev.cy = cy.data(); ev.n = n;
+  ev.cfg.min_ws = min_w * min_w; ev.cfg.max_ws = max_w * max_w; ev.cfg.delta = delta; ev.cfg.init_w = init_w;
+  for (int k = 0; k < 3; ++k) ev.cfg.c0[k] = center[k];
+  LMWork w;
+  init_guess(sorted.data(), sorted.data() + n - 10, kind, ev.cfg, w.x);
+  LMResult r = lm_solve(ev, w, 1.49012e-8, 1.49012e-8, 0.0, 1000, 100.0);
+  to_natural(w.x, ev.cfg, p_out);
+  // eps = mean |f - im| at the solution
+  Geom gm; make_geom(w.x, ev.cfg, gm);
+  double s = 0;
+  for (int v = 0; v < n; ++v) s += fabs((gm.ebk_f + model_f0(gm, cz[v], cx[v], cy[v])) - (double)im[v]);
+  p_out[10] = (float)(s / n);
+  for (int k = 0; k < NP; ++k) x_out[k] = w.x[k];
+  info_nfev[0] = r.info; info_nfev[1] = r.nfev; info_nfev[2] = r.iter;
+  return 0;
+}
