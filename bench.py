@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py — per-FOV spot calling (DoG seed + 3-D Gaussian LM fit) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
+torch.distributed.run (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1]: one 2048x2048x50 float32 FOV with ~5k spots per GPU per step
+(synthetic, repo generator G((50,2048,2048), 5000, seed 3+rank)), resident in HBM before the timed
+region.  A step = `fit_fov_image` semantics on that stack through the C ABI (`ia3_fit_fov_dev`:
+get_seeds -> firstfit -> repeatfit -> NaN/boundary row filters), spot table returned to the host.
+FOVs shard embarrassingly across ranks (weak scaling: one FOV per GPU per step); the only collective
+is the final all-gather of the padded spot table (+ counts), inside the timed region.
+
+value = fitted spots/s over all ranks; `fovs_per_sec` is reported beside it.
+roofline: the dominant kernel by HIP-event time on the library stream (see DESIGN.md §4 for the
+algorithmic bytes per launch); cpu_baseline: the NumPy/SciPy oracle (restatement of the reference's
+CPU path, pinned against it) timed on a crop of the same FOV on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SHAPE = (50, 2048, 2048)
+N_SPOTS = 5000
+TH_SEED = 600.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector peak (FMA = 2 flop)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", type=int, nargs=3, default=list(SHAPE))
+    ap.add_argument("--spots", type=int, default=N_SPOTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=384, help="x/y edge of the crop the CPU baseline runs on")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, shape, esize=4):
+    """ALGORITHMIC HBM bytes of one launch: every Gaussian axis pass reads and writes the
+    stack once (8 B/voxel for f32); seed_detect reads the two filtered stacks (8 B/voxel)."""
+    vox = float(shape[0]) * shape[1] * shape[2]
+    if kernel.startswith("gauss_axis"):
+        return 2 * esize * vox
+    if kernel == "seed_detect":
+        return 2 * esize * vox
+    return None
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.parallel import gather_spot_tables
+    import ctypes as C
+    lib = L.lib()
+    L.check(lib.ia3_init(local_rank))
+
+    shape = tuple(a.shape)
+    t0 = time.time()
+    im, centers, heights = synth.make_fov(shape, a.spots, 3 + rank)
+    gen_s = time.time() - t0
+    stack = L.DeviceStack.upload(im)
+    sp, keep = L.make_seed_params(TH_SEED, max_num_seeds=None)
+    fp = L.make_fit_params()
+    cap = max(4 * a.spots, 16384)
+    rows = np.empty((cap, 11), dtype=np.float32)
+
+    def step():
+        n_rows, n_seeds, n_iter = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(lib.ia3_fit_fov_dev(stack._h, C.byref(sp), C.byref(fp), L.ptr(rows), cap,
+                                    C.byref(n_rows), C.byref(n_seeds), C.byref(n_iter)))
+        return n_rows.value, n_seeds.value, n_iter.value
+
+    def barrier():
+        L.check(lib.ia3_sync())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    L.profile_enable(True)
+    L.profile_collect()
+    barrier()
+    t0 = time.perf_counter()
+    total_rows = 0
+    last = (0, 0, 0)
+    for _ in range(a.steps):
+        last = step()
+        total_rows += last[0]
+    # final spot-table all-gather (counts + padded [fovs, max_seeds, 11] f32), the path's only exchange
+    table = gather_spot_tables(rows[:last[0]], cap, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = L.profile_collect()
+    L.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt, float(total_rows)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rows_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, rows_all = dt, float(total_rows)
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt_max / a.steps * 1e3
+        # ---- roofline of the dominant kernel (HIP events on the library stream) --------------------
+        kern = sorted(prof.items(), key=lambda kv: -kv[1][1])
+        stage_ms = {k: v[1] / a.steps for k, v in prof.items()}
+        roof = None
+        hbm_kernels = [(k, v) for k, v in kern if algorithmic_bytes(k, shape) is not None]
+        dom_name, (dom_n, dom_ms) = kern[0]
+        if algorithmic_bytes(dom_name, shape) is None and hbm_kernels:
+            # the LM fit has no meaningful HBM figure (2 KB gathered per fit); report it in `fit`
+            # below and give the HBM roofline of the heaviest stack-streaming kernel
+            dom_name, (dom_n, dom_ms) = hbm_kernels[0]
+        if algorithmic_bytes(dom_name, shape) is not None:
+            avg_s = dom_ms / dom_n * 1e-3
+            ach = algorithmic_bytes(dom_name, shape) / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": dom_n,
+                    "note": "exact scipy.ndimage arithmetic (f64, no FMA) makes the Gaussian passes "
+                            "f64-VALU-bound: see valu_frac"}
+            if dom_name.startswith("gauss_axis"):
+                R = int(dom_name.split("_R")[1])
+                ops = (3 * R + 1) * float(shape[0]) * shape[1] * shape[2]   # add,mul,add per tap pair + 1
+                roof["valu_frac"] = round(ops / avg_s / (F64_VALU_PEAK_TFLOPS / 2 * 1e12), 4)
+        filt_seed_ms = sum(v for k, v in stage_ms.items() if k.startswith("gauss") or k == "seed_detect")
+        vox_bytes = 4.0 * shape[0] * shape[1] * shape[2]
+        out = {
+            "metric": "fitted spots/sec (+ FOVs/sec), 2048x2048x50 float32 stack, ~5k spots/FOV",
+            "value": round(rows_all / dt_max, 1), "unit": "spots/s",
+            "fovs_per_sec": round(world * a.steps / dt_max, 3),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single %dx%dx%d float32 FOV, %d injected spots, DoG seed + LM fit"
+                                   % (shape[1], shape[2], shape[0], a.spots),
+                       "fovs_per_gpu_per_step": 1, "th_seed": TH_SEED, "parallelism": "fov-shard x%d" % world,
+                       "spots_per_fov": last[0], "seeds_per_fov": last[1], "repeat_sweeps": last[2],
+                       "gathered_table_rows": int(table.shape[0]) if table is not None else None},
+            "roofline": roof,
+            "stage_ms_per_fov": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
+            "filter_seed": {"ms_per_fov": round(filt_seed_ms, 4),
+                            "algorithmic_GBps": round(vox_bytes / (filt_seed_ms * 1e-3) / 1e9, 1) if filt_seed_ms else None,
+                            "frac_of_hbm_peak": round(vox_bytes / (filt_seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if filt_seed_ms else None},
+            "host_gen_s": round(gen_s, 1),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(im, a.cpu_crop)
+        elif not a.no_cpu_baseline:
+            out["cpu_baseline"] = None
+    stack.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(im, crop):
+    """The oracle (NumPy/SciPy restatement of the reference's CPU path: ndimage-exact filters, MINPACK
+    lmder through scipy.optimize.leastsq, Python loop over seeds — same structure and cost profile as the
+    reference) on a bounded crop of the same FOV, 1 process."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import np_oracle as O
+    sub = np.ascontiguousarray(im[:, :crop, :crop])
+    t0 = time.perf_counter()
+    t = O.fit_fov_image(sub, "647", th_seed=TH_SEED, max_num_seeds=None, voronoi="lowest_index")
+    dt = time.perf_counter() - t0
+    return {"value": round(len(t) / dt, 2), "unit": "spots/s", "cores": 1, "kind": "port",
+            "fovs_per_sec": round((crop * crop) / float(im.shape[1] * im.shape[2]) / dt, 5),
+            "seconds": round(dt, 1), "spots": int(len(t)),
+            "sample": "oracle fit_fov_image on the [0:%d, 0:%d, 0:%d] crop of the same FOV (%.1f%% of the voxels)"
+                      % (im.shape[0], crop, crop, 100.0 * crop * crop / (im.shape[1] * im.shape[2]))}
+
+
+if __name__ == "__main__":
+    main()

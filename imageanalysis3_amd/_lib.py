@@ -16,7 +16,7 @@ MODE_REFLECT, MODE_NEAREST, MODE_CONSTANT = 0, 1, 2
 
 EXPORTS = [
     "ia3_init", "ia3_last_error", "ia3_version", "ia3_device_name", "ia3_sync", "ia3_stream",
-    "ia3_release_workspace",
+    "ia3_release_workspace", "ia3_profile_enable", "ia3_profile_collect",
     "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
@@ -171,6 +171,21 @@ class DeviceStack(object):
 
     def __exit__(self, *a):
         self.free()
+
+
+def profile_enable(on=True):
+    check(lib().ia3_profile_enable(1 if on else 0))
+
+
+def profile_collect():
+    """{kernel: (launches, total_ms)} measured with HIP events on the library stream since the last call."""
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().ia3_profile_collect(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.rsplit(",", 2)
+        out[name] = (int(n), float(ms))
+    return out
 
 
 def gaussian_taps(sigma, truncate=4.0):

@@ -493,6 +493,7 @@ int ia3_fit_first(ia3_fitter* f) {
   if (!f) return set_error(IA3_EINVAL, "null fitter");
   if (f->n > 0) {
     FitArgs a = make_args(f);
+    ProfScope ps("fit_first");
     hipLaunchKernelGGL(fit_first_k, dim3((unsigned)f->n), dim3(64), 0, stream(), a, f->n);
     IA3_KCHECK();
   }
@@ -508,8 +509,11 @@ int ia3_fit_repeat(ia3_fitter* f, int* n_iter) {
     FitArgs a = make_args(f);
     IA3_HIP(hipMemsetAsync(f->d_conv, 0, (size_t)f->n, stream()));
     IA3_HIP(hipMemsetAsync(f->d_niter, 0, sizeof(int), stream()));
-    hipLaunchKernelGGL(fit_repeat_k, dim3((unsigned)f->n_comp), dim3(64), 0, stream(), a,
-                       (const int*)f->d_comp_off, (const int*)f->d_comp_mem, f->n_comp);
+    {
+      ProfScope ps("fit_repeat");
+      hipLaunchKernelGGL(fit_repeat_k, dim3((unsigned)f->n_comp), dim3(64), 0, stream(), a,
+                         (const int*)f->d_comp_off, (const int*)f->d_comp_mem, f->n_comp);
+    }
     IA3_KCHECK();
     IA3_HIP(hipMemcpyAsync(&it, f->d_niter, sizeof(int), hipMemcpyDeviceToHost, stream()));
     IA3_HIP(hipStreamSynchronize(stream()));

@@ -159,18 +159,23 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   hipLaunchKernelGGL(border_map_k, dim3((cz + 255) / 256), dim3(256), 0, s, mz, cz, R, Z, mode);
   hipLaunchKernelGGL(border_map_k, dim3((cx + 255) / 256), dim3(256), 0, s, mx, cx, R, X, mode);
   hipLaunchKernelGGL(border_map_k, dim3((cy + 255) / 256), dim3(256), 0, s, my, cy, R, Y, mode);
+  static const std::string nz = "gauss_axis0_R" + std::to_string(R), nx = "gauss_axis1_R" + std::to_string(R),
+                           ny = "gauss_axis2_R" + std::to_string(R);
   // axis 0: src -> dst
   {
+    ia3rt::ProfScope ps(nz.c_str());
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + KS - 1) / KS));
     hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz);
   }
   // axis 1: dst -> tmp
   {
+    ia3rt::ProfScope ps(nx.c_str());
     dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + KS - 1) / KS));
     hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx);
   }
   // axis 2: tmp -> dst
   {
+    ia3rt::ProfScope ps(ny.c_str());
     dim3 g((unsigned)((Y + 256 * KC - 1) / (256 * KC)), (unsigned)(Z * X), 1);
     hipLaunchKernelGGL((gauss_contig<T, R, KC>), g, dim3(256), 0, s, (const T*)tmp, dst, Y, t, (const int*)my);
   }
@@ -243,6 +248,7 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
 
 int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out) {
   hipStream_t s = ia3rt::stream();
+  ia3rt::ProfScope ps("highpass_combine");
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (dtype == IA3_F32)

@@ -53,6 +53,14 @@ struct Scratch {  // RAII
                               hipGetErrorString(_e), __FILE__, __LINE__);                  \
   } while (0)
 
+// Optional per-kernel timing with HIP events on the library stream (ia3_profile_*): bench.py
+// derives roofline.achieved from these, rocprofv3 must agree.
+struct ProfScope {
+  int slot;
+  explicit ProfScope(const char* name);
+  ~ProfScope();
+};
+
 // scipy.ndimage._gaussian_kernel1d(order 0) incl. NumPy's pairwise summation order
 void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& radius);
 

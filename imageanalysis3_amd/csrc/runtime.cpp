@@ -82,6 +82,24 @@ void ws_release_all() {
   for (auto& e : g_ws) if (!e.busy && e.p) { hipFree(e.p); e.p = nullptr; e.bytes = 0; }
 }
 
+// ---- profiling ----------------------------------------------------------------------------------
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+
+ProfScope::ProfScope(const char* name) : slot(-1) {
+  if (!g_prof || !g_stream) return;
+  ProfRec r;
+  r.name = name;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, g_stream);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, g_stream);
+}
+
 // NumPy's pairwise sum for a contiguous double vector (numpy/_core/src/umath/loops_utils.h.src)
 static double np_pairwise(const double* a, int n) {
   if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
@@ -136,6 +154,36 @@ int ia3_sync(void) {
 }
 void* ia3_stream(void) { return ensure_init() ? nullptr : (void*)g_stream; }
 int ia3_release_workspace(void) { ws_release_all(); return IA3_OK; }
+
+int ia3_profile_enable(int on) {
+  int rc = ensure_init(); if (rc) return rc;
+  g_prof = on != 0;
+  return IA3_OK;
+}
+// Writes "name,count,total_ms\n" lines for everything recorded since the last call, and clears.
+int ia3_profile_collect(char* buf, int len) {
+  int rc = ensure_init(); if (rc) return rc;
+  IA3_HIP(hipStreamSynchronize(g_stream));
+  struct Agg { const char* name; int n; double ms; };
+  std::vector<Agg> agg;
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    bool found = false;
+    for (auto& a : agg) if (strcmp(a.name, r.name) == 0) { a.n++; a.ms += ms; found = true; break; }
+    if (!found) agg.push_back({r.name, 1, (double)ms});
+  }
+  g_recs.clear();
+  int off = 0;
+  if (buf && len > 0) buf[0] = 0;
+  for (auto& a : agg) {
+    int w = snprintf(buf + off, off < len ? len - off : 0, "%s,%d,%.6f\n", a.name, a.n, a.ms);
+    if (w < 0 || off + w >= len) break;
+    off += w;
+  }
+  return IA3_OK;
+}
 
 static int check_shape(int dtype, int Z, int X, int Y) {
   if (dtype != IA3_U16 && dtype != IA3_F32) return set_error(IA3_EINVAL, "unsupported dtype code %d", dtype);

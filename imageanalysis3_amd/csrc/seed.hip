@@ -211,6 +211,7 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
     Scratch ctl(sizeof(SeedCtl)), buf((size_t)capacity * sizeof(Cand));
     if (!ctl.p || !buf.p) return IA3_ENOMEM;
     IA3_HIP(hipMemsetAsync(ctl.p, 0, sizeof(SeedCtl), s));
+    ProfScope ps("seed_detect");
     if (im->dtype == IA3_F32)
       launch_detect<float>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, buf.as<Cand>(),
                            capacity, ctl.as<SeedCtl>(), s);

@@ -46,6 +46,9 @@ int ia3_device_name(char* buf, int len);
 int ia3_sync(void);                       /* hipStreamSynchronize on the library stream */
 void* ia3_stream(void);                   /* hipStream_t the kernels are launched on */
 int ia3_release_workspace(void);          /* drop cached device scratch buffers */
+/* per-kernel timing with HIP events on the library stream (off by default) */
+int ia3_profile_enable(int on);
+int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines since last collect */
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out);
