@@ -24,6 +24,8 @@ EXPORTS = [
     "ia3_dog_seed", "ia3_dog_seed_dev",
     "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_results", "ia3_fit_stats",
     "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev",
+    "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
+    "ia3_stack_crop",
 ]
 
 
@@ -148,6 +150,16 @@ class DeviceStack(object):
         code = IA3_F32 if dt == np.float32 else IA3_U16
         check(lib().ia3_stack_wrap(C.c_void_p(t.data_ptr()), code, t.shape[0], t.shape[1], t.shape[2], C.byref(h)))
         return cls(h, tuple(t.shape), dt, keepalive=t)
+
+    def crop(self, lims):
+        """New resident stack = self[z0:z1, x0:x1, y0:y1]; ``lims`` is a (3,2) [start, stop) array."""
+        l = np.array(lims, dtype=int)
+        l[:, 0] = np.maximum(l[:, 0], 0)
+        l[:, 1] = np.minimum(l[:, 1], np.array(self.shape))
+        h = C.c_void_p()
+        check(lib().ia3_stack_crop(self._h, int(l[0, 0]), int(l[0, 1]), int(l[1, 0]), int(l[1, 1]),
+                                   int(l[2, 0]), int(l[2, 1]), C.byref(h)))
+        return DeviceStack(h, tuple(int(b - a) for a, b in l), self.dtype)
 
     def download(self):
         out = np.empty(self.shape, dtype=self.dtype)

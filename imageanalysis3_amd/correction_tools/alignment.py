@@ -1,0 +1,211 @@
+"""Drop-in for the hot-path part of the reference's ``correction_tools/alignment.py``:
+``generate_drift_crops`` (:87-135), ``align_beads`` (:139-216), ``align_image`` (:527-695), plus
+``phase_cross_correlation`` (scikit-image's function as the reference calls it at :631) on the device.
+
+Both stacks are uploaded once; the <= 8 drift crops are cut on the device (``ia3_stack_crop``) and each
+crop is aligned by rocFFT phase correlation + upsampled DFT, or by bead fitting + FFT rough shift.
+"""
+import ctypes as C
+import time
+import numpy as np
+
+from .. import _lib as L
+from .. import _allowed_colors, _image_size, _num_buffer_frames, _num_empty_frames, _correction_folder
+
+# "phase" is scikit-image's default since 0.19; the reference pins no version, set to
+# None to get the un-normalised correlation of scikit-image 0.17/0.18.
+DEFAULT_NORMALIZATION = "phase"
+
+
+def _find_boundary(_ct, _radius, _im_size):
+    """correction_tools/alignment.py:80-85."""
+    return np.array([[max(_c - _radius, 0), min(_c + _radius, _sz)] for _c, _sz in zip(_ct, _im_size)], dtype=int)
+
+
+def generate_drift_crops(single_im_size=_image_size, coord_sel=None, drift_size=None):
+    """correction_tools/alignment.py:87-135 — 8 crops (8,3,2) around quarter/half anchor points."""
+    _single_im_size = np.array(single_im_size)
+    if coord_sel is None:
+        coord_sel = np.array(_single_im_size / 2, dtype=int)
+    if coord_sel[-2] >= _single_im_size[-2] or coord_sel[-1] >= _single_im_size[-1]:
+        raise ValueError(f"wrong input coord_sel:{coord_sel}, should be smaller than single_im_size:{single_im_size}")
+    if drift_size is None:
+        drift_size = int(np.max(_single_im_size) / 4)
+    _cz, _cx, _cy = coord_sel[-3] / 2, coord_sel[-2], coord_sel[-1]
+    _sx, _sy = _single_im_size[-2], _single_im_size[-1]
+    crop_cts = [
+        (_cz, _cx / 2, _cy / 2), (_cz, (_cx + _sx) / 2, (_cy + _sy) / 2),
+        (_cz, (_cx + _sx) / 2, _cy / 2), (_cz, _cx / 2, (_cy + _sy) / 2),
+        (_cz, _cx, _cy / 2), (_cz, _cx, (_cy + _sy) / 2),
+        (_cz, _cx / 2, _cy), (_cz, (_cx + _sx) / 2, _cy),
+    ]
+    return np.array([_find_boundary(_ct, _radius=drift_size / 2, _im_size=single_im_size) for _ct in crop_cts])
+
+
+def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, normalization="default", **kwargs):
+    """skimage.registration.phase_cross_correlation for 3-D stacks on the device (rocFFT).
+    Returns (shift, error, phasediff).  Inputs: ndarrays (uint16/float32) or DeviceStacks."""
+    if normalization == "default":
+        normalization = DEFAULT_NORMALIZATION
+    if normalization not in ("phase", None):
+        raise ValueError("normalization must be either 'phase' or None")
+    _norm = 1 if normalization == "phase" else 0
+    shift = (C.c_double * 3)()
+    err, ph = C.c_double(0), C.c_double(0)
+    if isinstance(reference_image, L.DeviceStack) and isinstance(moving_image, L.DeviceStack):
+        L.check(L.lib().ia3_phase_xcorr3d_dev(reference_image._h, moving_image._h, int(upsample_factor), _norm,
+                                              shift, C.byref(err), C.byref(ph)))
+    else:
+        a, b = L.as_stack_array(reference_image), L.as_stack_array(moving_image)
+        if a.shape != b.shape:
+            raise ValueError("images must be same shape")
+        if a.dtype != b.dtype:
+            b = b.astype(a.dtype)
+        L.check(L.lib().ia3_phase_xcorr3d(L.ptr(a), L.ptr(b), L.dtype_code(a), a.shape[0], a.shape[1], a.shape[2],
+                                          int(upsample_factor), _norm, shift, C.byref(err), C.byref(ph)))
+    return np.array([shift[0], shift[1], shift[2]]), float(err.value), float(ph.value)
+
+
+def align_beads(tar_cts, ref_cts,
+                tar_im=None, ref_im=None,
+                use_fft=True, fft_filt_size=0,
+                match_distance_th=2.,
+                check_paired_cts=True,
+                outlier_sigma=1.5,
+                return_paired_cts=True,
+                verbose=True):
+    """correction_tools/alignment.py:139-216 — mean shift of uniquely paired bead centres after an FFT
+    rough alignment of the two crops."""
+    _tar_cts = np.array(tar_cts)
+    _ref_cts = np.array(ref_cts)
+    _distance_th = float(match_distance_th)
+    from ..alignment_tools import fft3d_from2d
+    from ..spot_tools.matching import find_paired_centers, check_paired_centers
+    if not use_fft:
+        raise NotImplementedError("use_fft=False (alignment_tools.translation_align_pts brute-force matching) "
+                                  "is off the production path (alignment.py:653) and not provided")
+    if tar_im is None or ref_im is None:
+        raise ValueError("both tar_im and ref_im should be given if use FFT!")
+    if np.shape(tar_im) != np.shape(ref_im):
+        raise IndexError(f"tar_im shape:{np.shape(tar_im)} should match ref_im shape:{np.shape(ref_im)}")
+    _rough_drift = fft3d_from2d(tar_im, ref_im, gb=fft_filt_size, max_disp=np.max(np.shape(tar_im)) / 2)
+    _drift, _paired_tar_cts, _paired_ref_cts = find_paired_centers(
+        _tar_cts, _ref_cts, _rough_drift, cutoff=_distance_th, return_paired_cts=True, verbose=verbose)
+    if verbose:
+        print("before check:", _drift, len(_paired_ref_cts))
+    if check_paired_cts and len(_paired_ref_cts) > 3:
+        _drift, _paired_tar_cts, _paired_ref_cts = check_paired_centers(
+            _paired_tar_cts, _paired_ref_cts, outlier_sigma=outlier_sigma, return_paired_cts=True, verbose=verbose)
+    _return_args = [_drift]
+    if return_paired_cts:
+        _return_args += [_paired_tar_cts, _paired_ref_cts]
+    return tuple(_return_args)
+
+
+_default_align_corr_args = {
+    'single_im_size': _image_size, 'num_buffer_frames': _num_buffer_frames, 'num_empty_frames': _num_empty_frames,
+    'correction_folder': _correction_folder, 'illumination_corr': True, 'bleed_corr': False,
+    'chromatic_corr': False, 'z_shift_corr': False, 'hot_pixel_corr': True, 'normalization': False,
+}
+
+_default_align_fitting_args = {
+    'th_seed': 300, 'th_seed_per': 95, 'use_percentile': False, 'use_dynamic_th': True,
+    'min_dynamic_seeds': 10, 'max_num_seeds': 200,
+}
+
+
+def align_image(
+        src_im: np.ndarray,
+        ref_im: np.ndarray,
+        crop_list=None,
+        use_autocorr=True, precision_fold=100,
+        min_good_drifts=3, drift_diff_th=1.,
+        all_channels=_allowed_colors,
+        ref_all_channels=None,
+        drift_channel='488',
+        correction_args={},
+        fitting_args={},
+        match_distance_th=2.,
+        verbose=True,
+        detailed_verbose=False,
+):
+    """correction_tools/alignment.py:527-695 — per-crop sub-pixel drift + 3-of-n consensus.
+    Returns (drift (3,) float64, flag): drift = ref - src (add to source coordinates); flag 1 = the
+    crops disagreed and the mean of the three mutually closest drifts is returned.
+
+    ndarray inputs only: loading .dax files (``correct_fov_image``) is the caller's job."""
+    from ..spot_tools.fitting import fit_fov_image, select_sparse_centers
+    _correction_args = {_k: _v for _k, _v in _default_align_corr_args.items()}
+    _correction_args.update(correction_args)
+    _fitting_args = {_k: _v for _k, _v in _default_align_fitting_args.items()}
+    _fitting_args.update(fitting_args)
+    if not isinstance(src_im, np.ndarray) or not isinstance(ref_im, np.ndarray):
+        raise IOError(f"Wrong input file type, {type(src_im)} / {type(ref_im)} should be np.ndarray "
+                      "(.dax loading is outside the accelerated path)")
+    if np.shape(src_im) != np.shape(ref_im):
+        raise IndexError(f"shape of target image:{np.shape(src_im)} and reference image:{np.shape(ref_im)} doesnt match!")
+    if crop_list is None:
+        _size = correction_args.get('single_im_size', np.shape(src_im))
+        crop_list = generate_drift_crops(_size)
+    for _crop in crop_list:
+        if np.shape(np.array(_crop)) != (3, 2):
+            raise IndexError("crop should be 3x2 np.ndarray.")
+    _all_channels = [str(_ch) for _ch in all_channels]
+    if str(drift_channel) not in _all_channels:
+        raise ValueError(f"bead channel {drift_channel} not exist in all channels given:{_all_channels}")
+    if verbose:
+        print("-- start aligning given source image to given reference image.")
+    _src = L.DeviceStack.upload(src_im)
+    _ref = L.DeviceStack.upload(ref_im if ref_im.dtype == src_im.dtype else ref_im.astype(src_im.dtype))
+    _result_flag = 0
+    _drifts = []
+    _updated_mean_dft = None
+    try:
+        for _i, _crop in enumerate(crop_list):
+            _start_time = time.time()
+            _lims = np.array(_crop, dtype=int)
+            _sim, _rim = _src.crop(_lims), _ref.crop(_lims)
+            try:
+                if use_autocorr:
+                    _dft, _error, _phasediff = phase_cross_correlation(_rim, _sim, upsample_factor=precision_fold)
+                else:
+                    _sl = tuple(slice(*_l) for _l in _lims)
+                    _src_spots = fit_fov_image(src_im[_sl], drift_channel, verbose=detailed_verbose, **_fitting_args)
+                    _sp_src_cts = select_sparse_centers(_src_spots[:, 1:4], match_distance_th)
+                    _ref_spots = fit_fov_image(ref_im[_sl], drift_channel, verbose=detailed_verbose, **_fitting_args)
+                    _sp_ref_cts = select_sparse_centers(_ref_spots[:, 1:4], match_distance_th, verbose=detailed_verbose)
+                    _dft, _paired_src_cts, _paired_ref_cts = align_beads(
+                        _sp_src_cts, _sp_ref_cts, _sim, _rim, use_fft=True, match_distance_th=match_distance_th,
+                        return_paired_cts=True, verbose=detailed_verbose)
+                    _dft = _dft * -1  # beads center is the opposite as cross correlation (:658)
+            finally:
+                _sim.free()
+                _rim.free()
+            _drifts.append(_dft)
+            if verbose:
+                print(f"-- drift {_i}: {np.around(_dft, 2)} in {time.time()-_start_time:.3f}s.")
+            _mean_dft = np.nanmean(_drifts, axis=0)                                       # :664-674
+            if len(_drifts) >= min_good_drifts:
+                _dists = np.linalg.norm(_drifts - _mean_dft, axis=1)
+                _kept_drift_inds = np.where(_dists <= drift_diff_th)[0]
+                if len(_kept_drift_inds) >= min_good_drifts:
+                    _updated_mean_dft = np.nanmean(np.array(_drifts)[_kept_drift_inds], axis=0)
+                    if verbose:
+                        print(f"--- drifts for crops:{_kept_drift_inds} pass the thresold, exit cycle.")
+                    break
+    finally:
+        _src.free()
+        _ref.free()
+    if _updated_mean_dft is None:                                                          # :676-693
+        if verbose:
+            print("-- return a sub-optimal drift")
+        _drifts = np.array(_drifts)
+        from scipy.spatial.distance import pdist, squareform
+        _dist_mat = squareform(pdist(_drifts))
+        np.fill_diagonal(_dist_mat, np.inf)
+        _sel_inds = np.array(np.unravel_index(np.argmin(_dist_mat), np.shape(_dist_mat)))
+        _sel_drifts = list(_drifts[_sel_inds])
+        _sel_drifts.append(_drifts[np.argmin(_dist_mat[:, _sel_inds].sum(1))])
+        _updated_mean_dft = np.nanmean(_sel_drifts, axis=0)
+        _result_flag += 1
+    return _updated_mean_dft, _result_flag

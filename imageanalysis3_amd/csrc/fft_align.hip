@@ -1,0 +1,489 @@
+// Drift estimation on the device (rocFFT through the hipFFT API, float64).
+//
+//  (a10) alignment_tools.py:286-353 fftalign_2d / fft3d_from2d — integer shift from max-projections:
+//        normalised full cross-correlation (fftconvolve with the flipped target), argmax inside a
+//        ±max_disp window.  z-max projection = one HBM pass over each stack.
+//  (a9)  skimage.registration.phase_cross_correlation as called at correction_tools/alignment.py:631 —
+//        published algorithm (Guizar-Sicairos et al. 2008): cross-power spectrum, integer peak, then a
+//        matrix-multiply upsampled DFT in a ceil(1.5·u)³ window around it.  PARITY UNPINNED (scikit-image
+//        is an un-vendored, un-pinned dependency of the reference); validated by known-answer tests.
+//
+// All FFT-side arithmetic is float64 (complex128), the precision SciPy/skimage use for uint16 input.
+#include "ia3_rt.h"
+#include <hipfft/hipfft.h>
+#include <math.h>
+
+using namespace ia3rt;
+
+namespace {
+
+typedef hipfftDoubleComplex cplx;
+
+int next_fast_len(int n) {  // smallest 2^a 3^b 5^c 7^d >= n
+  for (int m = n;; ++m) {
+    int k = m;
+    for (int p : {2, 3, 5, 7}) while (k % p == 0) k /= p;
+    if (k == 1) return m;
+  }
+}
+
+#define IA3_FFT(expr)                                                                          \
+  do {                                                                                         \
+    hipfftResult _r = (expr);                                                                  \
+    if (_r != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "%s failed: hipfft error %d", #expr, (int)_r); \
+  } while (0)
+
+struct Plan {  // RAII
+  hipfftHandle h = 0; bool ok = false;
+  ~Plan() { if (ok) hipfftDestroy(h); }
+};
+
+template <class T> __device__ __forceinline__ double ldv(const T* p, size_t i) { return (double)p[i]; }
+
+// out[x,y] = max_z im[z, x0+x, y0+y]   (sub-box x0..x0+nx, y0..y0+ny)
+template <class T>
+__global__ void maxproj_z_k(const T* __restrict__ im, int Z, int X, int Y, int x0, int nx, int y0, int ny,
+                            double* __restrict__ out) {
+  int y = blockIdx.x * 64 + (threadIdx.x & 63), x = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= nx || y >= ny) return;
+  double m = -INFINITY;
+  for (int z = 0; z < Z; ++z) { double v = ldv(im, ((size_t)z * X + x0 + x) * Y + y0 + y); m = v > m ? v : m; }
+  out[(size_t)x * ny + y] = m;
+}
+// out[z,x] = max_y im[z, x0+x, y0..y0+ny)
+template <class T>
+__global__ void maxproj_y_k(const T* __restrict__ im, int Z, int X, int Y, int x0, int nx, int y0, int ny,
+                            double* __restrict__ out) {
+  const int row = blockIdx.x;  // z * nx + x
+  const int z = row / nx, x = row % nx;
+  const T* p = im + ((size_t)z * X + x0 + x) * Y + y0;
+  double m = -INFINITY;
+  for (int y = threadIdx.x; y < ny; y += 64) { double v = (double)p[y]; m = v > m ? v : m; }
+  for (int s = 1; s < 64; s <<= 1) { double o = __shfl_xor(m, s); m = o > m ? o : m; }
+  if (threadIdx.x == 0) out[row] = m;
+}
+
+// single-block mean / std (np.mean, np.std ddof 0) of n doubles -> stats[0]=mean, stats[1]=std
+__global__ __launch_bounds__(1024) void mean_std_k(const double* __restrict__ a, size_t n, double* stats) {
+  __shared__ double sh[1024];
+  double s = 0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) s += a[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  const double mean = sh[0] / (double)n;
+  __syncthreads();
+  double q = 0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) { double d = a[i] - mean; q += d * d; }
+  sh[threadIdx.x] = q;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) { stats[0] = mean; stats[1] = sqrt(sh[0] / (double)n); }
+}
+
+// dst (Fx x Fy, zero padded) = (src - mean)/std, optionally flipped in both axes (im2[::-1, ::-1])
+__global__ void pad_norm_k(const double* __restrict__ src, int sx, int sy, const double* __restrict__ stats,
+                           int flip, double* __restrict__ dst, int Fx, int Fy) {
+  int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= Fy) return;
+  double v = 0.0;
+  if (i < sx && j < sy) {
+    int si = flip ? sx - 1 - i : i, sj = flip ? sy - 1 - j : j;
+    v = (src[(size_t)si * sy + sj] - stats[0]) / stats[1];
+  }
+  dst[(size_t)i * Fy + j] = v;
+}
+__global__ void cmul_k(cplx* __restrict__ a, const cplx* __restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  cplx x = a[i], y = b[i];
+  a[i] = cplx{x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x};
+}
+// argmax over cor[0:cx, 0:cy] (leading dim Fy) of (inside window ? cor*scale : 0); first index wins ties
+__global__ __launch_bounds__(1024) void window_argmax_k(const double* __restrict__ cor, int cx, int cy, int Fy,
+                                                       double scale, int x_min, int x_max, int y_min, int y_max,
+                                                       long long* __restrict__ out_idx, double* __restrict__ out_val) {
+  __shared__ double sv[1024];
+  __shared__ long long si[1024];
+  double bv = -INFINITY; long long bi = 0x7fffffffffffffffLL;
+  const long long n = (long long)cx * cy;
+  for (long long k = threadIdx.x; k < n; k += 1024) {
+    int i = (int)(k / cy), j = (int)(k % cy);
+    bool in = i >= x_min && i < x_max && j >= y_min && j < y_max;
+    double v = in ? cor[(size_t)i * Fy + j] * scale : 0.0;
+    if (v > bv) { bv = v; bi = k; }   // k increases per thread -> first occurrence kept
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      double ov = sv[threadIdx.x + s]; long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *out_idx = si[0]; *out_val = sv[0]; }
+}
+
+// fftalign_2d on device-resident 2-D float64 images (alignment_tools.py:286-328)
+int fftalign2d_dev(const double* im1, int s1x, int s1y, const double* im2, int s2x, int s2y,
+                   const double center[2], double max_disp, int out[2]) {
+  hipStream_t st = stream();
+  if (s1x < 1 || s1y < 1 || s2x < 1 || s2y < 1) return set_error(IA3_EINVAL, "empty image in fftalign_2d");
+  const int cx = s1x + s2x - 1, cy = s1y + s2y - 1;
+  const int Fx = next_fast_len(cx), Fy = next_fast_len(cy);
+  const size_t nreal = (size_t)Fx * Fy, ncplx = (size_t)Fx * (Fy / 2 + 1);
+  Scratch a(nreal * sizeof(double)), b(nreal * sizeof(double)), fa(ncplx * sizeof(cplx)), fb(ncplx * sizeof(cplx)),
+      stats(4 * sizeof(double)), res(sizeof(long long) + sizeof(double));
+  if (!a.p || !b.p || !fa.p || !fb.p || !stats.p || !res.p) return IA3_ENOMEM;
+  ProfScope ps("fftalign_2d");
+  hipLaunchKernelGGL(mean_std_k, dim3(1), dim3(1024), 0, st, im1, (size_t)s1x * s1y, stats.as<double>());
+  hipLaunchKernelGGL(mean_std_k, dim3(1), dim3(1024), 0, st, im2, (size_t)s2x * s2y, stats.as<double>() + 2);
+  dim3 g((Fy + 255) / 256, Fx);
+  hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im1, s1x, s1y, (const double*)stats.as<double>(), 0, a.as<double>(), Fx, Fy);
+  hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im2, s2x, s2y, (const double*)(stats.as<double>() + 2), 1, b.as<double>(), Fx, Fy);
+  Plan fwd, inv;
+  IA3_FFT(hipfftPlan2d(&fwd.h, Fx, Fy, HIPFFT_D2Z)); fwd.ok = true;
+  IA3_FFT(hipfftPlan2d(&inv.h, Fx, Fy, HIPFFT_Z2D)); inv.ok = true;
+  IA3_FFT(hipfftSetStream(fwd.h, st));
+  IA3_FFT(hipfftSetStream(inv.h, st));
+  IA3_FFT(hipfftExecD2Z(fwd.h, a.as<double>(), fa.as<cplx>()));
+  IA3_FFT(hipfftExecD2Z(fwd.h, b.as<double>(), fb.as<cplx>()));
+  hipLaunchKernelGGL(cmul_k, dim3((unsigned)((ncplx + 255) / 256)), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), ncplx);
+  IA3_FFT(hipfftExecZ2D(inv.h, fa.as<cplx>(), a.as<double>()));
+  // window (alignment_tools.py:301-308)
+  const double c0 = center[0] + cx / 2.0, c1 = center[1] + cy / 2.0;
+  auto clampi = [](double v, int hi) { v = v < 0 ? 0 : v; v = v > hi ? hi : v; return (int)v; };
+  const int x_min = clampi(c0 - max_disp, cx), x_max = clampi(c0 + max_disp, cx);
+  const int y_min = clampi(c1 - max_disp, cy), y_max = clampi(c1 + max_disp, cy);
+  long long* d_idx = res.as<long long>();
+  double* d_val = (double*)(d_idx + 1);
+  hipLaunchKernelGGL(window_argmax_k, dim3(1), dim3(1024), 0, st, (const double*)a.as<double>(), cx, cy, Fy,
+                     1.0 / (double)nreal, x_min, x_max, y_min, y_max, d_idx, d_val);
+  IA3_KCHECK();
+  long long idx = 0;
+  IA3_HIP(hipMemcpyAsync(&idx, d_idx, sizeof(idx), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  const int yy = (int)(idx / cy), xx = (int)(idx % cy);
+  out[0] = -(cx / 2) + yy;   // -floor(shape/2) + [y, x]   (:327)
+  out[1] = -(cy / 2) + xx;
+  return IA3_OK;
+}
+
+template <class T>
+void launch_maxproj_z(const ia3_stack* s, int x0, int nx, int y0, int ny, double* out, hipStream_t st) {
+  dim3 g((ny + 63) / 64, (nx + 3) / 4);
+  hipLaunchKernelGGL((maxproj_z_k<T>), g, dim3(256), 0, st, (const T*)s->d, s->Z, s->X, s->Y, x0, nx, y0, ny, out);
+}
+template <class T>
+void launch_maxproj_y(const ia3_stack* s, int x0, int nx, int y0, int ny, double* out, hipStream_t st) {
+  hipLaunchKernelGGL((maxproj_y_k<T>), dim3((unsigned)(s->Z * nx)), dim3(64), 0, st, (const T*)s->d, s->Z, s->X, s->Y, x0, nx, y0, ny, out);
+}
+
+// ---- phase cross-correlation -----------------------------------------------------------------------
+template <class T>
+__global__ void to_cplx_k(const T* __restrict__ a, cplx* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = cplx{(double)a[i], 0.0};
+}
+// prod = A * conj(B); optional phase normalisation prod /= max(|prod|, 100 eps)
+__global__ void cross_power_k(cplx* __restrict__ a, const cplx* __restrict__ b, size_t n, int phase_norm) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  cplx x = a[i], y = b[i];
+  double re = x.x * y.x + x.y * y.y, im = x.y * y.x - x.x * y.y;
+  if (phase_norm) {
+    double m = hypot(re, im);
+    const double lim = 100.0 * 2.220446049250313e-16;
+    m = m > lim ? m : lim;
+    re /= m; im /= m;
+  }
+  a[i] = cplx{re, im};
+}
+__global__ void conj_k(cplx* __restrict__ a, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i].y = -a[i].y;
+}
+// multi-block |.|² argmax: per-block best -> partial arrays
+__global__ __launch_bounds__(256) void abs_argmax_part_k(const cplx* __restrict__ a, size_t n, double* pv, long long* pi) {
+  __shared__ double sv[256];
+  __shared__ long long si[256];
+  double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+    double v = a[k].x * a[k].x + a[k].y * a[k].y;
+    if (v > bv) { bv = v; bi = (long long)k; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      double ov = sv[threadIdx.x + s]; long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { pv[blockIdx.x] = sv[0]; pi[blockIdx.x] = si[0]; }
+}
+// sum of |a|^2 (single block)
+__global__ __launch_bounds__(1024) void abs2_sum_k(const cplx* __restrict__ a, size_t n, double* out) {
+  __shared__ double sh[1024];
+  double s = 0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) s += a[i].x * a[i].x + a[i].y * a[i].y;
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+// DFT kernel matrix K[r, n] = exp(-2πi (r - off) * fftfreq(N, u)[n]),  r < R, n < N
+__global__ void dft_kernel_k(cplx* __restrict__ K, int R, int N, double off, double u) {
+  int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (n >= N) return;
+  int kf = n < (N + 1) / 2 ? n : n - N;
+  double turns = ((double)r - off) * ((double)kf / ((double)N * u));
+  double s, c;
+  sincospi(-2.0 * turns, &s, &c);
+  K[(size_t)r * N + n] = cplx{c, s};
+}
+// out[r, m] = sum_n K[r, n] * in[m, n]     (np.tensordot(K, data, axes=(1, -1)) with data flattened to (M, N))
+// tile: 16 r x 64 m per 256-thread block, 4 m per thread, n staged through LDS in chunks of 32
+__global__ __launch_bounds__(256) void dft_contract_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
+                                                      cplx* __restrict__ out, int R, int M, int N) {
+  __shared__ cplx sk[16][33];
+  __shared__ cplx sd[64][33];
+  const int tr = threadIdx.x >> 4, tm = threadIdx.x & 15;
+  const int r0 = blockIdx.y * 16, m0 = blockIdx.x * 64;
+  cplx acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  for (int n0 = 0; n0 < N; n0 += 32) {
+    for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+      int rr = e >> 5, nn = e & 31;
+      sk[rr][nn] = (r0 + rr < R && n0 + nn < N) ? K[(size_t)(r0 + rr) * N + n0 + nn] : cplx{0, 0};
+    }
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+      int mm = e >> 5, nn = e & 31;
+      sd[mm][nn] = (m0 + mm < M && n0 + nn < N) ? in[(size_t)(m0 + mm) * N + n0 + nn] : cplx{0, 0};
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int nn = 0; nn < 32; ++nn) {
+      cplx k = sk[tr][nn];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cplx d = sd[tm + 16 * q][nn];
+        acc[q].x += k.x * d.x - k.y * d.y;
+        acc[q].y += k.x * d.y + k.y * d.x;
+      }
+    }
+    __syncthreads();
+  }
+  if (r0 + tr < R)
+    for (int q = 0; q < 4; ++q)
+      if (m0 + tm + 16 * q < M) out[(size_t)(r0 + tr) * M + m0 + tm + 16 * q] = acc[q];
+}
+
+int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
+  hipStream_t st = stream();
+  const int nb = 512;
+  Scratch pv(nb * sizeof(double)), pi(nb * sizeof(long long));
+  if (!pv.p || !pi.p) return IA3_ENOMEM;
+  hipLaunchKernelGGL(abs_argmax_part_k, dim3(nb), dim3(256), 0, st, a, n, pv.as<double>(), pi.as<long long>());
+  IA3_KCHECK();
+  std::vector<double> hv(nb); std::vector<long long> hi(nb);
+  IA3_HIP(hipMemcpyAsync(hv.data(), pv.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipMemcpyAsync(hi.data(), pi.p, nb * sizeof(long long), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  double bv = -1; long long bi = 0;
+  for (int k = 0; k < nb; ++k) if (hv[k] > bv || (hv[k] == bv && hi[k] < bi)) { bv = hv[k]; bi = hi[k]; }
+  *idx = bi; *val2 = bv;
+  return IA3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ia3_fftalign_2d(const double* im1, int s1x, int s1y, const double* im2, int s2x, int s2y,
+                    const double* center, double max_disp, int* out_xy) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im1 || !im2 || !center || !out_xy) return set_error(IA3_EINVAL, "null argument");
+  hipStream_t st = stream();
+  Scratch a((size_t)s1x * s1y * sizeof(double)), b((size_t)s2x * s2y * sizeof(double));
+  if (!a.p || !b.p) return IA3_ENOMEM;
+  IA3_HIP(hipMemcpyAsync(a.p, im1, (size_t)s1x * s1y * sizeof(double), hipMemcpyHostToDevice, st));
+  IA3_HIP(hipMemcpyAsync(b.p, im2, (size_t)s2x * s2y * sizeof(double), hipMemcpyHostToDevice, st));
+  return fftalign2d_dev(a.as<double>(), s1x, s1y, b.as<double>(), s2x, s2y, center, max_disp, out_xy);
+}
+
+// alignment_tools.py:330-353 with gb <= 1 (the production default fft_filt_size=0, alignment.py:141,191-193)
+int ia3_fft3d_from2d_dev(const ia3_stack* im1, const ia3_stack* im2, double max_disp, int* out_zxy) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im1 || !im2 || !out_zxy) return set_error(IA3_EINVAL, "null argument");
+  if (im1->dtype != im2->dtype) return set_error(IA3_EINVAL, "stacks differ in dtype");
+  hipStream_t st = stream();
+  const int sx = im1->X, sy = im1->Y;
+  const double center[2] = {0, 0};
+  int txy[2], tzq[2];
+  {
+    Scratch p1((size_t)im1->X * im1->Y * sizeof(double)), p2((size_t)im2->X * im2->Y * sizeof(double));
+    if (!p1.p || !p2.p) return IA3_ENOMEM;
+    {
+      ProfScope ps("maxproj_z");
+      if (im1->dtype == IA3_F32) { launch_maxproj_z<float>(im1, 0, im1->X, 0, im1->Y, p1.as<double>(), st); launch_maxproj_z<float>(im2, 0, im2->X, 0, im2->Y, p2.as<double>(), st); }
+      else { launch_maxproj_z<uint16_t>(im1, 0, im1->X, 0, im1->Y, p1.as<double>(), st); launch_maxproj_z<uint16_t>(im2, 0, im2->X, 0, im2->Y, p2.as<double>(), st); }
+    }
+    rc = fftalign2d_dev(p1.as<double>(), im1->X, im1->Y, p2.as<double>(), im2->X, im2->Y, center, max_disp, txy);
+    if (rc) return rc;
+  }
+  const int tx = txy[0], ty = txy[1];
+  // im1[:, max(tx,0):sx+tx, max(ty,0):sy+ty] and im2[:, max(-tx,0):sx-tx, max(-ty,0):sy-ty] (python slice clipping)
+  auto clip = [](int v, int n) { return v < 0 ? 0 : (v > n ? n : v); };
+  const int a0 = clip(tx > 0 ? tx : 0, im1->X), a1 = clip(sx + tx, im1->X), b0 = clip(ty > 0 ? ty : 0, im1->Y), b1 = clip(sy + ty, im1->Y);
+  const int c0 = clip(-tx > 0 ? -tx : 0, im2->X), c1 = clip(sx - tx, im2->X), d0 = clip(-ty > 0 ? -ty : 0, im2->Y), d1 = clip(sy - ty, im2->Y);
+  const int n1x = a1 - a0, n1y = b1 - b0, n2x = c1 - c0, n2y = d1 - d0;
+  if (n1x < 1 || n1y < 1 || n2x < 1 || n2y < 1) return set_error(IA3_EINVAL, "xy shift (%d,%d) leaves no overlap", tx, ty);
+  {
+    Scratch q1((size_t)im1->Z * n1x * sizeof(double)), q2((size_t)im2->Z * n2x * sizeof(double));
+    if (!q1.p || !q2.p) return IA3_ENOMEM;
+    {
+      ProfScope ps("maxproj_y");
+      if (im1->dtype == IA3_F32) { launch_maxproj_y<float>(im1, a0, n1x, b0, n1y, q1.as<double>(), st); launch_maxproj_y<float>(im2, c0, n2x, d0, n2y, q2.as<double>(), st); }
+      else { launch_maxproj_y<uint16_t>(im1, a0, n1x, b0, n1y, q1.as<double>(), st); launch_maxproj_y<uint16_t>(im2, c0, n2x, d0, n2y, q2.as<double>(), st); }
+    }
+    rc = fftalign2d_dev(q1.as<double>(), im1->Z, n1x, q2.as<double>(), im2->Z, n2x, center, max_disp, tzq);
+    if (rc) return rc;
+  }
+  out_zxy[0] = tzq[0]; out_zxy[1] = tx; out_zxy[2] = ty;
+  return IA3_OK;
+}
+
+int ia3_fft3d_from2d(const void* im1, const void* im2, int dtype, int Z, int X, int Y, double max_disp, int* out_zxy) {
+  ia3_stack *a = nullptr, *b = nullptr;
+  int rc = ia3_stack_upload(im1, dtype, Z, X, Y, &a); if (rc) return rc;
+  rc = ia3_stack_upload(im2, dtype, Z, X, Y, &b);
+  if (!rc) rc = ia3_fft3d_from2d_dev(a, b, max_disp, out_zxy);
+  ia3_stack_free(a); ia3_stack_free(b);
+  return rc;
+}
+
+// phase_cross_correlation(reference, moving, upsample_factor, normalization) -> shift, error, phasediff
+int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsample, int normalization,
+                          double* shift, double* err, double* phasediff) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!ref || !mov || !shift) return set_error(IA3_EINVAL, "null argument");
+  if (ref->dtype != mov->dtype || ref->Z != mov->Z || ref->X != mov->X || ref->Y != mov->Y)
+    return set_error(IA3_EINVAL, "reference and moving stacks differ in shape or dtype");
+  if (upsample < 1) return set_error(IA3_EINVAL, "upsample_factor must be >= 1");
+  hipStream_t st = stream();
+  const int Z = ref->Z, X = ref->X, Y = ref->Y;
+  const size_t n = (size_t)Z * X * Y;
+  Scratch fa(n * sizeof(cplx)), fb(n * sizeof(cplx)), sums(2 * sizeof(double));
+  if (!fa.p || !fb.p || !sums.p) return IA3_ENOMEM;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  ProfScope ps("phase_xcorr3d");
+  if (ref->dtype == IA3_F32) {
+    hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)ref->d, fa.as<cplx>(), n);
+    hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)mov->d, fb.as<cplx>(), n);
+  } else {
+    hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)ref->d, fa.as<cplx>(), n);
+    hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)mov->d, fb.as<cplx>(), n);
+  }
+  Plan plan;
+  IA3_FFT(hipfftPlan3d(&plan.h, Z, X, Y, HIPFFT_Z2Z)); plan.ok = true;
+  IA3_FFT(hipfftSetStream(plan.h, st));
+  IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
+  IA3_FFT(hipfftExecZ2Z(plan.h, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
+  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const cplx*)fa.as<cplx>(), n, sums.as<double>());
+  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const cplx*)fb.as<cplx>(), n, sums.as<double>() + 1);
+  hipLaunchKernelGGL(cross_power_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), n, normalization);
+  // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
+  IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
+  IA3_KCHECK();
+  long long idx; double v2;
+  rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;
+  double hs[2];
+  IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+  cplx ccmax;
+  IA3_HIP(hipMemcpyAsync(&ccmax, fb.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  ccmax.x /= (double)n; ccmax.y /= (double)n;
+  const int dims[3] = {Z, X, Y};
+  long long rem = idx;
+  int peak[3];
+  peak[2] = (int)(rem % Y); rem /= Y; peak[1] = (int)(rem % X); rem /= X; peak[0] = (int)rem;
+  double sh[3];
+  for (int a = 0; a < 3; ++a) {
+    double mid = (double)(dims[a] / 2);  // np.fix(size/2)
+    sh[a] = peak[a];
+    if (sh[a] > mid) sh[a] -= dims[a];
+  }
+  double src_amp = hs[0], tgt_amp = hs[1];
+  if (upsample == 1) {
+    src_amp /= (double)n; tgt_amp /= (double)n;
+  } else {
+    const double u = (double)upsample;
+    for (int a = 0; a < 3; ++a) sh[a] = nearbyint(sh[a] * u) / u;
+    const int R = (int)ceil(u * 1.5);
+    const double dftshift = trunc(R / 2.0);
+    double off[3];
+    for (int a = 0; a < 3; ++a) off[a] = dftshift - sh[a] * u;
+    // data = conj(prod) in fa; contract last axis three times (axes Y, X, Z), new axis goes first
+    hipLaunchKernelGGL(conj_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), n);
+    const int maxN = Y > X ? (Y > Z ? Y : Z) : (X > Z ? X : Z);
+    Scratch K((size_t)R * maxN * sizeof(cplx)), t1((size_t)R * Z * X * sizeof(cplx)), t2((size_t)R * R * Z * sizeof(cplx)),
+        t3((size_t)R * R * R * sizeof(cplx));
+    if (!K.p || !t1.p || !t2.p || !t3.p) return IA3_ENOMEM;
+    auto contract = [&](const cplx* in, cplx* out, int M, int N, double o) {
+      hipLaunchKernelGGL(dft_kernel_k, dim3((N + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, N, o, u);
+      hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
+    };
+    contract(fa.as<cplx>(), t1.as<cplx>(), Z * X, Y, off[2]);   // (R_y, Z, X)
+    contract(t1.as<cplx>(), t2.as<cplx>(), R * Z, X, off[1]);   // (R_x, R_y, Z)
+    contract(t2.as<cplx>(), t3.as<cplx>(), R * R, Z, off[0]);   // (R_z, R_x, R_y)
+    IA3_KCHECK();
+    const size_t nr = (size_t)R * R * R;
+    rc = abs_argmax(t3.as<cplx>(), nr, &idx, &v2); if (rc) return rc;   // |conj(x)| = |x|
+    IA3_HIP(hipMemcpyAsync(&ccmax, t3.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipStreamSynchronize(st));
+    ccmax.y = -ccmax.y;  // .conj()
+    rem = idx;
+    int pk[3];
+    pk[2] = (int)(rem % R); rem /= R; pk[1] = (int)(rem % R); rem /= R; pk[0] = (int)rem;
+    for (int a = 0; a < 3; ++a) sh[a] += ((double)pk[a] - dftshift) / u;
+  }
+  for (int a = 0; a < 3; ++a) { if (dims[a] == 1) sh[a] = 0; shift[a] = sh[a]; }
+  const double amp = src_amp * tgt_amp;
+  if (err) *err = amp != 0 ? sqrt(fabs(1.0 - (ccmax.x * ccmax.x + ccmax.y * ccmax.y) / amp)) : NAN;
+  if (phasediff) *phasediff = atan2(ccmax.y, ccmax.x);
+  return IA3_OK;
+}
+
+int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X, int Y, int upsample,
+                      int normalization, double* shift, double* err, double* phasediff) {
+  ia3_stack *a = nullptr, *b = nullptr;
+  int rc = ia3_stack_upload(ref, dtype, Z, X, Y, &a); if (rc) return rc;
+  rc = ia3_stack_upload(mov, dtype, Z, X, Y, &b);
+  if (!rc) rc = ia3_phase_xcorr3d_dev(a, b, upsample, normalization, shift, err, phasediff);
+  ia3_stack_free(a); ia3_stack_free(b);
+  return rc;
+}
+
+// copy the sub-box [z0,z1) x [x0,x1) x [y0,y1) of a resident stack into a new stack (drift crops)
+int ia3_stack_crop(const ia3_stack* s, int z0, int z1, int x0, int x1, int y0, int y1, ia3_stack** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!s || !out) return set_error(IA3_EINVAL, "null argument");
+  if (z0 < 0 || x0 < 0 || y0 < 0 || z1 > s->Z || x1 > s->X || y1 > s->Y || z0 >= z1 || x0 >= x1 || y0 >= y1)
+    return set_error(IA3_EINVAL, "bad crop [%d:%d, %d:%d, %d:%d] of (%d,%d,%d)", z0, z1, x0, x1, y0, y1, s->Z, s->X, s->Y);
+  rc = ia3_stack_alloc(s->dtype, z1 - z0, x1 - x0, y1 - y0, out); if (rc) return rc;
+  const size_t es = esize(s->dtype);
+  hipMemcpy3DParms p = {};
+  p.srcPtr = make_hipPitchedPtr(s->d, (size_t)s->Y * es, s->Y, s->X);
+  p.dstPtr = make_hipPitchedPtr((*out)->d, (size_t)(y1 - y0) * es, y1 - y0, x1 - x0);
+  p.srcPos = make_hipPos((size_t)y0 * es, x0, z0);
+  p.dstPos = make_hipPos(0, 0, 0);
+  p.extent = make_hipExtent((size_t)(y1 - y0) * es, x1 - x0, z1 - z0);
+  p.kind = hipMemcpyDeviceToDevice;
+  hipError_t e = hipMemcpy3DAsync(&p, stream());
+  if (e != hipSuccess) { ia3_stack_free(*out); *out = nullptr; return set_error(IA3_EHIP, "crop copy failed: %s", hipGetErrorString(e)); }
+  return IA3_OK;
+}
+
+}  // extern "C"

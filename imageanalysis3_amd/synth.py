@@ -201,7 +201,7 @@ def make_fov(shape, n_spots, seed, layout="isolated", dtype=np.float32, **kw):
 
 
 def make_bead_pair(shape, n_beads, seed, drift, dtype=np.float32, h_range=(3000.0, 8000.0),
-                   margin=(8, 24, 24), min_sep=16.0):
+                   margin=(8, 24, 24), min_sep=16.0, noise=15.0):
     """Reference bead stack and a source stack whose beads sit at ``c + d``.
 
     With beads injected at ``c + d`` in the source, the drift returned by
@@ -209,7 +209,7 @@ def make_bead_pair(shape, n_beads, seed, drift, dtype=np.float32, h_range=(3000.
     """
     centers, heights = spot_table(shape, n_beads, seed, layout="isolated", h_range=h_range,
                                   margin=margin, min_sep=min_sep)
-    ref = render(shape, centers, heights, seed, dtype=dtype)
+    ref = render(shape, centers, heights, seed, dtype=dtype, noise=noise)
     src = render(shape, centers + np.asarray(drift, dtype=np.float64)[None, :], heights,
-                 seed + 7919, dtype=dtype)
+                 seed + 7919, dtype=dtype, noise=noise)
     return ref, src, centers, heights

@@ -143,6 +143,25 @@ int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* 
 int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
                     float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter);
 
+/* ---- drift ------------------------------------------------------------------------------------
+ * alignment_tools.py:286-328 fftalign_2d: (xt, yt) of the normalised full cross-correlation peak of two
+ * 2-D float64 images inside a +-max_disp window around `center`. */
+int ia3_fftalign_2d(const double* im1, int s1x, int s1y, const double* im2, int s2x, int s2y,
+                    const double* center, double max_disp, int* out_xy);
+/* alignment_tools.py:330-353 fft3d_from2d (gb <= 1): integer (tz, tx, ty) from z- then y-max-projections. */
+int ia3_fft3d_from2d(const void* im1, const void* im2, int dtype, int Z, int X, int Y, double max_disp,
+                     int* out_zxy);
+int ia3_fft3d_from2d_dev(const ia3_stack* im1, const ia3_stack* im2, double max_disp, int* out_zxy);
+/* skimage.registration.phase_cross_correlation(reference, moving, upsample_factor) as called at
+ * correction_tools/alignment.py:491-494,631-632 and classes/preprocess.py:831-835 (published algorithm;
+ * parity unpinned).  normalization: 1 = "phase", 0 = None.  shift[3] = (dz, dx, dy) to apply to `moving`. */
+int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X, int Y, int upsample,
+                      int normalization, double* shift, double* err, double* phasediff);
+int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsample, int normalization,
+                          double* shift, double* err, double* phasediff);
+/* new resident stack = s[z0:z1, x0:x1, y0:y1] (drift crops, correction_tools/alignment.py:617-622) */
+int ia3_stack_crop(const ia3_stack* s, int z0, int z1, int x0, int x1, int y0, int y1, ia3_stack** out);
+
 #ifdef __cplusplus
 }
 #endif
