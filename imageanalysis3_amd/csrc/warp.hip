@@ -1,0 +1,330 @@
+// 3-D warp by drift + optional per-voxel displacement field (reference: correction_tools/translate.py:5-31
+// warp_3d_image and its production twins io_tools/load.py:438-453, classes/preprocess.py:918-946):
+//   coords = grid (+ chromatic_profile) - drift ;  out = scipy.ndimage.map_coordinates(image, coords, order, mode)
+//
+// scipy semantics restated (verified bit-for-bit on the host against SciPy 1.15, see tests):
+//   order 1            no prefilter; value = sum over the 2x2x2 corners, in C order, of ((c*w0)*w1)*w2 with
+//                      w = [1-y, y], y = cc - floor(cc).  mode 'constant': cc < 0 or cc > n-1 on any axis -> cval.
+//                      mode 'nearest': the coordinate is NOT clamped, out-of-range corner indices are.
+//   order 3 'nearest'  input edge-padded by 12, cubic B-spline prefilter along axes 0,1,2 in float64
+//                      (pole z = sqrt(3)-2 correctly rounded, gain (1-z)(1-1/z), half-sample-symmetric causal
+//                      initialisation, anticausal c[n-1] *= z/(z-1)), then the 4x4x4 weighted sum in C order with
+//                      weights w1=(y²(y-2)·3+4)/6, w2=(z²(z-2)·3+4)/6, w0=z³/6, w3=1-w0-w1-w2 (z=1-y).
+//   outputs            float32: cast; uint16: floor(t+0.5) clamped to [0, 65535].
+// The coordinate grid (5 GB of float64 per FOV in the reference) is never materialised.
+// Compiled with -ffp-contract=off.  HBM-bound streaming passes + an L2-served 64-tap gather.
+#include "ia3_rt.h"
+#include <math.h>
+
+using namespace ia3rt;
+
+namespace {
+
+constexpr int NPAD = 12;
+#define IA3_POLE3 (-0.26794919243112270647)
+
+template <class T> __device__ __forceinline__ T out_cvt(double t);
+template <> __device__ __forceinline__ float out_cvt<float>(double t) { return (float)t; }
+template <> __device__ __forceinline__ uint16_t out_cvt<uint16_t>(double t) {
+  t = t > 0 ? t + 0.5 : 0.0;
+  t = t > 65535.0 ? 65535.0 : t;
+  return (uint16_t)(int)t;
+}
+
+__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+// P[z,x,y] = im[clamp(z-12), clamp(x-12), clamp(y-12)] as float64 (np.pad(mode='edge'))
+template <class T>
+__global__ void spline_pad_k(const T* __restrict__ im, int Z, int X, int Y, double* __restrict__ P) {
+  const int Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  if (y >= Yp) return;
+  const int x = blockIdx.y, z = blockIdx.z;
+  const int sz = clampi(z - NPAD, Z), sx = clampi(x - NPAD, X), sy = clampi(y - NPAD, Y);
+  P[((size_t)z * Xp + x) * Yp + y] = (double)im[((size_t)sz * X + sx) * Y + sy];
+}
+
+// start-of-line value of the causal recursion for the 'nearest'/'reflect' boundary (see header)
+struct IirInit {
+  double z, gain, zn, scale;  // zn = z^n ; scale = z / (1 - zn*zn)
+  int full;                   // 1: sum all n terms incl. the zn mirror terms; 0: first 64 terms (zn == 0 or negligible)
+};
+
+// IIR along a strided axis: line p (lane along the contiguous axis), element i at base + i*stride
+__global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__ P, int inner, size_t stride, int n,
+                                                            size_t outer_stride, IirInit q) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= inner) return;
+  double* c = P + (size_t)blockIdx.y * outer_stride + p;
+  const double z = q.z, g = q.gain;
+  const double c0 = c[0] * g;
+  double s;
+  if (q.full) {
+    s = c0 + q.zn * (c[(size_t)(n - 1) * stride] * g);
+    double zi = z;
+    for (int i = 1; i < n; ++i) {
+      s += zi * (c[(size_t)i * stride] * g + q.zn * (c[(size_t)(n - 1 - i) * stride] * g));
+      zi *= z;
+    }
+  } else {
+    s = c0;
+    double zi = z;
+    const int m = n < 64 ? n : 64;
+    for (int i = 1; i < m; ++i) { s += zi * (c[(size_t)i * stride] * g); zi *= z; }
+  }
+  s *= q.scale;
+  s += c0;
+  double prev = s;
+  c[0] = prev;
+  for (int i = 1; i < n; ++i) {
+    double v = c[(size_t)i * stride] * g + z * prev;
+    c[(size_t)i * stride] = v;
+    prev = v;
+  }
+  prev = prev * (z / (z - 1.0));
+  c[(size_t)(n - 1) * stride] = prev;
+  for (int i = n - 2; i >= 0; --i) {
+    double v = z * (prev - c[(size_t)i * stride]);
+    c[(size_t)i * stride] = v;
+    prev = v;
+  }
+}
+
+// IIR along the contiguous axis: 64 lines per block, marched in 64-element tiles transposed through LDS
+__global__ __launch_bounds__(64) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
+  __shared__ double tile[64][65];
+  const int t = threadIdx.x;
+  const size_t l0 = (size_t)blockIdx.x * 64;
+  const double z = q.z, g = q.gain;
+  const int ntile = (n + 63) / 64;
+  double prev = 0.0;
+  for (int k = 0; k < ntile; ++k) {  // causal
+    const int y0 = k * 64, w = n - y0 < 64 ? n - y0 : 64;
+    for (int r = 0; r < 64; ++r)
+      if (l0 + r < n_lines && t < w) tile[r][t] = P[(l0 + r) * n + y0 + t] * g;
+    __syncthreads();
+    if (l0 + t < n_lines) {
+      int i0 = 0;
+      if (k == 0) {
+        const double c0 = tile[t][0];
+        double s = c0, zi = z;
+        if (q.full) {  // n <= 64 here: whole line is in this tile
+          s = c0 + q.zn * tile[t][n - 1];
+          for (int i = 1; i < n; ++i) { s += zi * (tile[t][i] + q.zn * tile[t][n - 1 - i]); zi *= z; }
+        } else {
+          for (int i = 1; i < w; ++i) { s += zi * tile[t][i]; zi *= z; }
+        }
+        s *= q.scale;
+        s += c0;
+        tile[t][0] = s;
+        prev = s;
+        i0 = 1;
+      }
+      for (int i = i0; i < w; ++i) { double v = tile[t][i] + z * prev; tile[t][i] = v; prev = v; }
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r)
+      if (l0 + r < n_lines && t < w) P[(l0 + r) * n + y0 + t] = tile[r][t];
+    __syncthreads();
+  }
+  for (int k = ntile - 1; k >= 0; --k) {  // anticausal
+    const int y0 = k * 64, w = n - y0 < 64 ? n - y0 : 64;
+    for (int r = 0; r < 64; ++r)
+      if (l0 + r < n_lines && t < w) tile[r][t] = P[(l0 + r) * n + y0 + t];
+    __syncthreads();
+    if (l0 + t < n_lines) {
+      int i1 = w - 1;
+      if (k == ntile - 1) { prev = tile[t][w - 1] * (z / (z - 1.0)); tile[t][w - 1] = prev; i1 = w - 2; }
+      for (int i = i1; i >= 0; --i) { double v = z * (prev - tile[t][i]); tile[t][i] = v; prev = v; }
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r)
+      if (l0 + r < n_lines && t < w) P[(l0 + r) * n + y0 + t] = tile[r][t];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
+  return fdt == 1 ? (double)((const float*)f)[i] : ((const double*)f)[i];
+}
+
+// order 1 on the raw stack
+template <class T>
+__global__ __launch_bounds__(256) void warp_lin_k(const T* __restrict__ im, int Z, int X, int Y, double dz, double dx,
+                                                  double dy, const void* __restrict__ field, int fdt, int mode,
+                                                  double cval, T* __restrict__ out) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  if (y >= Y) return;
+  const int x = blockIdx.y, zq = blockIdx.z;
+  const size_t o = ((size_t)zq * X + x) * Y + y, V = (size_t)Z * X * Y;
+  double cc[3] = {(double)zq, (double)x, (double)y};
+  if (field) { cc[0] = cc[0] + field_at(field, fdt, o); cc[1] = cc[1] + field_at(field, fdt, V + o); cc[2] = cc[2] + field_at(field, fdt, 2 * V + o); }
+  cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  const int dims[3] = {Z, X, Y};
+  if (mode == IA3_MODE_CONSTANT) {
+    bool outside = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) outside = outside || cc[a] < 0.0 || cc[a] > (double)(dims[a] - 1);
+    if (outside) { out[o] = out_cvt<T>(cval); return; }
+  }
+  int st[3]; double w[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double fl = floor(cc[a]);
+    const double yv = cc[a] - fl;
+    // far-away coordinates must not overflow int: every index beyond the range clamps to the same edge
+    st[a] = (int)(fl < -4.0 ? -4.0 : (fl > (double)dims[a] + 4.0 ? (double)dims[a] + 4.0 : fl));
+    w[a][0] = 1.0 - yv; w[a][1] = yv;
+  }
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        double c = (double)im[((size_t)clampi(st[0] + i, Z) * X + clampi(st[1] + j, X)) * Y + clampi(st[2] + k, Y)];
+        c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+        t = t + c;
+      }
+  out[o] = out_cvt<T>(t);
+}
+
+// order 3 on the prefiltered, padded coefficient array
+template <class T>
+__global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
+                                                    double dy, const void* __restrict__ field, int fdt,
+                                                    T* __restrict__ out) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  if (y >= Y) return;
+  const int x = blockIdx.y, zq = blockIdx.z;
+  const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
+  const size_t o = ((size_t)zq * X + x) * Y + y, V = (size_t)Z * X * Y;
+  double cc[3] = {(double)zq, (double)x, (double)y};
+  if (field) { cc[0] = cc[0] + field_at(field, fdt, o); cc[1] = cc[1] + field_at(field, fdt, V + o); cc[2] = cc[2] + field_at(field, fdt, 2 * V + o); }
+  cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  const int dims[3] = {Zp, Xp, Yp};
+  int idx[3][4]; double w[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double c = cc[a] + (double)NPAD;
+    const double fl = floor(c);
+    const double yv = c - fl, zv = 1.0 - yv;
+    w[a][1] = (yv * yv * (yv - 2.0) * 3.0 + 4.0) / 6.0;
+    w[a][2] = (zv * zv * (zv - 2.0) * 3.0 + 4.0) / 6.0;
+    w[a][0] = zv * zv * zv / 6.0;
+    w[a][3] = 1.0 - w[a][0] - w[a][1] - w[a][2];
+    double f2 = fl < -8.0 ? -8.0 : (fl > (double)dims[a] + 8.0 ? (double)dims[a] + 8.0 : fl);
+    const int st = (int)f2 - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[a][k] = clampi(st + k, dims[a]);
+  }
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double* row = C + ((size_t)idx[0][i] * Xp + idx[1][j]) * Yp;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double c = row[idx[2][k]];
+        c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+        t = t + c;
+      }
+    }
+  out[o] = out_cvt<T>(t);
+}
+
+IirInit make_init(int n) {
+  IirInit q;
+  q.z = IA3_POLE3;
+  q.gain = (1.0 - q.z) * (1.0 - 1.0 / q.z);
+  q.zn = pow(q.z, (double)n);
+  q.scale = q.z / (1.0 - q.zn * q.zn);
+  q.full = n <= 64 ? 1 : 0;  // else: first 64 terms, mirror terms (|z^n| < 4e-37) dropped
+  return q;
+}
+
+template <class T>
+int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt, int order, int mode, double cval,
+           ia3_stack* out) {
+  hipStream_t st = stream();
+  const int Z = im->Z, X = im->X, Y = im->Y;
+  dim3 g((unsigned)((Y + 255) / 256), (unsigned)X, (unsigned)Z);
+  if (order == 1) {
+    ProfScope ps("warp_linear");
+    hipLaunchKernelGGL((warp_lin_k<T>), g, dim3(256), 0, st, (const T*)im->d, Z, X, Y, drift[0], drift[1], drift[2],
+                       field, fdt, mode, cval, (T*)out->d);
+    IA3_KCHECK();
+    return IA3_OK;
+  }
+  const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
+  Scratch P((size_t)Zp * Xp * Yp * sizeof(double));
+  if (!P.p) return IA3_ENOMEM;
+  {
+    ProfScope ps("spline_prefilter");
+    hipLaunchKernelGGL((spline_pad_k<T>), dim3((unsigned)((Yp + 255) / 256), (unsigned)Xp, (unsigned)Zp), dim3(256), 0, st,
+                       (const T*)im->d, Z, X, Y, P.as<double>());
+    const size_t plane = (size_t)Xp * Yp;
+    // axis 0: lines = (x,y) columns, stride = plane
+    IirInit qz = make_init(Zp);
+    qz.full = 1;  // the strided kernel can always afford the faithful sum along the short z axis
+    hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(),
+                       (int)plane, plane, Zp, (size_t)0, qz);
+    // axis 1: lines = (z,y), stride = Yp
+    IirInit qx = make_init(Xp);
+    if (Xp <= 256) qx.full = 1;
+    hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
+                       Yp, (size_t)Yp, Xp, plane, qx);
+    // axis 2: contiguous lines (z,x)
+    IirInit qy = make_init(Yp);
+    const size_t nl = (size_t)Zp * Xp;
+    hipLaunchKernelGGL(spline_iir_contig_k, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, P.as<double>(), nl, Yp, qy);
+  }
+  {
+    ProfScope ps("warp_cubic");
+    hipLaunchKernelGGL((warp_cubic_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
+                       drift[2], field, fdt, (T*)out->d);
+  }
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// field: NULL or device pointer to a (3,Z,X,Y) displacement field; field_dtype 1 = float32, 2 = float64
+int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_dev, int field_dtype, int order,
+                   int mode, double cval, ia3_stack* out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !out || !drift) return set_error(IA3_EINVAL, "null argument");
+  if (im->dtype != out->dtype || im->Z != out->Z || im->X != out->X || im->Y != out->Y || im->d == out->d)
+    return set_error(IA3_EINVAL, "output stack must be a distinct stack of the same shape and dtype");
+  if (order != 1 && order != 3) return set_error(IA3_EUNSUPPORTED, "warp order %d (1 and 3 are implemented)", order);
+  if (order == 1 && mode != IA3_MODE_CONSTANT && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "border mode %d", mode);
+  if (order == 3 && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "order 3 is implemented for mode 'nearest'");
+  if (field_dev && field_dtype != 1 && field_dtype != 2) return set_error(IA3_EINVAL, "field dtype must be float32 or float64");
+  if (im->dtype == IA3_F32) return warp_t<float>(im, drift, field_dev, field_dtype, order, mode, cval, out);
+  return warp_t<uint16_t>(im, drift, field_dev, field_dtype, order, mode, cval, out);
+}
+
+int ia3_warp3d(const void* im, int dtype, int Z, int X, int Y, const double* drift, const void* field, int field_dtype,
+               int order, int mode, double cval, void* out) {
+  ia3_stack *a = nullptr, *b = nullptr;
+  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &a); if (rc) return rc;
+  rc = ia3_stack_alloc(dtype, Z, X, Y, &b);
+  void* dfield = nullptr;
+  if (!rc && field) {
+    size_t bytes = (size_t)3 * Z * X * Y * (field_dtype == 1 ? 4 : 8);
+    if (hipMalloc(&dfield, bytes) != hipSuccess) rc = set_error(IA3_ENOMEM, "hipMalloc(%zu) for the displacement field failed", bytes);
+    else if (hipMemcpy(dfield, field, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = set_error(IA3_EHIP, "field upload failed");
+  }
+  if (!rc) rc = ia3_warp3d_dev(a, drift, dfield, field_dtype, order, mode, cval, b);
+  if (!rc) rc = ia3_stack_download(b, out);
+  if (dfield) (void)hipFree(dfield);
+  ia3_stack_free(a); ia3_stack_free(b);
+  return rc;
+}
+
+}  // extern "C"

@@ -159,6 +159,16 @@ int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X,
                       int normalization, double* shift, double* err, double* phasediff);
 int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsample, int normalization,
                           double* shift, double* err, double* phasediff);
+/* ---- warp -------------------------------------------------------------------------------------
+ * correction_tools/translate.py:5-31 warp_3d_image and its inlined twins (io_tools/load.py:438-453,
+ * classes/preprocess.py:918-946): out = map_coordinates(im, grid (+ field) - drift, order, mode, cval).
+ * order 1 with mode constant|nearest, order 3 (B-spline prefilter) with mode nearest.
+ * field: NULL or a (3,Z,X,Y) displacement field, field_dtype 1 = float32, 2 = float64. */
+int ia3_warp3d(const void* im, int dtype, int Z, int X, int Y, const double* drift, const void* field,
+               int field_dtype, int order, int mode, double cval, void* out);
+int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_dev, int field_dtype,
+                   int order, int mode, double cval, ia3_stack* out);
+
 /* new resident stack = s[z0:z1, x0:x1, y0:y1] (drift crops, correction_tools/alignment.py:617-622) */
 int ia3_stack_crop(const ia3_stack* s, int z0, int z1, int x0, int x1, int y0, int y1, ia3_stack** out);
 
