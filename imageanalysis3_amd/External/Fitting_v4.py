@@ -18,6 +18,132 @@ def in_dim(x, y, z, xmax, ymax, zmax):
     return x[keep], y[keep], z[keep]
 
 
+def gaussfit_batch(ims, Xs, centers, delta_center=3., min_w=0.5, max_w=4., init_w=1.5):
+    """Run many independent ``GaussianFit(im, X, center=...).fit()`` in one launch (one wave per fit).
+    ims: list of 1-D voxel-value arrays; Xs: list of (3,n) coordinate arrays; centers: (N,3).
+    Returns (ps (N,11) float32, xs (N,10) float64, success (N,) bool, nfev (N,) int)."""
+    n_fits = len(ims)
+    off = np.zeros(n_fits + 1, dtype=np.int32)
+    kinds = np.zeros(n_fits, dtype=np.int32)
+    for i, im in enumerate(ims):
+        im = np.asarray(im)
+        off[i + 1] = off[i] + im.size
+        kinds[i] = 1 if im.dtype.kind in "ui" else (0 if im.dtype == np.float32 else 2)
+    vals = np.concatenate([np.asarray(im, dtype=np.float64).ravel() for im in ims]) if n_fits else np.zeros(0)
+    coords = (np.concatenate([np.asarray(X).T.reshape(-1, 3) for X in Xs]).astype(np.int32)
+              if n_fits else np.zeros((0, 3), np.int32))
+    vals, coords = np.ascontiguousarray(vals), np.ascontiguousarray(coords)
+    cen = np.ascontiguousarray(np.asarray(centers, dtype=np.float64).reshape(n_fits, 3))
+    cfg = np.ascontiguousarray(np.tile(np.array([delta_center, min_w, max_w, init_w], dtype=np.float64), (n_fits, 1)))
+    ps = np.full((n_fits, 11), np.nan, dtype=np.float32)
+    xs = np.full((n_fits, 10), np.nan, dtype=np.float64)
+    info = np.zeros((n_fits, 2), dtype=np.int32)
+    L.check(L.lib().ia3_gaussfit_voxels(L.dptr(vals), L.ptr(coords), L.ptr(off), n_fits, L.dptr(cen), L.dptr(cfg),
+                                        L.ptr(kinds), L.ptr(ps), L.dptr(xs), L.ptr(info)))
+    return ps, xs, info[:, 0].astype(bool), info[:, 1]
+
+
+class GaussianFit():
+    """External/Fitting_v4.py:165-396 — one constrained 10-parameter 3-D Gaussian fit on an explicit voxel
+    list.  ``fit()`` runs the wave-per-fit LM kernel (ia3_gaussfit_voxels); the small helpers below
+    (``to_natural_paramaters``, ``get_im``) evaluate the closed-form model on the host for the <= 512
+    voxels of one fit, as the reference does."""
+
+    def __init__(self, im, X, center=None, n_aprox=10, min_w=0.5, max_w=4., delta_center=3.,
+                 init_w=1.5):
+        self._min_w, self._max_w, self._init_w = min_w, max_w, init_w
+        self.min_w = min_w * min_w
+        self.max_w = max_w * max_w
+        self.delta_center = delta_center
+        self._im_in = np.asarray(im)
+        self._X_in = np.asarray(X)
+        self.im = np.array(im, dtype=np.float32)
+        self.x, self.y, self.z = np.array(X, dtype=np.float32)
+        argsort_im = np.argsort(im)
+        if center is None:                                                        # :176-177
+            center = np.median(self._X_in[:, argsort_im][:, -n_aprox:], -1)
+        self.center_est = center
+        if n_aprox != 10:
+            raise NotImplementedError("n_aprox != 10")
+        sorted_im = self._im_in[argsort_im]
+        eps = np.exp(-10.)
+        bk_guess = np.log(np.max([np.mean(sorted_im[:n_aprox]), eps]))
+        h_guess = np.log(np.max([np.mean(sorted_im[-n_aprox:]), eps]))
+        wsq = init_w ** 2
+        wg = np.log((self.max_w - wsq) / (wsq - self.min_w))
+        self.p_ = np.array([bk_guess, h_guess, 0, 0, 0, wg, wg, wg, 0, 0], dtype=np.float32)
+        self.to_natural_paramaters()
+        self.success = False
+
+    # -- closed-form model on the host (Fitting_v4.py:189-290) ---------------------------------
+    def _sig(self, v, lo, hi):
+        v = np.float64(v)
+        lim = np.log(np.finfo(np.float64).max)
+        if v >= lim:
+            return lo
+        if v <= -lim:
+            return hi
+        return (hi - lo) / (1. + np.exp(v)) + lo
+
+    def _geom(self, parms):
+        bk, h, xp, yp, zp, w1, w2, w3, pp, tp = [np.float64(v) for v in parms]
+        t, p = self._sig(tp, -1., 1.), self._sig(pp, -1., 1.)
+        ws = [self._sig(w, self.min_w, self.max_w) for w in (w1, w2, w3)]
+        d = self.delta_center
+        c = [self._sig(v, -d, d) + np.float64(c0) for v, c0 in zip((xp, yp, zp), self.center_est)]
+        return bk, h, t, p, ws, c
+
+    def calc_f(self, parms):
+        self.p_ = parms
+        bk, h, t, p, (ws1, ws2, ws3), (xc, yc, zc) = self._geom(parms)
+        xt, yt, zt = self.x - xc, self.y - yc, self.z - zc
+        p2, t2 = p * p, t * t
+        tc2, pc2 = 1 - t2, 1 - p2
+        tc, pc = np.sqrt(tc2), np.sqrt(pc2)
+        s1, s2, s3 = 1. / ws1, 1. / ws2, 1. / ws3
+        x2c = pc2 * tc2 * s1 + t2 * s2 + p2 * tc2 * s3
+        y2c = pc2 * t2 * s1 + tc2 * s2 + p2 * t2 * s3
+        z2c = p2 * s1 + pc2 * s3
+        xyc = 2 * tc * t * (pc2 * s1 - s2 + p2 * s3)
+        xzc = 2 * p * pc * tc * (s3 - s1)
+        yzc = 2 * p * pc * t * (s3 - s1)
+        xsigmax = x2c * xt * xt + y2c * yt * yt + z2c * zt * zt + xyc * xt * yt + xzc * xt * zt + yzc * yt * zt
+        self.f0 = np.exp(h - 0.5 * xsigmax)
+        self.f = np.exp(np.clip(bk, -709.78, 709.78)) + self.f0
+        return self.f
+
+    def calc_eps(self, parms):
+        return self.calc_f(parms) - self.im
+
+    def to_natural_paramaters(self, parms=None):
+        if parms is None:
+            parms = self.p_
+        bk, h, t, p, ws, c = self._geom(parms)
+        eps = np.mean(np.abs(self.calc_eps(parms)))
+        self.p = np.array([np.exp(h), c[0], c[1], c[2], np.exp(bk), np.sqrt(ws[0]), np.sqrt(ws[1]), np.sqrt(ws[2]),
+                           t, p, eps], dtype=np.float32)
+        return self.p
+
+    def fit(self, eps_frac=10E-3, eps_dist=10E-3, eps_angle=10E-3):
+        """Levenberg-Marquardt on the device; results in ``self.p`` = [height, c0, c1, c2, background,
+        width_0, width_1, width_2, sin_theta, sin_phi, error] (Fitting_v4.py:377-393)."""
+        if len(self.p_) > len(self.im):
+            self.success = False
+        else:
+            ps, xs, ok, nfev = gaussfit_batch([self._im_in], [self._X_in], [self.center_est],
+                                              delta_center=self.delta_center, min_w=self._min_w,
+                                              max_w=self._max_w, init_w=self._init_w)
+            self.p_ = xs[0]
+            self.p = ps[0]
+            self.center = self.p[1:4]
+            self.nfev = int(nfev[0])
+            self.success = True
+
+    def get_im(self):
+        self.calc_f(self.p_)
+        return self.f0
+
+
 class iter_fit_seed_points():
     def __init__(self, im, centers, radius_fit=5, min_delta_center=1., max_delta_center=2.5,
                  n_max_iter=10, max_dist_th=0.1,

@@ -330,6 +330,62 @@ __global__ __launch_bounds__(64) void fit_repeat_k(FitArgs fa, const int* __rest
   if (lane == 0) atomicMax(fa.n_iter, sweeps);
 }
 
+// ---- standalone GaussianFit(im, X, center).fit() on explicit voxel lists (Fitting_v4.py:165-396) --
+struct VoxArgs {
+  const double* vals;   // concatenated voxel values (float64 view of the caller's array)
+  const int* coords;    // concatenated (z,x,y) triples
+  const int* off;       // n_fits+1 offsets into vals / coords
+  const double* center; // n_fits x 3
+  const double* cfg;    // n_fits x 4: delta_center, min_w, max_w, init_w
+  const int* kind;      // n_fits: 0 float32 data, 1 integer data, 2 float64 data (start-point arithmetic)
+  float* ps;            // n_fits x 11
+  double* xs;           // n_fits x 10 unconstrained solution
+  int* info;            // n_fits x 2: success, nfev
+};
+
+__global__ __launch_bounds__(64) void fit_voxels_k(VoxArgs va, int n_fits, double ftol, double xtol, double gtol,
+                                                   int maxfev, double factor) {
+  __shared__ LMWork w;
+  const int i = blockIdx.x;
+  if (i >= n_fits) return;
+  const int lane = threadIdx.x & 63;
+  const int o0 = va.off[i], n = va.off[i + 1] - o0;
+  Ball ball;
+  double vals[SLOTS];
+  ball.valid = 0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int vi = lane + 64 * s;
+    ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
+    if (vi < n) {
+      ball.valid |= 1u << s;
+      vals[s] = va.vals[o0 + vi];
+      ball.dat[s] = (float)vals[s];
+      ball.cz[s] = (float)va.coords[3 * (o0 + vi)];
+      ball.cx[s] = (float)va.coords[3 * (o0 + vi) + 1];
+      ball.cy[s] = (float)va.coords[3 * (o0 + vi) + 2];
+    }
+  }
+  FitArgs fa;
+  const double min_w = va.cfg[4 * i + 1], max_w = va.cfg[4 * i + 2];
+  fa.min_ws = min_w * min_w; fa.max_ws = max_w * max_w; fa.init_w = va.cfg[4 * i + 3];
+  fa.ftol = ftol; fa.xtol = xtol; fa.gtol = gtol; fa.maxfev = maxfev; fa.factor = factor;
+  const double c0[3] = {va.center[3 * i], va.center[3 * i + 1], va.center[3 * i + 2]};
+  float p[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) p[k] = NAN;
+  int nfev = 0;
+  const bool ok = n >= NP;
+  if (ok) nfev = wave_gaussfit(fa, w, ball, vals, va.kind[i], c0, va.cfg[4 * i], n, p);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) va.ps[(size_t)i * 11 + k] = p[k];
+    for (int k = 0; k < NP; ++k) va.xs[(size_t)i * NP + k] = ok ? w.x[k] : NAN;
+    va.info[2 * i] = ok ? 1 : 0;
+    va.info[2 * i + 1] = nfev;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -558,6 +614,48 @@ int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* 
   ia3_fit_destroy(f);
   ia3_stack_free(s);
   return rc;
+}
+
+// Batch of independent GaussianFit(im, X, center=...).fit() calls on explicit voxel lists (<= 512 voxels each).
+// vals/coords are concatenated; off has n_fits+1 entries.  Outputs: ps n_fits x 11 (NaN rows when a fit
+// has fewer than 10 voxels, Fitting_v4.py:382-383), xs n_fits x 10, info n_fits x 2 (success, nfev).
+int ia3_gaussfit_voxels(const double* vals, const int* coords_zxy, const int* off, int n_fits, const double* centers,
+                        const double* cfg4, const int* kind, float* ps, double* xs, int* info) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (n_fits < 0 || (n_fits > 0 && (!vals || !coords_zxy || !off || !centers || !cfg4 || !kind || !ps)))
+    return set_error(IA3_EINVAL, "bad argument");
+  if (n_fits == 0) return IA3_OK;
+  const int total = off[n_fits];
+  for (int i = 0; i < n_fits; ++i)
+    if (off[i + 1] - off[i] > MAXBALL || off[i + 1] < off[i])
+      return set_error(IA3_EUNSUPPORTED, "fit %d has %d voxels (> %d)", i, off[i + 1] - off[i], MAXBALL);
+  hipStream_t st = stream();
+  Scratch dv((size_t)(total ? total : 1) * sizeof(double)), dc((size_t)(total ? total : 1) * 3 * sizeof(int)),
+      doff((size_t)(n_fits + 1) * sizeof(int)), dcen((size_t)n_fits * 3 * sizeof(double)),
+      dcfg((size_t)n_fits * 4 * sizeof(double)), dk((size_t)n_fits * sizeof(int)), dps((size_t)n_fits * 11 * sizeof(float)),
+      dxs((size_t)n_fits * NP * sizeof(double)), dinfo((size_t)n_fits * 2 * sizeof(int));
+  if (!dv.p || !dc.p || !doff.p || !dcen.p || !dcfg.p || !dk.p || !dps.p || !dxs.p || !dinfo.p) return IA3_ENOMEM;
+  if (total) {
+    IA3_HIP(hipMemcpyAsync(dv.p, vals, (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+    IA3_HIP(hipMemcpyAsync(dc.p, coords_zxy, (size_t)total * 3 * sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  IA3_HIP(hipMemcpyAsync(doff.p, off, (size_t)(n_fits + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  IA3_HIP(hipMemcpyAsync(dcen.p, centers, (size_t)n_fits * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+  IA3_HIP(hipMemcpyAsync(dcfg.p, cfg4, (size_t)n_fits * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+  IA3_HIP(hipMemcpyAsync(dk.p, kind, (size_t)n_fits * sizeof(int), hipMemcpyHostToDevice, st));
+  VoxArgs va;
+  va.vals = dv.as<double>(); va.coords = dc.as<int>(); va.off = doff.as<int>(); va.center = dcen.as<double>();
+  va.cfg = dcfg.as<double>(); va.kind = dk.as<int>(); va.ps = dps.as<float>(); va.xs = dxs.as<double>(); va.info = dinfo.as<int>();
+  {
+    ProfScope ps_("fit_voxels");
+    hipLaunchKernelGGL(fit_voxels_k, dim3((unsigned)n_fits), dim3(64), 0, st, va, n_fits, 1.49012e-8, 1.49012e-8, 0.0, 1000, 100.0);
+  }
+  IA3_KCHECK();
+  IA3_HIP(hipMemcpyAsync(ps, dps.p, (size_t)n_fits * 11 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (xs) IA3_HIP(hipMemcpyAsync(xs, dxs.p, (size_t)n_fits * NP * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (info) IA3_HIP(hipMemcpyAsync(info, dinfo.p, (size_t)n_fits * 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  return IA3_OK;
 }
 
 }  // extern "C"

@@ -133,6 +133,15 @@ int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox);
 int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev);
 void ia3_fit_destroy(ia3_fitter* f);
 
+/* External/Fitting_v4.py:165-396 GaussianFit(im, X, center, ...).fit() for a batch of explicit voxel lists
+ * (<= 512 voxels each): vals / coords_zxy concatenated, off[n_fits+1]; cfg4 = (delta_center, min_w, max_w,
+ * init_w) per fit; kind = dtype class of the caller's values (0 float32, 1 integer, 2 float64), which selects
+ * NumPy's arithmetic for the start point.  ps: n_fits x 11 (NaN row if < 10 voxels); xs: n_fits x 10
+ * unconstrained solution (may be NULL); info: n_fits x 2 (success, nfev) (may be NULL). */
+int ia3_gaussfit_voxels(const double* vals, const int* coords_zxy, const int* off, int n_fits,
+                        const double* centers, const double* cfg4, const int* kind, float* ps, double* xs,
+                        int* info);
+
 /* one call: upload + firstfit + repeatfit */
 int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* centers_zxy, int n,
                   const ia3_fit_params* p, float* out_ps, uint8_t* success, int* n_iter);

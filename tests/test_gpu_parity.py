@@ -346,3 +346,32 @@ def test_warp_identity_and_integer_shift():
         assert np.array_equal(w, O.warp_3d_image(im, [40.5, 100.25, -90.75], None, order, mode))
     with pytest.raises(NotImplementedError):
         warp_3d_image(im, [0, 0, 0], warp_order=3, border_mode="constant")
+
+
+def test_gaussianfit_class_vs_oracle():
+    """(a3) standalone GaussianFit on explicit voxel lists (Voronoi cells of the golden case)."""
+    import np_oracle as O
+    from imageanalysis3_amd.External.Fitting_v4 import GaussianFit, gaussfit_batch
+    for name in ("c1_f32", "c1_u16"):
+        im = build_case(name)
+        seeds = O.get_seeds(im, th_seed=600)
+        f = O.iter_fit_seed_points(im, seeds.T)
+        f.firstfit()
+        gp = f.gparms[:12]
+        ps, xs, ok, nfev = gaussfit_batch([g[0] for g in gp], [g[1] for g in gp], [g[2] for g in gp], delta_center=1.0)
+        assert ok.all() and (nfev > 2).all()
+        ref = np.array(f.ps[:12], dtype=np.float64)
+        assert (np.abs(ps[:, :8] - ref[:, :8]) / np.abs(ref[:, :8])).max() <= 1e-4
+        im_, X, c = gp[0]
+        obj = GaussianFit(im_, X, center=c, delta_center=1.0)
+        p0 = obj.p.copy()
+        oo = O.GaussianFit(im_, X, center=c, delta_center=1.0)
+        assert np.array_equal(obj.p_, oo.p_) and np.allclose(p0, oo.p, rtol=1e-6)   # same start point
+        obj.fit()
+        assert obj.success and np.array_equal(obj.p, ps[0])
+        oo.fit()
+        assert np.allclose(obj.get_im(), oo.get_im(), rtol=1e-4, atol=1e-6)
+    # < 10 voxels: fit refuses (Fitting_v4.py:382-383)
+    small = GaussianFit(np.arange(8, dtype=np.float32), np.zeros((3, 8), dtype=int), center=[0, 0, 0])
+    small.fit()
+    assert small.success is False
