@@ -20,7 +20,7 @@ EXPORTS = [
     "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
-    "ia3_remove_hot_pixels",
+    "ia3_remove_hot_pixels", "ia3_z_shift_correction", "ia3_illumination_correct", "ia3_bleedthrough_correct",
     "ia3_dog_seed", "ia3_dog_seed_dev",
     "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_results", "ia3_fit_stats",
     "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_gaussfit_voxels",

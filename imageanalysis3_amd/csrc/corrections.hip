@@ -1,0 +1,240 @@
+// Elementwise pre-corrections of correct_fov_image (reference: io_tools/load.py:337-384):
+//   z-shift       corrections.py:479-487  out = u16( f32(im) / median_z * median_all )        (float32 arithmetic)
+//   bleedthrough  io_tools/load.py:348-370 out_i = u16(clip( sum_j im_j * P[i,j] ))            (P (C,C,X,Y) f32|f64)
+//   illumination  io_tools/load.py:373-384 out = u16( f32(im) / P[ch] )                        (P (X,Y) f32|f64)
+// NumPy semantics kept: products/quotients are float32 when the profile is float32 and float64 when it is
+// float64; sums run in channel order; float -> uint16 is C truncation (out-of-range values wrap as on x86).
+// All three are single-pass HBM-bound streams; the medians use a 3-pass radix select (11+11+10 bits of the
+// order-preserving uint32 key of the float32 value), batched over the Z planes plus the whole stack, for the
+// two middle ranks NumPy averages.
+#include "ia3_rt.h"
+#include <math.h>
+
+using namespace ia3rt;
+
+namespace {
+
+__device__ __forceinline__ uint16_t to_u16(double t) {   // numpy .astype(np.uint16) of a float on x86-64
+  if (!(fabs(t) < 2147483648.0)) return 0;   // cvttss2si/cvttsd2si r32: out-of-range -> INT_MIN -> low 16 bits 0
+  return (uint16_t)(int)t;
+}
+template <class T> __device__ __forceinline__ float ldf(const T* p, size_t i) { return (float)p[i]; }
+
+__device__ __forceinline__ uint32_t fkey(float v) {      // order-preserving key
+  uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+constexpr int RB = 2048;  // buckets per pass (11 bits; last pass uses 10)
+struct SelState {         // per problem (plane z or whole stack) and rank r
+  uint32_t prefix;        // key bits decided so far (high bits)
+  unsigned long long k;   // remaining rank inside the current prefix group
+};
+
+// pass p: histogram of the next digit among voxels whose decided high bits match the problem's prefix.
+// problems: index 2*z + r for planes, 2*Z + r for the whole stack.
+template <class T>
+__global__ __launch_bounds__(256) void select_hist_k(const T* __restrict__ im, int Z, size_t plane, int pass,
+                                                     const SelState* __restrict__ st, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[4][RB];
+  const int z = blockIdx.y;
+  for (int i = threadIdx.x; i < 4 * RB; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+  const uint32_t dmask = pass == 2 ? 0x3ffu : 0x7ffu;
+  const int hi_shift = pass == 0 ? 32 : (pass == 1 ? 21 : 10);
+  uint32_t pre[4];
+  pre[0] = st[2 * z].prefix; pre[1] = st[2 * z + 1].prefix; pre[2] = st[2 * Z].prefix; pre[3] = st[2 * Z + 1].prefix;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+    const uint32_t key = fkey(ldf(im, (size_t)z * plane + i));
+    const uint32_t d = (key >> shift) & dmask;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bool match = hi_shift >= 32 ? true : ((key >> hi_shift) == (pre[q] >> hi_shift));
+      if (match) atomicAdd(&h[q][d], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RB; i += 256) {
+    if (h[0][i]) atomicAdd(&hist[((size_t)(2 * z) * RB) + i], h[0][i]);
+    if (h[1][i]) atomicAdd(&hist[((size_t)(2 * z + 1) * RB) + i], h[1][i]);
+    if (h[2][i]) atomicAdd(&hist[((size_t)(2 * Z) * RB) + i], h[2][i]);
+    if (h[3][i]) atomicAdd(&hist[((size_t)(2 * Z + 1) * RB) + i], h[3][i]);
+  }
+}
+// one thread per problem: pick the bucket holding rank k, extend the prefix
+__global__ void select_pick_k(SelState* st, const unsigned int* __restrict__ hist, int n_prob, int pass) {
+  int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= n_prob) return;
+  const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+  const int nb = pass == 2 ? 1024 : RB;
+  unsigned long long k = st[q].k, cum = 0;
+  int b = 0;
+  for (; b < nb; ++b) {
+    unsigned long long c = hist[(size_t)q * RB + b];
+    if (cum + c > k) break;
+    cum += c;
+  }
+  if (b >= nb) b = nb - 1;
+  st[q].prefix |= (uint32_t)b << shift;
+  st[q].k = k - cum;
+}
+// medians[z] (Z planes) and medians[Z] (whole stack): float32 mean of the two middle order statistics
+__global__ void select_finish_k(const SelState* __restrict__ st, int Z, float* __restrict__ med) {
+  int z = blockIdx.x * 64 + threadIdx.x;
+  if (z > Z) return;
+  float a = fkey_inv(st[2 * z].prefix), b = fkey_inv(st[2 * z + 1].prefix);
+  med[z] = (a + b) / 2.0f;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void zshift_apply_k(const T* __restrict__ im, int Z, size_t plane,
+                                                      const float* __restrict__ med, uint16_t* __restrict__ out) {
+  const int z = blockIdx.y;
+  const float mz = med[z], mall = med[Z];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+    float v = ldf(im, (size_t)z * plane + i);
+    out[(size_t)z * plane + i] = to_u16((double)((v / mz) * mall));
+  }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void illum_k(const uint16_t* __restrict__ im, int Z, size_t plane,
+                                               const P* __restrict__ prof, uint16_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+    const P pv = prof[i];
+    for (int z = 0; z < Z; ++z) {
+      // float32(im) / profile : float32 for a float32 profile, float64 for a float64 profile (NumPy promotion)
+      P q = (P)(float)im[(size_t)z * plane + i] / pv;
+      out[(size_t)z * plane + i] = to_u16((double)q);
+    }
+  }
+}
+
+constexpr int MAXC = 8;
+struct ChanPtrs { const uint16_t* in[MAXC]; uint16_t* out[MAXC]; };
+
+template <class P>
+__global__ __launch_bounds__(256) void bleed_k(ChanPtrs ch, int C, int Z, size_t plane, const P* __restrict__ prof) {
+  // prof[(i*C + j) * plane + xy]
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+    for (int z = 0; z < Z; ++z) {
+      P v[MAXC];
+      for (int j = 0; j < C; ++j) v[j] = (P)ch.in[j][(size_t)z * plane + i];
+      for (int a = 0; a < C; ++a) {
+        P s = v[0] * prof[((size_t)a * C) * plane + i];
+        for (int j = 1; j < C; ++j) s = s + v[j] * prof[((size_t)a * C + j) * plane + i];
+        s = s > (P)65535 ? (P)65535 : s;
+        s = s < (P)0 ? (P)0 : s;
+        ch.out[a][(size_t)z * plane + i] = to_u16((double)s);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// corrections.py:479-487 Z_Shift_Correction(im.astype(float32), dtype=uint16): out (uint16) = im / median_z * median
+int ia3_z_shift_correction(const void* im, int dtype, int Z, int X, int Y, void* out_u16, float* medians_out) {
+  ia3_stack* s = nullptr;
+  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
+  hipStream_t st = stream();
+  const size_t plane = (size_t)X * Y, n = plane * Z;
+  const int n_prob = 2 * (Z + 1);
+  Scratch dst((size_t)n_prob * sizeof(SelState)), dh((size_t)n_prob * RB * sizeof(unsigned int)),
+      dmed((size_t)(Z + 1) * sizeof(float)), dout(n * sizeof(uint16_t));
+  if (!dst.p || !dh.p || !dmed.p || !dout.p) { ia3_stack_free(s); return IA3_ENOMEM; }
+  std::vector<SelState> hs(n_prob);
+  for (int z = 0; z <= Z; ++z) {
+    const unsigned long long cnt = z < Z ? plane : n;
+    hs[2 * z] = SelState{0u, (cnt - 1) / 2};
+    hs[2 * z + 1] = SelState{0u, cnt / 2};
+  }
+  hipError_t e = hipMemcpyAsync(dst.p, hs.data(), hs.size() * sizeof(SelState), hipMemcpyHostToDevice, st);
+  unsigned gx = (unsigned)((plane + 256 * 16 - 1) / (256 * 16));
+  if (gx < 1) gx = 1;
+  {
+    ProfScope ps("zshift_median");
+    for (int pass = 0; pass < 3 && e == hipSuccess; ++pass) {
+      e = hipMemsetAsync(dh.p, 0, (size_t)n_prob * RB * sizeof(unsigned int), st);
+      if (dtype == IA3_F32) hipLaunchKernelGGL((select_hist_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)s->d, Z, plane, pass, (const SelState*)dst.p, dh.as<unsigned int>());
+      else hipLaunchKernelGGL((select_hist_k<uint16_t>), dim3(gx, Z), dim3(256), 0, st, (const uint16_t*)s->d, Z, plane, pass, (const SelState*)dst.p, dh.as<unsigned int>());
+      hipLaunchKernelGGL(select_pick_k, dim3((n_prob + 63) / 64), dim3(64), 0, st, dst.as<SelState>(), (const unsigned int*)dh.p, n_prob, pass);
+    }
+    hipLaunchKernelGGL(select_finish_k, dim3((Z + 64) / 64), dim3(64), 0, st, (const SelState*)dst.p, Z, dmed.as<float>());
+  }
+  {
+    ProfScope ps("zshift_apply");
+    if (dtype == IA3_F32) hipLaunchKernelGGL((zshift_apply_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)s->d, Z, plane, (const float*)dmed.p, dout.as<uint16_t>());
+    else hipLaunchKernelGGL((zshift_apply_k<uint16_t>), dim3(gx, Z), dim3(256), 0, st, (const uint16_t*)s->d, Z, plane, (const float*)dmed.p, dout.as<uint16_t>());
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out_u16, dout.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && medians_out) e = hipMemcpyAsync(medians_out, dmed.p, (size_t)(Z + 1) * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  ia3_stack_free(s);
+  if (e != hipSuccess) return set_error(IA3_EHIP, "z-shift correction failed: %s", hipGetErrorString(e));
+  return IA3_OK;
+}
+
+// io_tools/load.py:373-384: out = (im.astype(float32) / profile[None]).astype(uint16); profile (X,Y) f32 (1) or f64 (2)
+int ia3_illumination_correct(const void* im_u16, int Z, int X, int Y, const void* profile, int prof_dtype, void* out_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im_u16 || !profile || !out_u16) return set_error(IA3_EINVAL, "null argument");
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  hipStream_t st = stream();
+  const size_t plane = (size_t)X * Y, n = plane * Z, pb = plane * (prof_dtype == 1 ? 4 : 8);
+  Scratch din(n * 2), dout(n * 2), dp(pb);
+  if (!din.p || !dout.p || !dp.p) return IA3_ENOMEM;
+  IA3_HIP(hipMemcpyAsync(din.p, im_u16, n * 2, hipMemcpyHostToDevice, st));
+  IA3_HIP(hipMemcpyAsync(dp.p, profile, pb, hipMemcpyHostToDevice, st));
+  unsigned gx = (unsigned)((plane + 255) / 256);
+  {
+    ProfScope ps("illumination");
+    if (prof_dtype == 1) hipLaunchKernelGGL((illum_k<float>), dim3(gx), dim3(256), 0, st, din.as<uint16_t>(), Z, plane, (const float*)dp.p, dout.as<uint16_t>());
+    else hipLaunchKernelGGL((illum_k<double>), dim3(gx), dim3(256), 0, st, din.as<uint16_t>(), Z, plane, (const double*)dp.p, dout.as<uint16_t>());
+  }
+  IA3_KCHECK();
+  IA3_HIP(hipMemcpyAsync(out_u16, dout.p, n * 2, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  return IA3_OK;
+}
+
+// io_tools/load.py:348-370: out_i = clip(sum_j ims_j * profile[i,j]).astype(uint16); profile (C,C,X,Y)
+int ia3_bleedthrough_correct(const void* const* ims_u16, int C, int Z, int X, int Y, const void* profile, int prof_dtype,
+                             void* const* outs_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!ims_u16 || !profile || !outs_u16) return set_error(IA3_EINVAL, "null argument");
+  if (C < 1 || C > MAXC) return set_error(IA3_EUNSUPPORTED, "1..%d channels supported, got %d", MAXC, C);
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  hipStream_t st = stream();
+  const size_t plane = (size_t)X * Y, n = plane * Z, pb = plane * C * C * (prof_dtype == 1 ? 4 : 8);
+  Scratch din(n * 2 * C), dout(n * 2 * C), dp(pb);
+  if (!din.p || !dout.p || !dp.p) return IA3_ENOMEM;
+  ChanPtrs ch;
+  for (int j = 0; j < C; ++j) {
+    if (!ims_u16[j] || !outs_u16[j]) return set_error(IA3_EINVAL, "null channel pointer");
+    ch.in[j] = din.as<uint16_t>() + (size_t)j * n;
+    ch.out[j] = dout.as<uint16_t>() + (size_t)j * n;
+    IA3_HIP(hipMemcpyAsync((void*)ch.in[j], ims_u16[j], n * 2, hipMemcpyHostToDevice, st));
+  }
+  IA3_HIP(hipMemcpyAsync(dp.p, profile, pb, hipMemcpyHostToDevice, st));
+  unsigned gx = (unsigned)((plane + 255) / 256);
+  {
+    ProfScope ps("bleedthrough");
+    if (prof_dtype == 1) hipLaunchKernelGGL((bleed_k<float>), dim3(gx), dim3(256), 0, st, ch, C, Z, plane, (const float*)dp.p);
+    else hipLaunchKernelGGL((bleed_k<double>), dim3(gx), dim3(256), 0, st, ch, C, Z, plane, (const double*)dp.p);
+  }
+  IA3_KCHECK();
+  for (int j = 0; j < C; ++j) IA3_HIP(hipMemcpyAsync(outs_u16[j], ch.out[j], n * 2, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  return IA3_OK;
+}
+
+}  // extern "C"

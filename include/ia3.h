@@ -82,6 +82,17 @@ int ia3_gaussian_highpass_dev(const ia3_stack* im, double sigma, double truncate
 int ia3_remove_hot_pixels(const void* im, int dtype, int Z, int X, int Y, double hot_pix_th, double hot_th,
                           void* out, int* n_hot);
 
+/* Pre-corrections of io_tools/load.py:337-384 (correct_fov_image), uint16 outputs with NumPy's cast rules.
+ * corrections.py:479-487 Z_Shift_Correction: out = u16(f32(im) / median_z * median_all); medians_out (Z+1
+ * floats, per-plane then whole-stack) may be NULL. */
+int ia3_z_shift_correction(const void* im, int dtype, int Z, int X, int Y, void* out_u16, float* medians_out);
+/* io_tools/load.py:373-384: out = u16(f32(im) / profile[None]); profile (X,Y), prof_dtype 1 = float32, 2 = float64 */
+int ia3_illumination_correct(const void* im_u16, int Z, int X, int Y, const void* profile, int prof_dtype,
+                             void* out_u16);
+/* io_tools/load.py:348-370: outs[i] = u16(clip(sum_j ims[j] * profile[i,j])); profile (C,C,X,Y), C <= 8 */
+int ia3_bleedthrough_correct(const void* const* ims_u16, int C, int Z, int X, int Y, const void* profile,
+                             int prof_dtype, void* const* outs_u16);
+
 /* ---- seeding: spot_tools/fitting.py:20-154 get_seeds ------------------------------------------ */
 typedef struct ia3_seed_params {
   double th_seed;               /* threshold on max_im - min_im */

@@ -872,3 +872,32 @@ def warp_3d_image(image, drift, chromatic_profile=None, warp_order=1, border_mod
     out = map_coordinates(image, coords.reshape(coords.shape[0], -1), order=warp_order,
                           mode=border_mode, cval=np.min(image))
     return out.reshape(image.shape).astype(image.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# (a13) elementwise stages of correct_fov_image, io_tools/load.py:337-384 (the reference's own NumPy
+# expressions, verbatim in structure; corrections.py:479-487 for the z-shift)
+# ----------------------------------------------------------------------------------------------
+
+
+def z_shift_correction(im, dtype=np.uint16):
+    """corrections.py:479-487 as called at io_tools/load.py:342 with ``im.astype(np.float32)``."""
+    im = im.astype(np.float32)
+    nim = im / np.median(im, axis=(1, 2))[:, np.newaxis, np.newaxis] * np.median(im)
+    return nim.astype(dtype)
+
+
+def illumination_correction(im, profile, output_dtype=np.uint16):
+    """io_tools/load.py:382."""
+    return (im.astype(np.float32) / profile[np.newaxis, :]).astype(output_dtype)
+
+
+def bleedthrough_correction(ims, bleed_profile, output_dtype=np.uint16):
+    """io_tools/load.py:355-367."""
+    outs = []
+    for i in range(len(ims)):
+        nim = np.sum([im * bleed_profile[i, j] for j, im in enumerate(ims)], axis=0)
+        nim[nim > np.iinfo(output_dtype).max] = np.iinfo(output_dtype).max
+        nim[nim < np.iinfo(output_dtype).min] = np.iinfo(output_dtype).min
+        outs.append(nim.astype(output_dtype))
+    return outs
