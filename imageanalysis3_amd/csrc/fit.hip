@@ -27,7 +27,10 @@
 #include <numeric>
 #include <math.h>
 #include <string.h>
-#include <unordered_map>
+#include <stddef.h>
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 using namespace ia3;
 
@@ -41,6 +44,8 @@ struct SeedState {
   double delta;   // delta_center that fit used (needed to rebuild its reconstruction)
   int success;    // GaussianFit.success of the last attempt
   int has_rec;    // a reconstruction exists (ims_rec[ic] is an array, not NaN)
+  int conv;       // converged flag of repeatfit (:680)
+  int pad;
 };
 
 struct FitArgs {
@@ -76,6 +81,17 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { double o = __shfl_xor(v, m); v = o > v ? o : v; }
   return v;
+}
+
+// Cross-wave hand-off of per-seed results (persistent kernel below): every store of the handed-off words is a
+// relaxed agent-scope atomic (write-through `sc1`), every load of them a relaxed agent-scope atomic (`sc1`, served
+// by L2/memory, never by a stale L1 line); the producer drains its stores (vmcnt(0)) before it raises done[i].
+template <class T> __device__ __forceinline__ T ld_sc1(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define LDH(ptr) ld_sc1(ptr)
+template <class T> __device__ __forceinline__ void st_sc1(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ double load_voxel(const void* im, int dtype, size_t idx) {
@@ -187,23 +203,22 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, const flo
     fa.nvox[i] = n;
     fa.nfev[i] += nfev;
     SeedState& st = fa.state[i];
-    st.success = ok ? 1 : 0;
+    st_sc1(&st.success, ok ? 1 : 0);
     if (ok) {
-      for (int k = 0; k < NP; ++k) st.x[k] = w.x[k];
-      st.delta = delta;
-      st.has_rec = 1;
-      for (int k = 0; k < 11; ++k) fa.ps[(size_t)i * 11 + k] = p[k];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) st_sc1(&st.x[k], w.x[k]);
+      st_sc1(&st.delta, delta);
+      st_sc1(&st.has_rec, 1);
+#pragma unroll
+      for (int k = 0; k < 11; ++k) st_sc1(&fa.ps[(size_t)i * 11 + k], p[k]);
       atomicAdd(&fa.counters[0], 1ull);
       atomicAdd(&fa.counters[1], (unsigned long long)nfev);
     }
   }
 }
 
-// ---- firstfit: one wave per seed (Fitting_v4.py:590-639) ----------------------------------------
-__global__ __launch_bounds__(64) void fit_first_k(FitArgs fa, int n_seeds) {
-  __shared__ LMWork w;
-  const int i = blockIdx.x;
-  if (i >= n_seeds) return;
+// ---- stage 0 = firstfit of one seed (Fitting_v4.py:606-637) -----------------------------------------
+__device__ __forceinline__ void do_first(const FitArgs& fa, LMWork& w, int i) {
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
@@ -246,88 +261,155 @@ __global__ __launch_bounds__(64) void fit_first_k(FitArgs fa, int n_seeds) {
   store_result(fa, i, p, w, fa.delta_first, ok, n, nfev);
 }
 
-// ---- repeatfit: one wave per connected component of the ball-overlap graph (:641-683) -----------
-__global__ __launch_bounds__(64) void fit_repeat_k(FitArgs fa, const int* __restrict__ comp_off,
-                                                   const int* __restrict__ comp_mem, int n_comp) {
-  __shared__ LMWork w;
-  const int c = blockIdx.x;
-  if (c >= n_comp) return;
+// ---- stage k >= 1 = one seed's refit in sweep k of repeatfit (:651-680); returns "converged" -------------
+__device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
   const int lane = threadIdx.x & 63;
-  const int m0 = comp_off[c], m1 = comp_off[c + 1];
   const int r = fa.radius;
-  int sweeps = 0;
-  bool all_conv;
-  do {
-    all_conv = true;
-    for (int m = m0; m < m1; ++m) {
-      const int i = comp_mem[m];
-      if (fa.conv[i]) continue;
-      const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
-      const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
-      Ball ball;
-      double vals[SLOTS];
-      ball.valid = 0;
+  const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
+  const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
+  Ball ball;
+  double vals[SLOTS];
+  ball.valid = 0;
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        const int vi = lane + 64 * s;
-        ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
-        if (vi < fa.nball) {
-          const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
-          if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
-            ball.valid |= 1u << s;
-            vals[s] = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
-            ball.cz[s] = (float)z; ball.cx[s] = (float)x; ball.cy[s] = (float)y;
-          }
-        }
+  for (int s = 0; s < SLOTS; ++s) {
+    const int vi = lane + 64 * s;
+    ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
+    if (vi < fa.nball) {
+      const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
+      if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
+        ball.valid |= 1u << s;
+        vals[s] = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
+        ball.cz[s] = (float)z; ball.cx[s] = (float)x; ball.cy[s] = (float)y;
       }
-      // subtract the current reconstructions of the overlapping seeds (= im_add + own rec, :658-662)
-      for (int q = fa.nbr_off[i]; q < fa.nbr_off[i + 1]; ++q) {
-        const int j = fa.nbr_idx[q];
-        const SeedState& sj = fa.state[j];
-        if (!sj.has_rec) continue;
-        FitCfg cj;
-        cj.min_ws = fa.min_ws; cj.max_ws = fa.max_ws; cj.delta = sj.delta; cj.init_w = fa.init_w;
-        cj.c0[0] = fa.seeds[3 * j]; cj.c0[1] = fa.seeds[3 * j + 1]; cj.c0[2] = fa.seeds[3 * j + 2];
-        const int jz = (int)cj.c0[0], jx = (int)cj.c0[1], jy = (int)cj.c0[2];
-        double xj[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) xj[k] = sj.x[k];
-        Geom gj;
-        make_geom(xj, cj, gj);
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          if (ball.valid & (1u << s)) {
-            const int oz = (int)ball.cz[s] - jz, ox = (int)ball.cx[s] - jx, oy = (int)ball.cy[s] - jy;
-            if (oz >= -r && oz < r && ox >= -r && ox < r && oy >= -r && oy < r &&
-                oz * oz + ox * ox + oy * oy <= r * r)
-              vals[s] -= model_f0(gj, (double)ball.cz[s], (double)ball.cx[s], (double)ball.cy[s]);
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) ball.dat[s] = (float)vals[s];
-      const int n = (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
-      const int success_old = fa.state[i].success;
-      const float co0 = fa.ps[(size_t)i * 11 + 1], co1 = fa.ps[(size_t)i * 11 + 2], co2 = fa.ps[(size_t)i * 11 + 3];
-      float p[11];
-      int nfev = 0;
-      const bool ok = n >= NP;
-      if (ok) nfev = wave_gaussfit(fa, w, ball, vals, 2, c0, fa.delta_repeat, n, p);
-      store_result(fa, i, p, w, fa.delta_repeat, ok, n, nfev);
-      // convergence (:677-680): float32 centre differences, compared in float64
-      bool cv = true;
-      if (ok && success_old) {
-        const float d0 = co0 - p[1], d1 = co1 - p[2], d2 = co2 - p[3];
-        const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
-        cv = (double)dist < fa.dist_th2;
-      }
-      if (lane == 0) fa.conv[i] = cv ? 1 : 0;
-      all_conv = all_conv && cv;
-      __threadfence();  // this wave re-reads state/ps/conv of its own component from memory
     }
-    ++sweeps;
-  } while (!all_conv && sweeps <= fa.n_max_iter);
-  if (lane == 0) atomicMax(fa.n_iter, sweeps);
+  }
+  // subtract the current reconstructions of the overlapping seeds (= im_add + own rec, :658-662)
+  for (int q = fa.nbr_off[i]; q < fa.nbr_off[i + 1]; ++q) {
+    const int j = fa.nbr_idx[q];
+    const SeedState& sj = fa.state[j];
+    if (!LDH(&sj.has_rec)) continue;
+    FitCfg cj;
+    cj.min_ws = fa.min_ws; cj.max_ws = fa.max_ws; cj.delta = LDH(&sj.delta); cj.init_w = fa.init_w;
+    cj.c0[0] = fa.seeds[3 * j]; cj.c0[1] = fa.seeds[3 * j + 1]; cj.c0[2] = fa.seeds[3 * j + 2];
+    const int jz = (int)cj.c0[0], jx = (int)cj.c0[1], jy = (int)cj.c0[2];
+    double xj[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) xj[k] = LDH(&sj.x[k]);
+    Geom gj;
+    make_geom(xj, cj, gj);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      if (ball.valid & (1u << s)) {
+        const int oz = (int)ball.cz[s] - jz, ox = (int)ball.cx[s] - jx, oy = (int)ball.cy[s] - jy;
+        if (oz >= -r && oz < r && ox >= -r && ox < r && oy >= -r && oy < r && oz * oz + ox * ox + oy * oy <= r * r)
+          vals[s] -= model_f0(gj, (double)ball.cz[s], (double)ball.cx[s], (double)ball.cy[s]);
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) ball.dat[s] = (float)vals[s];
+  const int n = (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
+  const int success_old = LDH(&fa.state[i].success);
+  const float co0 = LDH(&fa.ps[(size_t)i * 11 + 1]), co1 = LDH(&fa.ps[(size_t)i * 11 + 2]),
+              co2 = LDH(&fa.ps[(size_t)i * 11 + 3]);
+  float p[11];
+  int nfev = 0;
+  const bool ok = n >= NP;
+  if (ok) nfev = wave_gaussfit(fa, w, ball, vals, 2, c0, fa.delta_repeat, n, p);
+  store_result(fa, i, p, w, fa.delta_repeat, ok, n, nfev);
+  // convergence (:677-680): float32 centre differences, compared in float64
+  bool cv = true;
+  if (ok && success_old) {
+    const float d0 = co0 - p[1], d1 = co1 - p[2], d2 = co2 - p[3];
+    const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
+    cv = (double)dist < fa.dist_th2;
+  }
+  return cv;
+}
+
+// ---- dependency-ordered fit kernel ------------------------------------------------------------------------
+// Work list = stages x seeds, stage-major: stage 0 is firstfit, stage k>=1 is sweep k of repeatfit; inside a
+// stage the seeds come in `order` (components by size, members by index).  Every wave claims the next position
+// with one atomic and waits until the fits it depends on have published:
+//     (i, k>=1) needs   own stage k-1,   neighbours j < i at stage k   (already refitted in this sweep, the
+//     reference's in-place Gauss–Seidel order),   neighbours j > i at stage k-1.
+// done[j] = number of stages seed j has completed.  All dependencies of a position lie EARLIER in the list, so
+// whoever holds the earliest unfinished position can always run: no deadlock, no co-residency requirement.
+// Hand-off: producer sc1 stores -> vmcnt(0) -> relaxed agent store of done[j]; consumer relaxed agent poll of
+// done[j] -> sc1 loads of the payload (MI355X_MICROARCH.md "Valid forms": every load and store of the handed-off
+// words is sc1, the storing lane drains before it raises the counter, the polling wave loads only afterwards).
+struct StageCtl {
+  unsigned int claim;       // next work-list position
+  int n_unconv;             // seeds not yet converged (repeat stages stop when it reaches 0)
+  int abort;                // set if a spin-wait exceeded its bound (never expected)
+  int pad;
+};
+
+// wave-uniform poll: every lane issues the (same-address) load, lane 0's value decides for the whole wave
+__device__ __forceinline__ bool wait_done(const int* done, int j, int need, StageCtl* ctl) {
+  long long spins = 0;
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= need) return true;
+    __builtin_amdgcn_s_sleep(16);
+    const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (++spins > (1LL << 24) || ab) {
+      __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+}
+
+__device__ __forceinline__ void publish(int* done, int i, int value) {
+  if ((threadIdx.x & 63) == 0) {   // the same lane issued every hand-off store of this fit
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // max, not store: an early-exiting wave may already have marked this seed "all stages done" (1 << 20)
+    // while the holder of an earlier position of the same seed publishes its smaller stage count afterwards
+    __hip_atomic_fetch_max(&done[i], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One block (= one wave) per work-list position.  The position is a TICKET drawn when the block starts running,
+// not blockIdx: tickets are handed out in the order blocks actually start, so everything a block may wait for is
+// held by a block that is already running (or done) whatever order the dispatcher picks.
+__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, const int* __restrict__ order, int n, int stage0,
+                                                   int stage1, StageCtl* ctl, int* done) {
+  __shared__ LMWork w;
+  const int lane = threadIdx.x & 63;
+  const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
+  unsigned pos = 0;
+  if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
+  pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+  if (pos >= total) return;
+  const int k = stage0 + (int)(pos / (unsigned)n);
+  const int i = order[pos % (unsigned)n];
+  if (k == 0) {
+    do_first(fa, w, i);
+    publish(done, i, 1);
+    return;
+  }
+  // nothing left to refit anywhere: every remaining position is a skip.  The claimed position is still
+  // published (as "all stages done") so that a block which passed this check earlier and waits on it can go on.
+  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
+    publish(done, i, 1 << 20);
+    return;
+  }
+  if (!wait_done(done, i, k, ctl)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return; }   // converged: skipped (:652)
+  for (int q = fa.nbr_off[i]; q < fa.nbr_off[i + 1]; ++q) {
+    const int j = fa.nbr_idx[q];
+    if (!wait_done(done, j, j < i ? k + 1 : k, ctl)) return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const bool cv = do_repeat(fa, w, i);
+  if (lane == 0) {
+    st_sc1(&fa.state[i].conv, cv ? 1 : 0);
+    atomicMax(fa.n_iter, k);
+    if (cv) atomicSub(&ctl->n_unconv, 1);
+  }
+  publish(done, i, k + 1);
 }
 
 // ---- standalone GaussianFit(im, X, center).fit() on explicit voxel lists (Fitting_v4.py:165-396) --
@@ -399,9 +481,13 @@ struct ia3_fitter {
   int n;
   int n_comp;
   int nball;
+  void* pool;          // one device block from the scratch cache holding every array below
+  size_t pool_bytes;
   void *d_seeds, *d_nbr_off, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
-      *d_counters, *d_comp_off, *d_comp_mem;
+      *d_counters, *d_comp_off, *d_comp_mem, *d_done, *d_ctl;
   bool first_done;
+  StageCtl host_ctl;
+  std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
 };
 
 namespace {
@@ -415,67 +501,75 @@ int build_ball(int r, std::vector<signed char>& ball) {
   return (int)(ball.size() / 4);
 }
 
-struct Cell { long long z, x, y; bool operator==(const Cell& o) const { return z == o.z && x == o.x && y == o.y; } };
-struct CellHash { size_t operator()(const Cell& c) const { return (size_t)(c.z * 73856093LL ^ c.x * 19349663LL ^ c.y * 83492791LL); } };
-
-// neighbours j != i with |c_i - c_j|² <= (2r)², ascending; connected components of that graph
+// neighbours j != i with |c_i - c_j|² <= r2, ascending; connected components of that graph.
+// Spatial hash on a sorted key array (cell edge = sqrt(r2)), union-find for the components.
 void build_graph(const double* c, int n, double r2, std::vector<int>& off, std::vector<int>& idx,
                  std::vector<int>& comp_off, std::vector<int>& comp_mem) {
   const double cell = sqrt(r2) > 0 ? sqrt(r2) : 1.0;
-  std::unordered_map<Cell, std::vector<int>, CellHash> grid;
-  grid.reserve((size_t)n * 2);
-  auto key = [&](int i) { return Cell{(long long)floor(c[3 * i] / cell), (long long)floor(c[3 * i + 1] / cell), (long long)floor(c[3 * i + 2] / cell)}; };
-  for (int i = 0; i < n; ++i) grid[key(i)].push_back(i);
+  struct Key { long long k; int i; };
+  auto pack = [](long long z, long long x, long long y) { return ((z + (1LL << 20)) << 42) | ((x + (1LL << 20)) << 21) | (y + (1LL << 20)); };
+  std::vector<Key> keys(n);
+  std::vector<long long> cz(n), cx(n), cy(n);
+  for (int i = 0; i < n; ++i) {
+    cz[i] = (long long)floor(c[3 * i] / cell); cx[i] = (long long)floor(c[3 * i + 1] / cell); cy[i] = (long long)floor(c[3 * i + 2] / cell);
+    keys[i] = Key{pack(cz[i], cx[i], cy[i]), i};
+  }
+  std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.k < b.k || (a.k == b.k && a.i < b.i); });
   off.assign(n + 1, 0);
   idx.clear();
   std::vector<int> parent(n);
   std::iota(parent.begin(), parent.end(), 0);
   auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
-  std::vector<int> tmp;
-  for (int i = 0; i < n; ++i) {
-    tmp.clear();
-    Cell k = key(i);
+  // sort-merge join: walking the seeds in key order, the first key of every neighbour-cell range is monotone,
+  // so each of the 9 (dz,dx) offsets keeps one moving cursor (3 adjacent y-cells form one contiguous key range)
+  std::vector<std::pair<int, int>> edges;  // (i, j), i != j, both directions
+  size_t cur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s_ = 0; s_ < n; ++s_) {
+    const int i = keys[s_].i;
+    int q = 0;
     for (long long dz = -1; dz <= 1; ++dz)
-      for (long long dx = -1; dx <= 1; ++dx)
-        for (long long dy = -1; dy <= 1; ++dy) {
-          auto it = grid.find(Cell{k.z + dz, k.x + dx, k.y + dy});
-          if (it == grid.end()) continue;
-          for (int j : it->second) {
-            if (j == i) continue;
-            double a = c[3 * i] - c[3 * j], b = c[3 * i + 1] - c[3 * j + 1], d = c[3 * i + 2] - c[3 * j + 2];
-            if (a * a + b * b + d * d <= r2) tmp.push_back(j);
-          }
+      for (long long dx = -1; dx <= 1; ++dx, ++q) {
+        const long long lo = pack(cz[i] + dz, cx[i] + dx, cy[i] - 1), hi = pack(cz[i] + dz, cx[i] + dx, cy[i] + 1);
+        size_t& p0 = cur[q];
+        while (p0 < (size_t)n && keys[p0].k < lo) ++p0;
+        for (size_t t = p0; t < (size_t)n && keys[t].k <= hi; ++t) {
+          const int j = keys[t].i;
+          if (j == i) continue;
+          double a = c[3 * i] - c[3 * j], b = c[3 * i + 1] - c[3 * j + 1], d = c[3 * i + 2] - c[3 * j + 2];
+          if (a * a + b * b + d * d <= r2) edges.emplace_back(i, j);
         }
-    std::sort(tmp.begin(), tmp.end());
-    for (int j : tmp) { idx.push_back(j); int ra = find(i), rb = find(j); if (ra != rb) parent[ra > rb ? ra : rb] = ra > rb ? rb : ra; }
-    off[i + 1] = (int)idx.size();
+      }
+  }
+  std::sort(edges.begin(), edges.end());
+  {
+    size_t e = 0;
+    for (int i = 0; i < n; ++i) {
+      for (; e < edges.size() && edges[e].first == i; ++e) {
+        const int j = edges[e].second;
+        idx.push_back(j);
+        int ra = find(i), rb = find(j);
+        if (ra != rb) parent[ra > rb ? ra : rb] = ra > rb ? rb : ra;
+      }
+      off[i + 1] = (int)idx.size();
+    }
   }
   // components: members ascending; big components first (they are the serial tail of repeatfit)
-  std::vector<std::vector<int>> comps;
-  std::vector<int> cid(n, -1);
+  std::vector<int> cid(n, -1), csize;
   for (int i = 0; i < n; ++i) {
     int rt = find(i);
-    if (cid[rt] < 0) { cid[rt] = (int)comps.size(); comps.emplace_back(); }
-    comps[cid[rt]].push_back(i);
+    if (cid[rt] < 0) { cid[rt] = (int)csize.size(); csize.push_back(0); }
+    csize[cid[rt]]++;
   }
-  std::stable_sort(comps.begin(), comps.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });
-  comp_off.assign(1, 0);
-  comp_mem.clear();
-  for (auto& cm : comps) { comp_mem.insert(comp_mem.end(), cm.begin(), cm.end()); comp_off.push_back((int)comp_mem.size()); }
-}
-
-template <class T>
-int dev_upload(void** d, const std::vector<T>& h) {
-  size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
-  if (hipMalloc(d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
-  if (h.size()) IA3_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return IA3_OK;
-}
-int dev_zero(void** d, size_t bytes) {
-  if (bytes == 0) bytes = 8;
-  if (hipMalloc(d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
-  IA3_HIP(hipMemset(*d, 0, bytes));
-  return IA3_OK;
+  const int nc = (int)csize.size();
+  std::vector<int> order(nc);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return csize[a] > csize[b]; });
+  std::vector<int> rank(nc);
+  comp_off.assign(nc + 1, 0);
+  for (int r = 0; r < nc; ++r) { rank[order[r]] = r; comp_off[r + 1] = comp_off[r] + csize[order[r]]; }
+  comp_mem.assign(n, 0);
+  std::vector<int> fill(comp_off.begin(), comp_off.end() - 1);
+  for (int i = 0; i < n; ++i) comp_mem[fill[rank[cid[find(i)]]]++] = i;
 }
 
 FitArgs make_args(const ia3_fitter* f) {
@@ -500,9 +594,7 @@ extern "C" {
 
 void ia3_fit_destroy(ia3_fitter* f) {
   if (!f) return;
-  void* ptrs[] = {f->d_seeds, f->d_nbr_off, f->d_nbr_idx, f->d_ball, f->d_state, f->d_ps, f->d_nvox, f->d_nfev,
-                  f->d_conv, f->d_niter, f->d_counters, f->d_comp_off, f->d_comp_mem};
-  for (void* p : ptrs) if (p) hipFree(p);
+  if (f->pool) ws_put(f->pool);   // back to the scratch cache; reuse is stream-ordered
   delete f;
 }
 
@@ -516,42 +608,110 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
   if (nball > MAXBALL) return set_error(IA3_EUNSUPPORTED, "radius_fit %d gives %d voxels (> %d)", p->radius_fit, nball, MAXBALL);
   for (int i = 0; i < 3 * n; ++i)
     if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
-  ia3_fitter* f = new ia3_fitter();
-  memset(f, 0, sizeof(*f));
+  ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
   f->im = im; f->prm = *p; f->n = n; f->nball = nball;
-  std::vector<double> seeds(centers_zxy, centers_zxy + 3 * (size_t)n);
   std::vector<int> off, idx, coff, cmem;
   double rr = 2.0 * p->radius_fit;
-  build_graph(seeds.data(), n, rr * rr, off, idx, coff, cmem);
+  build_graph(centers_zxy, n, rr * rr, off, idx, coff, cmem);
   f->n_comp = (int)coff.size() - 1;
-  rc = dev_upload(&f->d_seeds, seeds);
-  if (!rc) rc = dev_upload(&f->d_nbr_off, off);
-  if (!rc) rc = dev_upload(&f->d_nbr_idx, idx);
-  if (!rc) rc = dev_upload(&f->d_ball, ball);
-  if (!rc) rc = dev_upload(&f->d_comp_off, coff);
-  if (!rc) rc = dev_upload(&f->d_comp_mem, cmem);
-  if (!rc) rc = dev_zero(&f->d_state, sizeof(SeedState) * (size_t)n);
-  if (!rc) rc = dev_zero(&f->d_nvox, sizeof(int) * (size_t)n);
-  if (!rc) rc = dev_zero(&f->d_nfev, sizeof(int) * (size_t)n);
-  if (!rc) rc = dev_zero(&f->d_conv, (size_t)n);
-  if (!rc) rc = dev_zero(&f->d_niter, sizeof(int));
-  if (!rc) rc = dev_zero(&f->d_counters, 2 * sizeof(unsigned long long));
-  if (!rc) {
-    std::vector<float> nanrows((size_t)n * 11, NAN);  // failed fits stay NaN rows (:636)
-    rc = dev_upload(&f->d_ps, nanrows);
-  }
-  if (rc) { ia3_fit_destroy(f); return rc; }
+  (void)coff;
+  // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows]
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n), b_off = al(sizeof(int) * ((size_t)n + 1)),
+               b_idx = al(sizeof(int) * idx.size()), b_ball = al(ball.size()), b_coff = al(sizeof(int) * coff.size()),
+               b_cmem = al(sizeof(int) * cmem.size());
+  const size_t up_bytes = b_seeds + b_off + b_idx + b_ball + b_coff + b_cmem;
+  const size_t b_state = al(sizeof(SeedState) * (size_t)n), b_nvox = al(sizeof(int) * (size_t)n), b_nfev = b_nvox,
+               b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = 256;
+  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl;
+  const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
+  f->pool_bytes = up_bytes + zero_bytes + b_ps;
+  f->pool = ws_get(f->pool_bytes);
+  if (!f->pool) { delete f; return IA3_ENOMEM; }
+  char* base = (char*)f->pool;
+  size_t o = 0;
+  f->d_seeds = base + o; o += b_seeds;
+  f->d_nbr_off = base + o; o += b_off;
+  f->d_nbr_idx = base + o; o += b_idx;
+  f->d_ball = base + o; o += b_ball;
+  f->d_comp_off = base + o; o += b_coff;
+  f->d_comp_mem = base + o; o += b_cmem;
+  char* zero0 = base + o;
+  f->d_state = base + o; o += b_state;
+  f->d_nvox = base + o; o += b_nvox;
+  f->d_nfev = base + o; o += b_nfev;
+  f->d_conv = base + o; o += b_conv;
+  f->d_niter = base + o; o += b_niter;
+  f->d_counters = base + o; o += b_cnt;
+  f->d_done = base + o; o += b_done;
+  f->d_ctl = base + o; o += b_ctl;
+  f->d_ps = base + o;
+  // stage the read-only part contiguously and ship it with one copy
+  std::vector<char>& host = f->host_stage;
+  host.assign(up_bytes, 0);
+  size_t h = 0;
+  if (n) memcpy(host.data() + h, centers_zxy, sizeof(double) * 3 * (size_t)n);
+  h += b_seeds;
+  memcpy(host.data() + h, off.data(), sizeof(int) * off.size()); h += b_off;
+  if (!idx.empty()) memcpy(host.data() + h, idx.data(), sizeof(int) * idx.size());
+  h += b_idx;
+  memcpy(host.data() + h, ball.data(), ball.size()); h += b_ball;
+  memcpy(host.data() + h, coff.data(), sizeof(int) * coff.size()); h += b_coff;
+  if (!cmem.empty()) memcpy(host.data() + h, cmem.data(), sizeof(int) * cmem.size());
+  hipStream_t st = stream();
+  hipError_t e = hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(zero0, 0, zero_bytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(f->d_ps, 0xFF, b_ps, st);   // all-ones float32 = NaN: failed fits stay NaN rows (:636)
+  if (e != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "fitter setup failed: %s", hipGetErrorString(e)); }
   *out = f;
+  return IA3_OK;
+}
+
+// Launch the work list for stages [stage0, stage1).  `fresh` re-arms the whole control block (claim = 0,
+// n_unconv = n, abort = 0); otherwise only the ticket counter is reset and n_unconv / done[] carry over.
+static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
+  FitArgs a = make_args(f);
+  hipStream_t st = stream();
+  if (fresh) {
+    f->host_ctl = StageCtl{0u, f->n, 0, 0};
+    IA3_HIP(hipMemcpyAsync(f->d_ctl, &f->host_ctl, sizeof(StageCtl), hipMemcpyHostToDevice, st));
+  } else {
+    IA3_HIP(hipMemsetAsync(f->d_ctl, 0, sizeof(unsigned int), st));   // StageCtl::claim is the first word
+  }
+  long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order)
+  if (blocks < 1) blocks = 1;
+  ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
+  hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, (const int*)f->d_comp_mem, f->n, stage0, stage1,
+                     (StageCtl*)f->d_ctl, (int*)f->d_done);
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+// Sweeps are launched two at a time and the next pair only while some seed is still unconverged: a launch costs
+// one block per (stage, seed) even for converged seeds, and most fields converge after the first sweep.
+static int run_sweeps(ia3_fitter* f, int stage, bool fresh) {
+  const int last = f->prm.n_max_iter + 2;   // sweeps 1 .. n_max_iter+1 (Fitting_v4.py:683)
+  hipStream_t st = stream();
+  while (stage < last) {
+    const int s1 = stage + 2 < last ? stage + 2 : last;
+    int rc = launch_stages(f, stage, s1, fresh); if (rc) return rc;
+    fresh = false;
+    stage = s1;
+    if (stage >= last) break;
+    StageCtl hc;
+    IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipStreamSynchronize(st));
+    if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+    if (hc.n_unconv <= 0) break;
+  }
   return IA3_OK;
 }
 
 int ia3_fit_first(ia3_fitter* f) {
   if (!f) return set_error(IA3_EINVAL, "null fitter");
   if (f->n > 0) {
-    FitArgs a = make_args(f);
-    ProfScope ps("fit_first");
-    hipLaunchKernelGGL(fit_first_k, dim3((unsigned)f->n), dim3(64), 0, stream(), a, f->n);
-    IA3_KCHECK();
+    IA3_HIP(hipMemsetAsync(f->d_done, 0, sizeof(int) * (size_t)f->n, stream()));
+    int rc = launch_stages(f, 0, 1, true); if (rc) return rc;
   }
   f->first_done = true;
   return IA3_OK;
@@ -562,34 +722,58 @@ int ia3_fit_repeat(ia3_fitter* f, int* n_iter) {
   if (!f->first_done) return set_error(IA3_EINVAL, "repeatfit() before firstfit()");
   int it = 0;
   if (f->n > 0) {
-    FitArgs a = make_args(f);
-    IA3_HIP(hipMemsetAsync(f->d_conv, 0, (size_t)f->n, stream()));
-    IA3_HIP(hipMemsetAsync(f->d_niter, 0, sizeof(int), stream()));
-    {
-      ProfScope ps("fit_repeat");
-      hipLaunchKernelGGL(fit_repeat_k, dim3((unsigned)f->n_comp), dim3(64), 0, stream(), a,
-                         (const int*)f->d_comp_off, (const int*)f->d_comp_mem, f->n_comp);
+    hipStream_t st = stream();
+    IA3_HIP(hipMemset2DAsync((char*)f->d_state + offsetof(SeedState, conv), sizeof(SeedState), 0, sizeof(int), (size_t)f->n, st));
+    IA3_HIP(hipMemsetAsync(f->d_niter, 0, sizeof(int), st));
+    IA3_HIP(hipMemsetD32Async((hipDeviceptr_t)f->d_done, 1, (size_t)f->n, st));   // every seed has completed stage 0
+    int rc = run_sweeps(f, 1, true); if (rc) return rc;
+    if (n_iter) {   // callers that fetch results next pass NULL and read n_iter with them (one sync)
+      IA3_HIP(hipMemcpyAsync(&it, f->d_niter, sizeof(int), hipMemcpyDeviceToHost, st));
+      IA3_HIP(hipStreamSynchronize(st));
     }
-    IA3_KCHECK();
-    IA3_HIP(hipMemcpyAsync(&it, f->d_niter, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    IA3_HIP(hipStreamSynchronize(stream()));
   }
   if (n_iter) *n_iter = it;
   return IA3_OK;
 }
 
-int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox) {
+// firstfit + repeatfit: stage 0 and sweep 1 go out in ONE launch (no host round trip between them)
+int ia3_fit_run(ia3_fitter* f) {
   if (!f) return set_error(IA3_EINVAL, "null fitter");
-  IA3_HIP(hipStreamSynchronize(stream()));
-  if (f->n == 0) return IA3_OK;
-  if (ps) IA3_HIP(hipMemcpy(ps, f->d_ps, sizeof(float) * 11 * (size_t)f->n, hipMemcpyDeviceToHost));
-  if (nvox) IA3_HIP(hipMemcpy(nvox, f->d_nvox, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost));
-  if (success) {
-    std::vector<SeedState> st(f->n);
-    IA3_HIP(hipMemcpy(st.data(), f->d_state, sizeof(SeedState) * (size_t)f->n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)st[i].success;
+  if (f->n > 0) {
+    hipStream_t st = stream();
+    IA3_HIP(hipMemsetAsync(f->d_done, 0, sizeof(int) * (size_t)f->n, st));
+    IA3_HIP(hipMemset2DAsync((char*)f->d_state + offsetof(SeedState, conv), sizeof(SeedState), 0, sizeof(int), (size_t)f->n, st));
+    IA3_HIP(hipMemsetAsync(f->d_niter, 0, sizeof(int), st));
+    int rc = run_sweeps(f, 0, true); if (rc) return rc;
   }
+  f->first_done = true;
   return IA3_OK;
+}
+
+// one synchronisation for everything the caller wants back
+int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, int* n_iter) {
+  if (!f) return set_error(IA3_EINVAL, "null fitter");
+  hipStream_t st = stream();
+  std::vector<SeedState> stv;
+  if (n_iter) { *n_iter = 0; if (f->n) IA3_HIP(hipMemcpyAsync(n_iter, f->d_niter, sizeof(int), hipMemcpyDeviceToHost, st)); }
+  if (f->n > 0) {
+    if (ps) IA3_HIP(hipMemcpyAsync(ps, f->d_ps, sizeof(float) * 11 * (size_t)f->n, hipMemcpyDeviceToHost, st));
+    if (nvox) IA3_HIP(hipMemcpyAsync(nvox, f->d_nvox, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost, st));
+    if (success) {
+      stv.resize(f->n);
+      IA3_HIP(hipMemcpyAsync(stv.data(), f->d_state, sizeof(SeedState) * (size_t)f->n, hipMemcpyDeviceToHost, st));
+    }
+  }
+  StageCtl hc = StageCtl{0u, 0, 0, 0};
+  if (f->n > 0) IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+  if (success) for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)stv[i].success;
+  return IA3_OK;
+}
+
+int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox) {
+  return ia3_fit_results_ex(f, ps, success, nvox, nullptr);
 }
 
 int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev) {
@@ -608,9 +792,8 @@ int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* 
   ia3_fitter* f = nullptr;
   int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
   rc = ia3_fit_create(s, centers_zxy, n, p, &f);
-  if (!rc) rc = ia3_fit_first(f);
-  if (!rc) rc = ia3_fit_repeat(f, n_iter);
-  if (!rc) rc = ia3_fit_results(f, out_ps, success, nullptr);
+  if (!rc) rc = ia3_fit_run(f);
+  if (!rc) rc = ia3_fit_results_ex(f, out_ps, success, nullptr, n_iter);
   ia3_fit_destroy(f);
   ia3_stack_free(s);
   return rc;

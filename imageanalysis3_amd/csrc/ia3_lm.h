@@ -16,31 +16,39 @@
 // widths are equal) are handled the way lmpar's rank-deficient branch does: their step
 // component is zero and the Newton lower bound parl is not used.
 //
+// Every loop has compile-time bounds (NP = 10) and is fully unrolled, so on the GPU all matrix
+// and vector accesses are statically indexed: the persistent state (LMWork, in LDS) is read with
+// immediate offsets and the per-call temporaries (Cholesky factor, work vectors) live in
+// registers.  The factor stores reciprocal diagonals, so a factorisation costs 10 divisions.
+//
 // Host/device agnostic. `Eval` supplies:  double eval(const double* x, double* A, double* g)
-// which returns |f(x)| and, when A != nullptr, fills the packed upper triangle of JᵀJ (row-major,
-// NTRI entries) and g = Jᵀf at the same x.
+// which returns |f(x)| and fills the packed upper triangle of JᵀJ (row-major, NTRI entries) and
+// g = Jᵀf at the same x.
 #pragma once
 #include "ia3_model.h"
 
 namespace ia3 {
 
-IA3_HD int tri(int i, int j) {  // packed upper-triangle index, i <= j
+IA3_HD constexpr int tri(int i, int j) {  // packed upper-triangle index, i <= j
   return i * NP - (i * (i - 1)) / 2 + (j - i);
 }
 
-struct LMWork {
+#if defined(__HIPCC__) || defined(__clang__)
+#define IA3_UNROLL _Pragma("unroll")
+#else
+#define IA3_UNROLL _Pragma("GCC unroll 16")
+#endif
+
+struct LMWork {      // persistent across evaluations (LDS on the device)
   double A[NTRI];    // JᵀJ at the current accepted point
   double g[NP];      // Jᵀf at the current accepted point
   double A1[NTRI];   // the same at the trial point (kept if the step is accepted)
   double g1[NP];
-  double L[NTRI];    // Cholesky factor (upper, packed): A + par D² = LᵀL
   double diag[NP];
+  double cn[NP];     // column norms sqrt(A_jj) of the current accepted point
   double x[NP];
   double xt[NP];     // trial point
   double p[NP];      // step
-  double w1[NP];
-  double w2[NP];
-  int skip[NP];      // 1 = zero pivot (column treated as absent)
 };
 
 struct LMResult {
@@ -53,65 +61,81 @@ struct LMResult {
 #define IA3_EPSMCH 2.220446049250313e-16
 #define IA3_DWARF 2.2250738585072014e-308
 
-// Cholesky of M = A + par*diag² (upper packed). Non-positive pivots -> column skipped.
-IA3_HD int lm_factor(const double* A, const double* diag, double par, double* L, int* skip) {
-  int nskip = 0;
+struct Chol {        // A + par D² = LᵀL, L upper; transient (registers)
+  double L[NTRI];    // off-diagonals; L[tri(j,j)] holds 1 / L_jj (0 for a skipped column)
+  unsigned skip;     // bit j: non-positive pivot, column treated as absent
+};
+
+IA3_HD void lm_factor(const double* A, const double* diag, double par, Chol& c) {
+  c.skip = 0;
+  IA3_UNROLL
   for (int j = 0; j < NP; ++j) {
+    IA3_UNROLL
     for (int i = 0; i <= j; ++i) {
       double s = A[tri(i, j)];
       if (i == j) s += par * diag[j] * diag[j];
-      for (int k = 0; k < i; ++k) s -= L[tri(k, i)] * L[tri(k, j)];
+      IA3_UNROLL
+      for (int k = 0; k < i; ++k) s -= c.L[tri(k, i)] * c.L[tri(k, j)];
       if (i == j) {
-        if (s > 0.0) { L[tri(j, j)] = sqrt(s); skip[j] = 0; }
-        else { L[tri(j, j)] = 0.0; skip[j] = 1; ++nskip; }
+        if (s > 0.0) c.L[tri(j, j)] = 1.0 / sqrt(s);
+        else { c.L[tri(j, j)] = 0.0; c.skip |= 1u << j; }
       } else {
-        L[tri(i, j)] = skip[i] ? 0.0 : s / L[tri(i, i)];
+        c.L[tri(i, j)] = s * c.L[tri(i, i)];
       }
     }
   }
-  return nskip;
 }
-// y := L⁻ᵀ b  (forward substitution with Lᵀ), skipped components = 0
-IA3_HD void lm_fwd(const double* L, const int* skip, const double* b, double* y) {
+// y := L⁻ᵀ b  (forward substitution with Lᵀ), skipped components = 0; in-place safe
+IA3_HD void lm_fwd(const Chol& c, const double* b, double* y) {
+  IA3_UNROLL
   for (int j = 0; j < NP; ++j) {
     double s = b[j];
-    for (int k = 0; k < j; ++k) s -= L[tri(k, j)] * y[k];
-    y[j] = skip[j] ? 0.0 : s / L[tri(j, j)];
+    IA3_UNROLL
+    for (int k = 0; k < j; ++k) s -= c.L[tri(k, j)] * y[k];
+    y[j] = s * c.L[tri(j, j)];
   }
 }
 // x := L⁻¹ y  (back substitution), skipped components = 0
-IA3_HD void lm_bwd(const double* L, const int* skip, const double* y, double* x) {
+IA3_HD void lm_bwd(const Chol& c, const double* y, double* x) {
+  IA3_UNROLL
   for (int j = NP - 1; j >= 0; --j) {
     double s = y[j];
-    for (int k = j + 1; k < NP; ++k) s -= L[tri(j, k)] * x[k];
-    x[j] = skip[j] ? 0.0 : s / L[tri(j, j)];
+    IA3_UNROLL
+    for (int k = j + 1; k < NP; ++k) s -= c.L[tri(j, k)] * x[k];
+    x[j] = s * c.L[tri(j, j)];
   }
 }
 IA3_HD double lm_norm(const double* v) {
   double s = 0;
+  IA3_UNROLL
   for (int j = 0; j < NP; ++j) s += v[j] * v[j];
   return sqrt(s);
 }
 
 // lmpar on the normal equations: find par with | |D x| - delta | <= 0.1 delta, x = (A+par D²)⁻¹ g
-IA3_HD void lm_par(LMWork& w, double delta, double& par, double* x) {
-  int nskip = lm_factor(w.A, w.diag, 0.0, w.L, w.skip);
-  lm_fwd(w.L, w.skip, w.g, w.w1);
-  lm_bwd(w.L, w.skip, w.w1, x);
+IA3_HD void lm_par(const LMWork& w, double delta, double& par, double* x) {
+  Chol c;
+  double t1[NP], t2[NP];
+  lm_factor(w.A, w.diag, 0.0, c);
+  lm_fwd(c, w.g, t1);
+  lm_bwd(c, t1, x);
   int iter = 0;
-  for (int j = 0; j < NP; ++j) w.w2[j] = w.diag[j] * x[j];
-  double dxnorm = lm_norm(w.w2);
+  IA3_UNROLL
+  for (int j = 0; j < NP; ++j) t2[j] = w.diag[j] * x[j];
+  double dxnorm = lm_norm(t2);
   double fp = dxnorm - delta;
   if (fp <= 0.1 * delta) { par = 0.0; return; }
   double parl = 0.0;
-  if (nskip == 0) {
-    for (int j = 0; j < NP; ++j) w.w1[j] = w.diag[j] * (w.w2[j] / dxnorm);
-    lm_fwd(w.L, w.skip, w.w1, w.w1);
-    double temp = lm_norm(w.w1);
+  if (c.skip == 0) {
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) t1[j] = w.diag[j] * (t2[j] / dxnorm);
+    lm_fwd(c, t1, t1);
+    double temp = lm_norm(t1);
     parl = ((fp / delta) / temp) / temp;
   }
-  for (int j = 0; j < NP; ++j) w.w1[j] = w.g[j] / w.diag[j];
-  double gnorm = lm_norm(w.w1);
+  IA3_UNROLL
+  for (int j = 0; j < NP; ++j) t1[j] = w.g[j] / w.diag[j];
+  double gnorm = lm_norm(t1);
   double paru = gnorm / delta;
   if (paru == 0.0) paru = IA3_DWARF / (delta < 0.1 ? delta : 0.1);
   par = par > parl ? par : parl;
@@ -120,17 +144,19 @@ IA3_HD void lm_par(LMWork& w, double delta, double& par, double* x) {
   for (;;) {
     ++iter;
     if (par == 0.0) { double t = 0.001 * paru; par = IA3_DWARF > t ? IA3_DWARF : t; }
-    lm_factor(w.A, w.diag, par, w.L, w.skip);
-    lm_fwd(w.L, w.skip, w.g, w.w1);
-    lm_bwd(w.L, w.skip, w.w1, x);
-    for (int j = 0; j < NP; ++j) w.w2[j] = w.diag[j] * x[j];
-    dxnorm = lm_norm(w.w2);
+    lm_factor(w.A, w.diag, par, c);
+    lm_fwd(c, w.g, t1);
+    lm_bwd(c, t1, x);
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) t2[j] = w.diag[j] * x[j];
+    dxnorm = lm_norm(t2);
     double temp = fp;
     fp = dxnorm - delta;
     if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-    for (int j = 0; j < NP; ++j) w.w1[j] = w.diag[j] * (w.w2[j] / dxnorm);
-    lm_fwd(w.L, w.skip, w.w1, w.w1);
-    temp = lm_norm(w.w1);
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) t1[j] = w.diag[j] * (t2[j] / dxnorm);
+    lm_fwd(c, t1, t1);
+    temp = lm_norm(t1);
     double parc = ((fp / delta) / temp) / temp;
     if (fp > 0.0) parl = parl > par ? parl : par;
     if (fp < 0.0) paru = paru < par ? paru : par;
@@ -147,52 +173,59 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
   double fnorm = ev.eval(w.x, w.A, w.g);
   double par = 0.0, delta = 0.0, xnorm = 0.0;
   for (;;) {  // outer loop: A, g hold JᵀJ, Jᵀf at x
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(w.A[tri(j, j)]);
     if (r.iter == 1) {
+      double t[NP];
+      IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
-        double cn = sqrt(w.A[tri(j, j)]);
-        w.diag[j] = cn == 0.0 ? 1.0 : cn;
-        w.w1[j] = w.diag[j] * w.x[j];
+        w.diag[j] = w.cn[j] == 0.0 ? 1.0 : w.cn[j];
+        t[j] = w.diag[j] * w.x[j];
       }
-      xnorm = lm_norm(w.w1);
+      xnorm = lm_norm(t);
       delta = factor * xnorm;
       if (delta == 0.0) delta = factor;
     }
     double gnorm = 0.0;
     if (fnorm != 0.0) {
+      IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
-        double cn = sqrt(w.A[tri(j, j)]);
-        if (cn != 0.0) {
-          double v = fabs((w.g[j] / fnorm) / cn);
+        if (w.cn[j] != 0.0) {
+          double v = fabs((w.g[j] / fnorm) / w.cn[j]);
           gnorm = gnorm > v ? gnorm : v;
         }
       }
     }
     if (gnorm <= gtol) { r.info = 4; break; }
-    for (int j = 0; j < NP; ++j) {
-      double cn = sqrt(w.A[tri(j, j)]);
-      w.diag[j] = w.diag[j] > cn ? w.diag[j] : cn;
-    }
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) w.diag[j] = w.diag[j] > w.cn[j] ? w.diag[j] : w.cn[j];
     for (;;) {  // inner loop
-      lm_par(w, delta, par, w.p);
+      double pv[NP], t[NP];
+      lm_par(w, delta, par, pv);
+      IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
-        w.p[j] = -w.p[j];
-        w.xt[j] = w.x[j] + w.p[j];
-        w.w1[j] = w.diag[j] * w.p[j];
+        pv[j] = -pv[j];
+        w.p[j] = pv[j];
+        w.xt[j] = w.x[j] + pv[j];
+        t[j] = w.diag[j] * pv[j];
       }
-      double pnorm = lm_norm(w.w1);
+      double pnorm = lm_norm(t);
       if (r.iter == 1) delta = delta < pnorm ? delta : pnorm;
+      // |J p|² = pᵀ A p   (A of the current accepted point; must precede the trial evaluation only
+      // in the sense that A is still untouched: eval writes A1/g1)
+      double jp2 = 0.0;
+      IA3_UNROLL
+      for (int i = 0; i < NP; ++i) {
+        double s = 0.0;
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) s += (i <= j ? w.A[tri(i, j)] : w.A[tri(j, i)]) * pv[j];
+        jp2 += pv[i] * s;
+      }
+      if (jp2 < 0.0) jp2 = 0.0;
       double fnorm1 = ev.eval(w.xt, w.A1, w.g1);
       ++r.nfev;
       double actred = -1.0;
       if (0.1 * fnorm1 < fnorm) { double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
-      // |J p|² = pᵀ A p
-      double jp2 = 0.0;
-      for (int i = 0; i < NP; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < NP; ++j) s += (i <= j ? w.A[tri(i, j)] : w.A[tri(j, i)]) * w.p[j];
-        jp2 += w.p[i] * s;
-      }
-      if (jp2 < 0.0) jp2 = 0.0;
       double temp1 = sqrt(jp2) / fnorm;
       double temp2 = (sqrt(par) * pnorm) / fnorm;
       double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
@@ -211,9 +244,11 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
         par = 0.5 * par;
       }
       if (ratio >= 1e-4) {  // successful iteration
-        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; w.w1[j] = w.diag[j] * w.x[j]; w.g[j] = w.g1[j]; }
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; t[j] = w.diag[j] * w.xt[j]; w.g[j] = w.g1[j]; }
+        IA3_UNROLL
         for (int k = 0; k < NTRI; ++k) w.A[k] = w.A1[k];
-        xnorm = lm_norm(w.w1);
+        xnorm = lm_norm(t);
         fnorm = fnorm1;
         ++r.iter;
       }

@@ -20,6 +20,7 @@ namespace ia3rt {
 int set_error(int code, const char* fmt, ...);
 int ensure_init();
 hipStream_t stream();
+int num_cus();  // compute units of the selected device
 inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 
 // Cached device scratch: get(bytes) returns a buffer that stays valid until put(); buffers are

@@ -22,9 +22,8 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   ia3_fitter* f = nullptr;
   rc = ia3_fit_create(im, c.data(), n, fp, &f); if (rc) return rc;
   std::vector<float> ps((size_t)n * 11);
-  rc = ia3_fit_first(f);
-  if (!rc) rc = ia3_fit_repeat(f, n_iter);
-  if (!rc) rc = ia3_fit_results(f, ps.data(), nullptr, nullptr);
+  rc = ia3_fit_run(f);
+  if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
   ia3_fit_destroy(f);
   if (rc) return rc;
   int m = 0;

@@ -14,6 +14,7 @@ static thread_local char g_err[1024] = "";
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
 static pid_t g_pid = 0;
+static int g_cus = 256;
 static std::mutex g_mu;
 
 struct WsEntry { void* p; size_t bytes; bool busy; };
@@ -46,6 +47,8 @@ static int do_init(int device) {
   IA3_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = device;
   g_pid = getpid();
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_cus = cus;
   return IA3_OK;
 }
 
@@ -54,6 +57,7 @@ int ensure_init() {
   return do_init(-1);
 }
 hipStream_t stream() { return g_stream; }
+int num_cus() { return g_cus; }
 
 void* ws_get(size_t bytes) {
   if (bytes == 0) bytes = 256;

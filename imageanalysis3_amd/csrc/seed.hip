@@ -21,14 +21,15 @@
 
 namespace {
 
-struct Cand { int z, x, y; float h; };
+struct Cand { int z, x, y; float h; };   // 16 B
 
 constexpr int MAXLEV = 64;
 struct Levels { double th[MAXLEV]; int n; };
 
-struct SeedCtl {            // device-resident counters
+struct SeedCtl {            // device-resident counters (16 B so the candidate array stays 16-B aligned)
   unsigned int n_cand;      // candidates found (may exceed capacity)
   unsigned int overflow;
+  unsigned int pad[2];
 };
 
 template <class T> __device__ __forceinline__ T ldc(const T* p, int z, int x, int y, int X, int Y) {
@@ -204,27 +205,36 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
   }
   double th_low = lev.th[0];
   for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
+  // device buffer = [SeedCtl | Cand x capacity]; the header and the first FIRST candidates come back in ONE
+  // copy (the common case: a few thousand seeds), the rest only if there are more
   unsigned capacity = 1u << 20;
+  constexpr unsigned FIRST = 8192;
   std::vector<Cand> cand;
+  std::vector<char> hbuf(sizeof(SeedCtl) + (size_t)FIRST * sizeof(Cand));
   SeedCtl hctl;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    Scratch ctl(sizeof(SeedCtl)), buf((size_t)capacity * sizeof(Cand));
-    if (!ctl.p || !buf.p) return IA3_ENOMEM;
-    IA3_HIP(hipMemsetAsync(ctl.p, 0, sizeof(SeedCtl), s));
-    ProfScope ps("seed_detect");
-    if (im->dtype == IA3_F32)
-      launch_detect<float>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, buf.as<Cand>(),
-                           capacity, ctl.as<SeedCtl>(), s);
-    else
-      launch_detect<uint16_t>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, buf.as<Cand>(),
-                              capacity, ctl.as<SeedCtl>(), s);
+    Scratch buf(sizeof(SeedCtl) + (size_t)capacity * sizeof(Cand));
+    if (!buf.p) return IA3_ENOMEM;
+    SeedCtl* dctl = (SeedCtl*)buf.p;
+    Cand* dcand = (Cand*)((char*)buf.p + sizeof(SeedCtl));
+    IA3_HIP(hipMemsetAsync(dctl, 0, sizeof(SeedCtl), s));
+    {
+      ProfScope ps("seed_detect");
+      if (im->dtype == IA3_F32)
+        launch_detect<float>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, dcand, capacity, dctl, s);
+      else
+        launch_detect<uint16_t>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, dcand, capacity, dctl, s);
+    }
     IA3_KCHECK();
-    IA3_HIP(hipMemcpyAsync(&hctl, ctl.p, sizeof(SeedCtl), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipMemcpyAsync(hbuf.data(), buf.p, hbuf.size(), hipMemcpyDeviceToHost, s));
     IA3_HIP(hipStreamSynchronize(s));
+    memcpy(&hctl, hbuf.data(), sizeof(SeedCtl));
     if (hctl.n_cand <= capacity) {
       cand.resize(hctl.n_cand);
-      if (hctl.n_cand) {
-        IA3_HIP(hipMemcpyAsync(cand.data(), buf.p, (size_t)hctl.n_cand * sizeof(Cand), hipMemcpyDeviceToHost, s));
+      const unsigned nfirst = hctl.n_cand < FIRST ? hctl.n_cand : FIRST;
+      if (nfirst) memcpy(cand.data(), hbuf.data() + sizeof(SeedCtl), (size_t)nfirst * sizeof(Cand));
+      if (hctl.n_cand > FIRST) {
+        IA3_HIP(hipMemcpyAsync(cand.data() + FIRST, dcand + FIRST, (size_t)(hctl.n_cand - FIRST) * sizeof(Cand), hipMemcpyDeviceToHost, s));
         IA3_HIP(hipStreamSynchronize(s));
       }
       break;

@@ -138,9 +138,12 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
                    ia3_fitter** out);
 int ia3_fit_first(ia3_fitter* f);                 /* .firstfit()  */
 int ia3_fit_repeat(ia3_fitter* f, int* n_iter);   /* .repeatfit() */
+int ia3_fit_run(ia3_fitter* f);                   /* .firstfit(); .repeatfit() in one persistent launch */
 /* ps: n x 11 float32 rows [h,z,x,y,bk,sz,sx,sy,sin_t,sin_p,eps] (NaN rows for failed fits);
  * success: n bytes; nvox: n ints (voxels used by the last fit of each seed); any may be NULL. */
 int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox);
+/* same, plus n_iter of the last repeatfit, with a single stream synchronisation */
+int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, int* n_iter);
 int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev);
 void ia3_fit_destroy(ia3_fitter* f);
 

@@ -413,7 +413,7 @@ class iter_fit_seed_points(object):
             return nn == ic
         c = np.asarray(self.centers, dtype=np.float64)
         d2 = ((c - c[ic]) ** 2).sum(1)
-        near = np.where(d2 < (2.0 * self.radius_fit) ** 2)[0]
+        near = np.where(d2 <= (2.0 * self.radius_fit) ** 2)[0]  # a voxel 5 away from two seeds 10 apart is a tie
         dv = ((pts[:, None, :].astype(np.float64) - c[near][None]) ** 2).sum(-1)
         mine = dv[:, list(near).index(ic)]
         keep = np.ones(len(pts), dtype=bool)
