@@ -46,30 +46,44 @@ __global__ void border_map_k(int* bmap, int count, int R, int len, int mode) {
 }  // w[j] = weight at offset j (0..R), passed by value -> SGPRs
 
 // ---- strided axis: element(line p, position q) = base + q*stride + p ---------------------------
+// A thread walks one segment [blockIdx.z*seg, +seg) of its line in chunks of K outputs with a sliding register
+// window: after a chunk the window shifts by K (2R register moves) and only K new inputs are loaded, so every
+// input is read once per segment instead of (K+2R)/K times.
 template <class T, int R, int K>
 __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T* __restrict__ out,
                                                      int inner, size_t stride, int len,
                                                      size_t outer_stride, Taps taps,
-                                                     const int* __restrict__ bmap) {
+                                                     const int* __restrict__ bmap, int seg) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= inner) return;
   const size_t base = (size_t)blockIdx.y * outer_stride + p;
-  const int q0 = blockIdx.z * K;
-  const int* bm = bmap + q0;  // bm[i] = border-mapped index of position q0 - R + i (wave-uniform)
+  const int q_begin = blockIdx.z * seg;
+  const int q_end = q_begin + seg < len ? q_begin + seg : len;
+  // bmap[i] = border-mapped index of position i - R (wave-uniform -> scalar loads)
   double win[K + 2 * R];
 #pragma unroll
-  for (int i = 0; i < K + 2 * R; ++i) win[i] = ld<T>(in, base + (size_t)bm[i] * stride);
-  double acc[K];
+  for (int i = 0; i < K + 2 * R; ++i) win[i] = ld<T>(in, base + (size_t)bmap[q_begin + i] * stride);
+  for (int q0 = q_begin; q0 < q_end; q0 += K) {
+    // prefetch the K inputs the next chunk adds (positions q0+K+R .. q0+2K+R-1)
+    T nxt[K];   // kept in the stack dtype (half the registers of f64) until they enter the window
 #pragma unroll
-  for (int k = 0; k < K; ++k) acc[k] = win[k + R] * taps.w[0];
+    for (int i = 0; i < K; ++i) nxt[i] = in[base + (size_t)bmap[q0 + K + 2 * R + i] * stride];
+    double acc[K];
 #pragma unroll
-  for (int j = R; j >= 1; --j) {
+    for (int k = 0; k < K; ++k) acc[k] = win[k + R] * taps.w[0];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
+    for (int j = R; j >= 1; --j) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (q0 + k < q_end) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
+#pragma unroll
+    for (int i = 0; i < 2 * R; ++i) win[i] = win[i + K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) win[2 * R + i] = (double)nxt[i];
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    if (q0 + k < len) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
 }
 
 // ---- contiguous axis: one block = one segment of 256*K outputs of one row ----------------------
@@ -149,8 +163,8 @@ __global__ __launch_bounds__(256) void highpass_k(const T* __restrict__ im, cons
 template <class T, int R, int KS, int KC>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
-  // border maps for the three axes (each: len + 2R + K slack entries)
-  const int cz = Z + 2 * R + KS, cx = X + 2 * R + KS, cy = Y + 2 * R + 256 * KC;
+  // border maps for the three axes: positions -R .. len + R + 2K (sliding-window prefetch overshoots by < 2K)
+  const int cz = Z + 2 * R + 3 * KS, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * KC;
   ia3rt::Scratch maps((size_t)(cz + cx + cy) * sizeof(int));
   if (!maps.p) return IA3_ENOMEM;
   int* mz = maps.as<int>();
@@ -161,17 +175,26 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   hipLaunchKernelGGL(border_map_k, dim3((cy + 255) / 256), dim3(256), 0, s, my, cy, R, Y, mode);
   static const std::string nz = "gauss_axis0_R" + std::to_string(R), nx = "gauss_axis1_R" + std::to_string(R),
                            ny = "gauss_axis2_R" + std::to_string(R);
+  // segment length along the filter axis: a multiple of K, long enough to amortise the 2R-deep window fill
+  auto seg_for = [](int len, long long lines) {
+    int seg = ((len + KS - 1) / KS) * KS;                 // whole line
+    const int min_seg = ((8 * R + KS - 1) / KS) * KS;     // halo re-read <= 25 %
+    while (lines * ((len + seg - 1) / seg) < 256LL * 256 * 8 && seg / 2 >= min_seg) seg = ((seg / 2 + KS - 1) / KS) * KS;
+    return seg;
+  };
   // axis 0: src -> dst
   {
     ia3rt::ProfScope ps(nz.c_str());
-    dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + KS - 1) / KS));
-    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz);
+    const int seg = seg_for(Z, (long long)plane);
+    dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
+    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg);
   }
   // axis 1: dst -> tmp
   {
     ia3rt::ProfScope ps(nx.c_str());
-    dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + KS - 1) / KS));
-    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx);
+    const int seg = seg_for(X, (long long)Y * Z);
+    dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
+    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg);
   }
   // axis 2: tmp -> dst
   {
