@@ -37,6 +37,7 @@ using namespace ia3;
 namespace {
 
 constexpr int SLOTS = 8;  // voxel slots per lane
+constexpr int MAXNB = 64; // neighbour slots per seed (seeds within 2r; more than this is reported as an error)
 constexpr int MAXBALL = 64 * SLOTS;
 
 struct SeedState {
@@ -51,8 +52,8 @@ struct SeedState {
 struct FitArgs {
   const void* im; int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
-  const int* nbr_off;       // n+1
-  const int* nbr_idx;       // neighbours with |c_i - c_j|² <= (2r)², ascending
+  const int* nbr_cnt;       // n: number of neighbours of seed i (clamped to MAXNB)
+  const int* nbr_idx;       // n x MAXNB: seeds j != i with |c_i - c_j|² <= (2r)², ascending
   const signed char* ball;  // nball x 4 (dz,dx,dy,0), np.indices order
   int nball, radius;
   SeedState* state;
@@ -217,12 +218,42 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, const flo
   }
 }
 
+// ---- neighbour lists on the device: one wave per seed scans all seeds 64 at a time; hits are appended with
+// ballot + prefix rank, so every list comes out in ascending index order (5 k seeds: 25 M distance tests, ~10 µs;
+// the seed list never goes back to the host for this)
+__global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ seeds, int n, double r2, int* __restrict__ cnt,
+                                                   int* __restrict__ idx, int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;   // whole wave leaves together
+  const double cz = seeds[3 * i], cx = seeds[3 * i + 1], cy = seeds[3 * i + 2];
+  int c = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < n && j != i) {
+      const double a = cz - seeds[3 * j], b = cx - seeds[3 * j + 1], d = cy - seeds[3 * j + 2];
+      hit = a * a + b * b + d * d <= r2;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int pos = c + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < MAXNB) idx[(size_t)i * MAXNB + pos] = j;
+    }
+    c += __popcll(m);
+  }
+  if (lane == 0) {
+    if (c > MAXNB) { atomicMax(overflow, c); c = MAXNB; }
+    cnt[i] = c;
+  }
+}
+
 // ---- stage 0 = firstfit of one seed (Fitting_v4.py:606-637) -----------------------------------------
 __device__ __forceinline__ void do_first(const FitArgs& fa, LMWork& w, int i) {
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
-  const int nb0 = fa.nbr_off[i], nb1 = fa.nbr_off[i + 1];
+  const int nb0 = i * MAXNB, nb1 = nb0 + fa.nbr_cnt[i];
   Ball ball;
   double vals[SLOTS];
   ball.valid = 0;
@@ -284,7 +315,7 @@ __device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
     }
   }
   // subtract the current reconstructions of the overlapping seeds (= im_add + own rec, :658-662)
-  for (int q = fa.nbr_off[i]; q < fa.nbr_off[i + 1]; ++q) {
+  for (int q = i * MAXNB; q < i * MAXNB + fa.nbr_cnt[i]; ++q) {
     const int j = fa.nbr_idx[q];
     const SeedState& sj = fa.state[j];
     if (!LDH(&sj.has_rec)) continue;
@@ -329,7 +360,7 @@ __device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
 
 // ---- dependency-ordered fit kernel ------------------------------------------------------------------------
 // Work list = stages x seeds, stage-major: stage 0 is firstfit, stage k>=1 is sweep k of repeatfit; inside a
-// stage the seeds come in `order` (components by size, members by index).  Every wave claims the next position
+// stage the seeds come in index order.  Every block draws the next position
 // with one atomic and waits until the fits it depends on have published:
 //     (i, k>=1) needs   own stage k-1,   neighbours j < i at stage k   (already refitted in this sweep, the
 //     reference's in-place Gauss–Seidel order),   neighbours j > i at stage k-1.
@@ -373,8 +404,8 @@ __device__ __forceinline__ void publish(int* done, int i, int value) {
 // One block (= one wave) per work-list position.  The position is a TICKET drawn when the block starts running,
 // not blockIdx: tickets are handed out in the order blocks actually start, so everything a block may wait for is
 // held by a block that is already running (or done) whatever order the dispatcher picks.
-__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, const int* __restrict__ order, int n, int stage0,
-                                                   int stage1, StageCtl* ctl, int* done) {
+__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
+                                                   int* done) {
   __shared__ LMWork w;
   const int lane = threadIdx.x & 63;
   const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
@@ -383,7 +414,7 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, const int* __rest
   pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
   if (pos >= total) return;
   const int k = stage0 + (int)(pos / (unsigned)n);
-  const int i = order[pos % (unsigned)n];
+  const int i = (int)(pos % (unsigned)n);   // seed order inside a stage: lower-index neighbours come first
   if (k == 0) {
     do_first(fa, w, i);
     publish(done, i, 1);
@@ -398,7 +429,7 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, const int* __rest
   if (!wait_done(done, i, k, ctl)) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return; }   // converged: skipped (:652)
-  for (int q = fa.nbr_off[i]; q < fa.nbr_off[i + 1]; ++q) {
+  for (int q = i * MAXNB; q < i * MAXNB + fa.nbr_cnt[i]; ++q) {
     const int j = fa.nbr_idx[q];
     if (!wait_done(done, j, j < i ? k + 1 : k, ctl)) return;
   }
@@ -479,12 +510,11 @@ struct ia3_fitter {
   const ia3_stack* im;
   ia3_fit_params prm;
   int n;
-  int n_comp;
   int nball;
   void* pool;          // one device block from the scratch cache holding every array below
   size_t pool_bytes;
-  void *d_seeds, *d_nbr_off, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
-      *d_counters, *d_comp_off, *d_comp_mem, *d_done, *d_ctl;
+  void *d_seeds, *d_nbr_cnt, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
+      *d_counters, *d_done, *d_ctl, *d_nbr_overflow;
   bool first_done;
   StageCtl host_ctl;
   std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
@@ -501,81 +531,10 @@ int build_ball(int r, std::vector<signed char>& ball) {
   return (int)(ball.size() / 4);
 }
 
-// neighbours j != i with |c_i - c_j|² <= r2, ascending; connected components of that graph.
-// Spatial hash on a sorted key array (cell edge = sqrt(r2)), union-find for the components.
-void build_graph(const double* c, int n, double r2, std::vector<int>& off, std::vector<int>& idx,
-                 std::vector<int>& comp_off, std::vector<int>& comp_mem) {
-  const double cell = sqrt(r2) > 0 ? sqrt(r2) : 1.0;
-  struct Key { long long k; int i; };
-  auto pack = [](long long z, long long x, long long y) { return ((z + (1LL << 20)) << 42) | ((x + (1LL << 20)) << 21) | (y + (1LL << 20)); };
-  std::vector<Key> keys(n);
-  std::vector<long long> cz(n), cx(n), cy(n);
-  for (int i = 0; i < n; ++i) {
-    cz[i] = (long long)floor(c[3 * i] / cell); cx[i] = (long long)floor(c[3 * i + 1] / cell); cy[i] = (long long)floor(c[3 * i + 2] / cell);
-    keys[i] = Key{pack(cz[i], cx[i], cy[i]), i};
-  }
-  std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.k < b.k || (a.k == b.k && a.i < b.i); });
-  off.assign(n + 1, 0);
-  idx.clear();
-  std::vector<int> parent(n);
-  std::iota(parent.begin(), parent.end(), 0);
-  auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
-  // sort-merge join: walking the seeds in key order, the first key of every neighbour-cell range is monotone,
-  // so each of the 9 (dz,dx) offsets keeps one moving cursor (3 adjacent y-cells form one contiguous key range)
-  std::vector<std::pair<int, int>> edges;  // (i, j), i != j, both directions
-  size_t cur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s_ = 0; s_ < n; ++s_) {
-    const int i = keys[s_].i;
-    int q = 0;
-    for (long long dz = -1; dz <= 1; ++dz)
-      for (long long dx = -1; dx <= 1; ++dx, ++q) {
-        const long long lo = pack(cz[i] + dz, cx[i] + dx, cy[i] - 1), hi = pack(cz[i] + dz, cx[i] + dx, cy[i] + 1);
-        size_t& p0 = cur[q];
-        while (p0 < (size_t)n && keys[p0].k < lo) ++p0;
-        for (size_t t = p0; t < (size_t)n && keys[t].k <= hi; ++t) {
-          const int j = keys[t].i;
-          if (j == i) continue;
-          double a = c[3 * i] - c[3 * j], b = c[3 * i + 1] - c[3 * j + 1], d = c[3 * i + 2] - c[3 * j + 2];
-          if (a * a + b * b + d * d <= r2) edges.emplace_back(i, j);
-        }
-      }
-  }
-  std::sort(edges.begin(), edges.end());
-  {
-    size_t e = 0;
-    for (int i = 0; i < n; ++i) {
-      for (; e < edges.size() && edges[e].first == i; ++e) {
-        const int j = edges[e].second;
-        idx.push_back(j);
-        int ra = find(i), rb = find(j);
-        if (ra != rb) parent[ra > rb ? ra : rb] = ra > rb ? rb : ra;
-      }
-      off[i + 1] = (int)idx.size();
-    }
-  }
-  // components: members ascending; big components first (they are the serial tail of repeatfit)
-  std::vector<int> cid(n, -1), csize;
-  for (int i = 0; i < n; ++i) {
-    int rt = find(i);
-    if (cid[rt] < 0) { cid[rt] = (int)csize.size(); csize.push_back(0); }
-    csize[cid[rt]]++;
-  }
-  const int nc = (int)csize.size();
-  std::vector<int> order(nc);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return csize[a] > csize[b]; });
-  std::vector<int> rank(nc);
-  comp_off.assign(nc + 1, 0);
-  for (int r = 0; r < nc; ++r) { rank[order[r]] = r; comp_off[r + 1] = comp_off[r] + csize[order[r]]; }
-  comp_mem.assign(n, 0);
-  std::vector<int> fill(comp_off.begin(), comp_off.end() - 1);
-  for (int i = 0; i < n; ++i) comp_mem[fill[rank[cid[find(i)]]]++] = i;
-}
-
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
-  a.seeds = (const double*)f->d_seeds; a.nbr_off = (const int*)f->d_nbr_off; a.nbr_idx = (const int*)f->d_nbr_idx;
+  a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
   a.conv = (unsigned char*)f->d_conv; a.n_iter = (int*)f->d_niter; a.counters = (unsigned long long*)f->d_counters;
@@ -610,32 +569,23 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
     if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
   ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
   f->im = im; f->prm = *p; f->n = n; f->nball = nball;
-  std::vector<int> off, idx, coff, cmem;
-  double rr = 2.0 * p->radius_fit;
-  build_graph(centers_zxy, n, rr * rr, off, idx, coff, cmem);
-  f->n_comp = (int)coff.size() - 1;
-  (void)coff;
-  // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows]
+  // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows | neighbour lists]
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n), b_off = al(sizeof(int) * ((size_t)n + 1)),
-               b_idx = al(sizeof(int) * idx.size()), b_ball = al(ball.size()), b_coff = al(sizeof(int) * coff.size()),
-               b_cmem = al(sizeof(int) * cmem.size());
-  const size_t up_bytes = b_seeds + b_off + b_idx + b_ball + b_coff + b_cmem;
+  const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n), b_ball = al(ball.size());
+  const size_t up_bytes = b_seeds + b_ball;
   const size_t b_state = al(sizeof(SeedState) * (size_t)n), b_nvox = al(sizeof(int) * (size_t)n), b_nfev = b_nvox,
-               b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = 256;
-  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl;
+               b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = 256,
+               b_ovf = 256;
+  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf;
   const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
-  f->pool_bytes = up_bytes + zero_bytes + b_ps;
+  const size_t b_ncnt = al(sizeof(int) * (size_t)n), b_nidx = al(sizeof(int) * MAXNB * (size_t)n);
+  f->pool_bytes = up_bytes + zero_bytes + b_ps + b_ncnt + b_nidx;
   f->pool = ws_get(f->pool_bytes);
   if (!f->pool) { delete f; return IA3_ENOMEM; }
   char* base = (char*)f->pool;
   size_t o = 0;
   f->d_seeds = base + o; o += b_seeds;
-  f->d_nbr_off = base + o; o += b_off;
-  f->d_nbr_idx = base + o; o += b_idx;
   f->d_ball = base + o; o += b_ball;
-  f->d_comp_off = base + o; o += b_coff;
-  f->d_comp_mem = base + o; o += b_cmem;
   char* zero0 = base + o;
   f->d_state = base + o; o += b_state;
   f->d_nvox = base + o; o += b_nvox;
@@ -645,24 +595,28 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
   f->d_counters = base + o; o += b_cnt;
   f->d_done = base + o; o += b_done;
   f->d_ctl = base + o; o += b_ctl;
-  f->d_ps = base + o;
+  f->d_nbr_overflow = base + o; o += b_ovf;
+  f->d_ps = base + o; o += b_ps;
+  f->d_nbr_cnt = base + o; o += b_ncnt;
+  f->d_nbr_idx = base + o;
   // stage the read-only part contiguously and ship it with one copy
   std::vector<char>& host = f->host_stage;
   host.assign(up_bytes, 0);
-  size_t h = 0;
-  if (n) memcpy(host.data() + h, centers_zxy, sizeof(double) * 3 * (size_t)n);
-  h += b_seeds;
-  memcpy(host.data() + h, off.data(), sizeof(int) * off.size()); h += b_off;
-  if (!idx.empty()) memcpy(host.data() + h, idx.data(), sizeof(int) * idx.size());
-  h += b_idx;
-  memcpy(host.data() + h, ball.data(), ball.size()); h += b_ball;
-  memcpy(host.data() + h, coff.data(), sizeof(int) * coff.size()); h += b_coff;
-  if (!cmem.empty()) memcpy(host.data() + h, cmem.data(), sizeof(int) * cmem.size());
+  if (n) memcpy(host.data(), centers_zxy, sizeof(double) * 3 * (size_t)n);
+  memcpy(host.data() + b_seeds, ball.data(), ball.size());
   hipStream_t st = stream();
   hipError_t e = hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(zero0, 0, zero_bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(f->d_ps, 0xFF, b_ps, st);   // all-ones float32 = NaN: failed fits stay NaN rows (:636)
   if (e != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "fitter setup failed: %s", hipGetErrorString(e)); }
+  if (n > 0) {
+    const double rr = 2.0 * p->radius_fit;
+    ProfScope ps("nbr_build");
+    hipLaunchKernelGGL(nbr_build_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)f->d_seeds, n, rr * rr,
+                       (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "nbr_build launch failed: %s", hipGetErrorString(le)); }
+  }
   *out = f;
   return IA3_OK;
 }
@@ -681,8 +635,8 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order)
   if (blocks < 1) blocks = 1;
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
-  hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, (const int*)f->d_comp_mem, f->n, stage0, stage1,
-                     (StageCtl*)f->d_ctl, (int*)f->d_done);
+  hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
+                     (int*)f->d_done);
   IA3_KCHECK();
   return IA3_OK;
 }
@@ -765,9 +719,14 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
     }
   }
   StageCtl hc = StageCtl{0u, 0, 0, 0};
-  if (f->n > 0) IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
+  int ovf = 0;
+  if (f->n > 0) {
+    IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipMemcpyAsync(&ovf, f->d_nbr_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   IA3_HIP(hipStreamSynchronize(st));
   if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+  if (ovf) return set_error(IA3_EUNSUPPORTED, "a seed has %d other seeds within 2*radius_fit (limit %d): field too dense", ovf, MAXNB);
   if (success) for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)stv[i].success;
   return IA3_OK;
 }

@@ -242,7 +242,7 @@ int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int 
       case 3:  return run_fixed<T, 3, 16, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
       case 6:  return run_fixed<T, 6, 16, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
       case 10: return run_fixed<T, 10, 12, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 30: return run_fixed<T, 30, 10, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 30: return run_fixed<T, 30, 8, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
       default: break;
     }
   }
