@@ -14,8 +14,8 @@
 // instructions per tap pair with the taps in SGPRs and no LDS/VMEM traffic.
 //   - axes 0/1 (strided): lanes run along the contiguous y axis, every window load is a coalesced
 //     256 B row segment per wave; the reflect/nearest index mapping is wave-uniform (scalar).
-//   - axis 2 (contiguous): a 256-thread block stages one row segment (+halo) in LDS with coalesced
-//     loads; each thread then reads its window with stride K words (K odd -> conflict-free).
+//   - axis 2 (contiguous): a wave owns 64 rows; 64x32 tiles are transposed through LDS so that every lane
+//     slides the same register window along its own row while global access stays row-coalesced.
 #include "ia3_rt.h"
 
 namespace {
@@ -86,9 +86,10 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
   }
 }
 
-// ---- contiguous axis: one block = one segment of 256*K outputs of one row ----------------------
+// ---- contiguous axis, long filters: one block = one segment of 256*K outputs of one row, window read from an
+// LDS-staged row with stride K (odd) words.  Kept for R >= 16 where the register-window variant below spills.
 template <class T, int R, int K>
-__global__ __launch_bounds__(256) void gauss_contig(const T* __restrict__ in, T* __restrict__ out,
+__global__ __launch_bounds__(256) void gauss_contig_row(const T* __restrict__ in, T* __restrict__ out,
                                                     int len, Taps taps,
                                                     const int* __restrict__ bmap) {
   constexpr int SEG = 256 * K;
@@ -129,6 +130,86 @@ __global__ __launch_bounds__(256) void gauss_contig(const T* __restrict__ in, T*
     if (s0 + i < len) out[row + s0 + i] = tout[i];
 }
 
+// ---- contiguous axis: a wave owns 64 rows and walks a y-segment with the same sliding register window ------
+// Lanes must run along y for coalesced global access but a thread wants its own row, so the data goes through
+// LDS transposes in 64 (rows) x 32 (y) tiles: two rows per wave-load fill tin[row][y] with 128-B row pieces; lane r
+// then reads ITS row (stride 33 words -> conflict-free), slides the window over the 32 new inputs in chunks of K,
+// drops the outputs into tout[row][y], and the tile is written back the same way.  Every input is read once.
+template <class T, int R, int K>
+__global__ __launch_bounds__(64, 2) void gauss_contig(const T* __restrict__ in, T* __restrict__ out, int len,
+                                                   size_t n_rows, Taps taps, const int* __restrict__ bmap, int seg) {
+  constexpr int TW = 32;
+  static_assert(TW % K == 0, "a tile must hold whole chunks");
+  __shared__ float tin[64][TW + 1];
+  __shared__ float tout[64][TW + 1];
+  const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+  const size_t row0 = (size_t)blockIdx.x * 64;
+  const int nr = n_rows - row0 < 64 ? (int)(n_rows - row0) : 64;   // rows of this block
+  const int q_begin = blockIdx.y * seg;
+  const int q_end = q_begin + seg < len ? q_begin + seg : len;
+  // bmap[i] = border-mapped index of position i - R
+  double win[K + 2 * R];
+  // prologue: positions q_begin-R .. q_begin+R-1 (2R values per row), streamed through tin in pieces of TW
+#pragma unroll
+  for (int p0 = 0; p0 < 2 * R; p0 += TW) {
+    const int w = 2 * R - p0 < TW ? 2 * R - p0 : TW;
+    __syncthreads();
+    for (int r = half; r < nr; r += 2)
+      if (col < w) tin[r][col] = (float)ld<T>(in, (row0 + r) * (size_t)len + bmap[q_begin + p0 + col]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < TW; ++c)
+      if (c < w) win[p0 + c] = (double)tin[lane][c];
+  }
+  // tile pipeline: the inputs of tile t+1 travel HBM -> registers while tile t is being filtered out of LDS
+  T pre[32];
+  auto fetch = [&](int o0) {   // inputs at positions o0+R .. o0+R+TW-1  ->  bmap index = position + R
+    const int src = bmap[o0 + 2 * R + col];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int r = half + 2 * i;
+      pre[i] = r < nr ? in[(row0 + r) * (size_t)len + src] : (T)0;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tin[half + 2 * i][col] = (float)pre[i];
+  };
+  __syncthreads();
+  fetch(q_begin);
+  stash();
+  __syncthreads();
+  for (int o0 = q_begin; o0 < q_end; o0 += TW) {
+    const bool more = o0 + TW < q_end;
+    if (more) fetch(o0 + TW);
+#pragma unroll 1
+    for (int c8 = 0; c8 < TW; c8 += K) {   // not unrolled: one chunk's registers at a time
+#pragma unroll
+      for (int i = 0; i < K; ++i) win[2 * R + i] = (double)tin[lane][c8 + i];
+      double acc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = win[k + R] * taps.w[0];
+#pragma unroll
+      for (int j = R; j >= 1; --j) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
+      }
+      // quantise to the stack dtype here (float32 round / uint16 truncate); the value is exact in a float
+#pragma unroll
+      for (int k = 0; k < K; ++k) tout[lane][c8 + k] = (float)cvt<T>(acc[k]);
+#pragma unroll
+      for (int i = 0; i < 2 * R; ++i) win[i] = win[i + K];
+    }
+    __syncthreads();   // every lane is done with tin and has filled its row of tout
+    const int wv = q_end - o0 < TW ? q_end - o0 : TW;
+#pragma unroll 4
+    for (int r = half; r < nr; r += 2)
+      if (col < wv) out[(row0 + r) * (size_t)len + o0 + col] = (T)tout[r][col];
+    if (more) stash();
+    __syncthreads();
+  }
+}
+
 // ---- generic fallback: any radius, one output per thread, taps from global memory --------------
 template <class T>
 __global__ __launch_bounds__(256) void gauss_generic(const T* __restrict__ in, T* __restrict__ out,
@@ -164,7 +245,7 @@ template <class T, int R, int KS, int KC>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
   // border maps for the three axes: positions -R .. len + R + 2K (sliding-window prefetch overshoots by < 2K)
-  const int cz = Z + 2 * R + 3 * KS, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * KC;
+  const int cz = Z + 2 * R + 3 * KS, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * 9;
   ia3rt::Scratch maps((size_t)(cz + cx + cy) * sizeof(int));
   if (!maps.p) return IA3_ENOMEM;
   int* mz = maps.as<int>();
@@ -199,8 +280,18 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   // axis 2: tmp -> dst
   {
     ia3rt::ProfScope ps(ny.c_str());
-    dim3 g((unsigned)((Y + 256 * KC - 1) / (256 * KC)), (unsigned)(Z * X), 1);
-    hipLaunchKernelGGL((gauss_contig<T, R, KC>), g, dim3(256), 0, s, (const T*)tmp, dst, Y, t, (const int*)my);
+    const size_t rows = (size_t)Z * X;
+    constexpr int KY = KC;
+    if constexpr (R >= 16) {   // long filters: LDS-staged row variant (K = 9 outputs per thread)
+      dim3 g((unsigned)((Y + 256 * 9 - 1) / (256 * 9)), (unsigned)rows, 1);
+      hipLaunchKernelGGL((gauss_contig_row<T, R, 9>), g, dim3(256), 0, s, (const T*)tmp, dst, Y, t, (const int*)my);
+      return 0;
+    }
+    int seg = ((Y + 31) / 32) * 32;
+    const int min_seg = ((8 * R + 31) / 32) * 32;
+    while ((long long)((rows + 63) / 64) * ((Y + seg - 1) / seg) < 256LL * 24 && seg / 2 >= min_seg) seg = ((seg / 2 + 31) / 32) * 32;
+    dim3 g((unsigned)((rows + 63) / 64), (unsigned)((Y + seg - 1) / seg), 1);
+    hipLaunchKernelGGL((gauss_contig<T, R, KY>), g, dim3(64), 0, s, (const T*)tmp, dst, Y, rows, t, (const int*)my, seg);
   }
   return 0;
 }
@@ -239,10 +330,10 @@ int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int 
     Taps t;
     for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
     switch (R) {
-      case 3:  return run_fixed<T, 3, 16, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 6:  return run_fixed<T, 6, 16, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 10: return run_fixed<T, 10, 12, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 30: return run_fixed<T, 30, 8, 9>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 3:  return run_fixed<T, 3, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 6:  return run_fixed<T, 6, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 10: return run_fixed<T, 10, 12, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 30: return run_fixed<T, 30, 8, 8>(src, Z, X, Y, t, mode, dst, tmp, s);
       default: break;
     }
   }
