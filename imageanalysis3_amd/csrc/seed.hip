@@ -18,6 +18,9 @@
 #include <algorithm>
 #include <math.h>
 #include <string.h>
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -227,7 +230,7 @@ using namespace ia3rt;
 
 namespace ia3k {
 
-// Host tail of get_seeds: np.where order, level pick, hot columns, sort, truncate.
+// Host tail of get_seeds: level pick, hot columns, sort, truncate (fitting.py:113-150) on a few thousand records.
 static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed_params& p, int Y,
                          SeedOut& o) {
   // dynamic threshold: first level whose (edge-filtered) count reaches min_dynamic_seeds,
@@ -242,28 +245,40 @@ static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed
   std::vector<Cand> s;
   s.reserve(c.size());
   for (auto& k : c) if ((double)k.h >= lev.th[chosen]) s.push_back(k);
-  std::sort(s.begin(), s.end(), [](const Cand& a, const Cand& b) {
-    if (a.z != b.z) return a.z < b.z;
-    if (a.x != b.x) return a.x < b.x;
-    return a.y < b.y;
-  });
   if (p.remove_hot_pixel && !s.empty()) {  // fitting.py:131-138: drop (x,y) seen in >= hot_pixel_th planes
-    std::vector<long long> key(s.size());
-    for (size_t i = 0; i < s.size(); ++i) key[i] = (long long)s[i].x * (Y + 1) + s[i].y;
-    std::vector<long long> sorted(key);
-    std::sort(sorted.begin(), sorted.end());
-    std::vector<Cand> kept;
-    for (size_t i = 0; i < s.size(); ++i) {
-      auto r = std::equal_range(sorted.begin(), sorted.end(), key[i]);
-      if ((r.second - r.first) < p.hot_pixel_th) kept.push_back(s[i]);
+    // open-addressing count table over the (x,y) keys
+    size_t cap = 64;
+    while (cap < 4 * s.size()) cap <<= 1;
+    std::vector<long long> keys(cap, -1);
+    std::vector<int> cnts(cap, 0);
+    auto slot = [&](long long key) {
+      size_t h = (size_t)((unsigned long long)key * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+      while (keys[h] != -1 && keys[h] != key) h = (h + 1) & (cap - 1);
+      return h;
+    };
+    bool any_hot = false;
+    for (auto& k : s) {
+      const long long key = (long long)k.x * (Y + 1) + k.y;
+      size_t h = slot(key);
+      keys[h] = key;
+      if (++cnts[h] >= p.hot_pixel_th) any_hot = true;
     }
-    s.swap(kept);
+    if (any_hot) {
+      std::vector<Cand> kept;
+      kept.reserve(s.size());
+      for (auto& k : s) if (cnts[slot((long long)k.x * (Y + 1) + k.y)] < p.hot_pixel_th) kept.push_back(k);
+      s.swap(kept);
+    }
   }
-  // np.flipud(np.argsort(h)): ascending by h then reversed.  NumPy's quicksort is not stable, so
-  // the order inside groups of equal h is implementation-defined there; here: ties come out in
-  // descending np.where order (stable ascending sort, then flip).
-  std::stable_sort(s.begin(), s.end(), [](const Cand& a, const Cand& b) { return a.h < b.h; });
-  std::reverse(s.begin(), s.end());
+  // np.flipud(np.argsort(h)) on the np.where-ordered list: ascending by h then reversed.  NumPy's quicksort is
+  // not stable, so the order inside groups of equal h is implementation-defined there; here ties come out in
+  // descending np.where (z, x, y) order = what a stable ascending sort followed by the flip gives.
+  std::sort(s.begin(), s.end(), [](const Cand& a, const Cand& b) {
+    if (a.h != b.h) return a.h > b.h;
+    if (a.z != b.z) return a.z > b.z;
+    if (a.x != b.x) return a.x > b.x;
+    return a.y > b.y;
+  });
   if (p.max_num_seeds > 0 && (size_t)p.max_num_seeds <= s.size()) s.resize(p.max_num_seeds);
   o.zxyh.resize(s.size() * 4);
   for (size_t i = 0; i < s.size(); ++i) {
@@ -271,8 +286,12 @@ static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed
   }
 }
 
+static double now_ms() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
 int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
   hipStream_t s = stream();
+  const bool dbg = getenv("IA3_DEBUG_TIMING") != nullptr;
+  const double t0 = now_ms();
   const int Z = im->Z, X = im->X, Y = im->Y;
   const size_t bytes = im->bytes;
   if (p.filt_size < 1 || p.filt_size > 8) return set_error(IA3_EUNSUPPORTED, "filt_size %d not in 1..8", p.filt_size);
@@ -305,6 +324,7 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
     if (rc) return rc;
     minim = b.p;
   }
+  const double t1 = now_ms();
   double th_low = lev.th[0];
   for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
   // device buffer = [SeedCtl | Cand x capacity]; the header and the first FIRST candidates come back in ONE
@@ -344,7 +364,9 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
     if (attempt == 1) return set_error(IA3_ECAPACITY, "more than %u seed candidates", capacity);
     capacity = hctl.n_cand + 1024;  // exact size known now; one retry
   }
+  const double t2 = now_ms();
   finish_seeds(cand, lev, p, Y, out);
+  if (dbg) fprintf(stderr, "dog_seed: launch gauss %.3f ms, detect+copy(sync) %.3f ms, finish %.3f ms (%zu cand)\n", t1 - t0, t2 - t1, now_ms() - t2, cand.size());
   return IA3_OK;
 }
 
