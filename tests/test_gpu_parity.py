@@ -439,3 +439,40 @@ def test_z_shift_correction_bit_exact(name):
     assert np.array_equal(Z_Shift_Correction(im), O.z_shift_correction(im))
     odd = np.ascontiguousarray(im[:, :17, :19])   # odd plane size: single middle element
     assert np.array_equal(Z_Shift_Correction(odd), O.z_shift_correction(odd))
+
+
+# ---------------------------------------------------------------------------------------------
+# full size (BASELINE.json configs[1]): size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_fov_properties():
+    """2048x2048x50 float32, 5000 isolated spots: every injected spot is called once and recovered (centre,
+    height, widths, background), the run is deterministic, and a crop of the field seeded/fitted on its own
+    gives the same rows for the spots whose neighbourhood lies inside the crop (shift consistency)."""
+    from imageanalysis3_amd import synth
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    from scipy.spatial import cKDTree
+    shape = (50, 2048, 2048)
+    im, c, h = synth.make_fov(shape, 5000, 3)
+    t = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    assert t.shape == (5000, 11) and t.dtype == np.float32
+    d, j = cKDTree(c).query(t[:, 1:4])
+    assert d.max() < 0.35 and len(np.unique(j)) == 5000                      # one row per injected spot
+    assert np.median(d) < 0.03
+    assert np.median(np.abs(t[:, 0] / h[j] - 1)) < 0.02                        # heights
+    assert np.abs(np.median(t[:, 4]) - 400) < 1.0                              # background
+    assert np.allclose(np.median(t[:, 5:8], axis=0), [1.35, 1.9, 1.9], atol=0.02)
+    assert (np.diff(fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False), axis=0) ==
+            np.diff(t, axis=0)).all()                                          # deterministic
+    # shift consistency: same spots from a crop (spots >= 40 px from the crop border see identical filters
+    # up to the 30-px reflect halo; their fits depend on a 5-px ball only)
+    x0, y0, n = 512, 768, 512
+    sub = np.ascontiguousarray(im[:, x0:x0 + n, y0:y0 + n])
+    ts = fit_fov_image(sub, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    inner = (ts[:, 2] > 40) & (ts[:, 2] < n - 40) & (ts[:, 3] > 40) & (ts[:, 3] < n - 40)
+    ts = ts[inner]
+    ts[:, 2] += x0
+    ts[:, 3] += y0
+    d, j = cKDTree(t[:, 1:4]).query(ts[:, 1:4])
+    assert len(ts) > 150 and d.max() < 1e-3
+    rel = np.abs(ts[:, :8].astype(np.float64) - t[j, :8]) / np.abs(t[j, :8])
+    assert rel.max() < 1e-4
