@@ -186,12 +186,15 @@ class iter_fit_seed_points():
             self._own_stack = L.DeviceStack.upload(self.im)
             stack = self._own_stack
         self._stack = stack
-        p = L.make_fit_params(self.radius_fit, self.min_delta_center, self.max_delta_center, self.n_max_iter,
-                              self.max_dist_th, self.min_w, self.max_w, self.init_w)
+        p = self._fit_params()
         c = np.ascontiguousarray(self.centers, dtype=np.float64)
         h = C.c_void_p()
         L.check(L.lib().ia3_fit_create(stack._h, L.dptr(c), len(c), C.byref(p), C.byref(h)))
         self._fitter = h
+
+    def _fit_params(self):
+        return L.make_fit_params(self.radius_fit, self.min_delta_center, self.max_delta_center, self.n_max_iter,
+                                 self.max_dist_th, self.min_w, self.max_w, self.init_w)
 
     def _pull(self):
         n = len(self.centers)

@@ -21,7 +21,7 @@ EXPORTS = [
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
     "ia3_remove_hot_pixels", "ia3_z_shift_correction", "ia3_illumination_correct", "ia3_bleedthrough_correct",
-    "ia3_dog_seed", "ia3_dog_seed_dev",
+    "ia3_dog_seed", "ia3_dog_seed_dev", "ia3_seed_in_distance",
     "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_run", "ia3_fit_results", "ia3_fit_results_ex", "ia3_fit_stats",
     "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
@@ -38,10 +38,18 @@ class SeedParams(C.Structure):
                 ("w_back", C.POINTER(C.c_double)), ("r_back", C.c_int)]
 
 
+class LegacySeedParams(C.Structure):
+    _fields_ = [("num_seeds", C.c_int), ("seed_radius", C.c_double), ("gfilt_size", C.c_double),
+                ("background_gfilt_size", C.c_double), ("filt_size", C.c_int), ("th_seed", C.c_double),
+                ("dynamic", C.c_int), ("dynamic_iters", C.c_int), ("min_dynamic_seeds", C.c_int),
+                ("hot_pix_th", C.c_int)]
+
+
 class FitParams(C.Structure):
     _fields_ = [("radius_fit", C.c_int), ("min_delta_center", C.c_double), ("max_delta_center", C.c_double),
                 ("n_max_iter", C.c_int), ("max_dist_th", C.c_double), ("min_w", C.c_double),
-                ("max_w", C.c_double), ("init_w", C.c_double)]
+                ("max_w", C.c_double), ("init_w", C.c_double),
+                ("model_variant", C.c_int), ("init_w_zxy", C.c_double * 3)]
 
 
 _lib = None
@@ -243,8 +251,11 @@ def make_seed_params(th_seed, gfilt_size=0.75, background_gfilt_size=7.5, filt_s
 
 
 def make_fit_params(radius_fit=5, min_delta_center=1., max_delta_center=2.5, n_max_iter=10, max_dist_th=0.1,
-                    min_w=0.5, max_w=4, init_w=1.5):
+                    min_w=0.5, max_w=4, init_w=1.5, model_variant=0, init_w_zxy=(1.35, 1.9, 1.9)):
     p = FitParams()
+    p.model_variant = int(model_variant)
+    for k in range(3):
+        p.init_w_zxy[k] = float(init_w_zxy[k])
     p.radius_fit = int(radius_fit)
     p.min_delta_center = float(min_delta_center)
     p.max_delta_center = float(max_delta_center)

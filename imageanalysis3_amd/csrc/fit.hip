@@ -66,6 +66,8 @@ struct FitArgs {
   double min_ws, max_ws, init_w, delta_first, delta_repeat, dist_th2;
   int n_max_iter;
   double ftol, xtol, gtol; int maxfev; double factor;
+  int variant = 0;            // FitCfg::variant (0 = Fitting_v4, 1 = legacy Fitting_v3)
+  double iw[3] = {0, 0, 0};   // variant 1: start widths in w_ space
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -118,12 +120,16 @@ struct WaveEval {
     for (int k = 0; k < NTRI; ++k) a[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) gg[k] = 0.0;
+    int nbad = 0;   // non-finite residuals, NaN counted twice (see below)
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
+      bool r_inf = false, r_nan = false;
       if (b->valid & (1u << s)) {
         double J[NP];
         double F = model_jac(gm, (double)b->cz[s], (double)b->cx[s], (double)b->cy[s], J);
         double r = (gm.ebk_f + F) - (double)b->dat[s];
+        r_nan = r != r;
+        r_inf = !r_nan && (r - r != 0.0);
         ss += r * r;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -132,12 +138,18 @@ struct WaveEval {
           for (int j = i; j < NP; ++j) a[tri(i, j)] += J[i] * J[j];
         }
       }
+      nbad += __popcll(__ballot(r_inf)) + 2 * __popcll(__ballot(r_nan));
     }
 #pragma unroll
     for (int k = 0; k < NTRI; ++k) A[k] = wave_sum(a[k]);
 #pragma unroll
     for (int k = 0; k < NP; ++k) g[k] = wave_sum(gg[k]);
-    return sqrt(wave_sum(ss));
+    // MINPACK's enorm (scaled sums) returns NaN, not inf, as soon as two components are infinite (inf/inf) or one
+    // is NaN; lmder's tests `0.1*fnorm1 < fnorm` and `0.1*fnorm1 >= fnorm` are then both false, which changes
+    // the trust-region update.  Reached by the legacy model (no clip on the background exponent) when a trial
+    // step sends bk past 709.
+    const double fn = sqrt(wave_sum(ss));
+    return nbad >= 2 ? NAN : fn;
   }
 };
 
@@ -181,6 +193,7 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const
   ev.b = &ball;
   ev.cfg.min_ws = fa.min_ws; ev.cfg.max_ws = fa.max_ws; ev.cfg.delta = delta; ev.cfg.init_w = fa.init_w;
   ev.cfg.c0[0] = c0[0]; ev.cfg.c0[1] = c0[1]; ev.cfg.c0[2] = c0[2];
+  ev.cfg.variant = fa.variant; ev.cfg.iw[0] = fa.iw[0]; ev.cfg.iw[1] = fa.iw[1]; ev.cfg.iw[2] = fa.iw[2];
   double lo10[10], hi10[10];
   wave_extremes(vals, ball.valid, lo10, hi10);
   init_guess(lo10, hi10, kind, ev.cfg, w.x);
@@ -321,6 +334,7 @@ __device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
     if (!LDH(&sj.has_rec)) continue;
     FitCfg cj;
     cj.min_ws = fa.min_ws; cj.max_ws = fa.max_ws; cj.delta = LDH(&sj.delta); cj.init_w = fa.init_w;
+    cj.variant = fa.variant;
     cj.c0[0] = fa.seeds[3 * j]; cj.c0[1] = fa.seeds[3 * j + 1]; cj.c0[2] = fa.seeds[3 * j + 2];
     const int jz = (int)cj.c0[0], jx = (int)cj.c0[1], jy = (int)cj.c0[2];
     double xj[NP];
@@ -544,6 +558,16 @@ FitArgs make_args(const ia3_fitter* f) {
   a.n_max_iter = f->prm.n_max_iter;
   // scipy.optimize.leastsq defaults used at Fitting_v4.py:388
   a.ftol = 1.49012e-8; a.xtol = 1.49012e-8; a.gtol = 0.0; a.maxfev = 1000; a.factor = 100.0;
+  if (f->prm.model_variant == 1) {
+    // Fitting_v3.py:253 calls leastsq without maxfev: MINPACK's default with Dfun is 100*(n+1)
+    a.maxfev = 100 * (NP + 1);
+    a.variant = 1;
+    for (int k = 0; k < 3; ++k) {   // Fitting_v3.py:71-79 (the range test uses the un-squared bounds, as there)
+      double w = f->prm.init_w_zxy[k];
+      if (w * w > f->prm.max_w || w * w < f->prm.min_w) w = 1.5 * 1.5;
+      a.iw[k] = log((a.max_ws - w * w) / (w * w - a.min_ws));
+    }
+  }
   return a;
 }
 

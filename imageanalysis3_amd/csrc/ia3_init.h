@@ -38,6 +38,7 @@ IA3_HD void init_guess(const double* lo10, const double* hi10, int kind, const F
   x[0] = (double)(float)bk; x[1] = (double)(float)h;
   x[2] = 0; x[3] = 0; x[4] = 0;
   x[5] = x[6] = x[7] = (double)(float)wg;
+  if (cfg.variant == 1) { x[5] = (double)(float)cfg.iw[0]; x[6] = (double)(float)cfg.iw[1]; x[7] = (double)(float)cfg.iw[2]; }
   x[8] = 0; x[9] = 0;
 }
 

@@ -29,6 +29,11 @@ struct FitCfg {
   double delta;    // delta_center
   double init_w;
   double c0[3];    // centre estimate (the seed)
+  // model variant: 0 = External/Fitting_v4.py (production); 1 = External/Fitting_v3.py (legacy
+  // `_fit_single_image` path, classes/__init__.py:57-88): per-axis start widths (Fitting_v3.py:71-79) and its
+  // to_center (:81-87), whose third coordinate mixes the second and third offsets.
+  int variant = 0;
+  double iw[3] = {0, 0, 0};   // variant 1: start value of the three width parameters (already in w_ space)
 };
 
 // log(DBL_MAX): the reference's overflow guard (np.log(np.finfo(float64).max)); parameters
@@ -39,6 +44,21 @@ IA3_HD double sig_center(double c_, double delta, double c0) {
   if (c_ >= IA3_LOGMAX) return -delta + c0;
   if (c_ <= -IA3_LOGMAX) return delta + c0;
   return 2. * delta / (1. + exp(c_)) - delta + c0;
+}
+// Fitting_v3.py:84-86: 2*delta*exp(-a)/(1+exp(-b)) - delta + c0 (a == b for the first two axes)
+IA3_HD double sig_center_v3(double a, double b, double delta, double c0) {
+  return 2. * delta * exp(-a) / (1. + exp(-b)) - delta + c0;
+}
+IA3_HD void centers_of(const double* x, const FitCfg& cfg, double* c) {
+  if (cfg.variant == 1) {
+    c[0] = sig_center_v3(x[2], x[2], cfg.delta, cfg.c0[0]);
+    c[1] = sig_center_v3(x[3], x[3], cfg.delta, cfg.c0[1]);
+    c[2] = sig_center_v3(x[3], x[4], cfg.delta, cfg.c0[2]);
+  } else {
+    c[0] = sig_center(x[2], cfg.delta, cfg.c0[0]);
+    c[1] = sig_center(x[3], cfg.delta, cfg.c0[1]);
+    c[2] = sig_center(x[4], cfg.delta, cfg.c0[2]);
+  }
 }
 IA3_HD double sig_sine(double t_) {
   if (t_ >= IA3_LOGMAX) return -1.;
@@ -80,9 +100,7 @@ IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
   const double ws1 = sig_ws(w1, cfg.min_ws, cfg.max_ws);
   const double ws2 = sig_ws(w2, cfg.min_ws, cfg.max_ws);
   const double ws3 = sig_ws(w3, cfg.min_ws, cfg.max_ws);
-  g.c[0] = sig_center(xp, cfg.delta, cfg.c0[0]);
-  g.c[1] = sig_center(yp, cfg.delta, cfg.c0[1]);
-  g.c[2] = sig_center(zp, cfg.delta, cfg.c0[2]);
+  centers_of(x, cfg, g.c);
   const double p2 = p * p, t2 = t * t, tc2 = 1 - t2, pc2 = 1 - p2;
   const double tc = sqrt(tc2), pc = sqrt(pc2);
   const double s1 = 1. / ws1, s2 = 1. / ws2, s3 = 1. / ws3;
@@ -95,7 +113,7 @@ IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
   g.q[0] = x2c; g.q[1] = y2c; g.q[2] = z2c; g.q[3] = xyc; g.q[4] = xzc; g.q[5] = yzc;
   g.h = h;
   double bkc = bk < -709.78 ? -709.78 : (bk > 709.78 ? 709.78 : bk);
-  g.ebk_f = exp(bkc);
+  g.ebk_f = cfg.variant == 1 ? exp(bk) : exp(bkc);   // Fitting_v3.py:119 has no clip
   g.ebk_j = exp(bk);
   const double d = cfg.delta;
   const double e_xp = exp(-fabs(xp)), e_yp = exp(-fabs(yp)), e_zp = exp(-fabs(zp));
@@ -158,9 +176,9 @@ IA3_HD double model_jac(const Geom& g, double vz, double vx, double vy, double* 
 // natural parameters [h, c0, c1, c2, bk, w0, w1, w2, sin_t, sin_p] (eps appended by the caller)
 IA3_HD void to_natural(const double* x, const FitCfg& cfg, float* p) {
   p[0] = (float)exp(x[1]);
-  p[1] = (float)sig_center(x[2], cfg.delta, cfg.c0[0]);
-  p[2] = (float)sig_center(x[3], cfg.delta, cfg.c0[1]);
-  p[3] = (float)sig_center(x[4], cfg.delta, cfg.c0[2]);
+  double c[3];
+  centers_of(x, cfg, c);
+  p[1] = (float)c[0]; p[2] = (float)c[1]; p[3] = (float)c[2];
   p[4] = (float)exp(x[0]);
   p[5] = (float)sqrt(sig_ws(x[5], cfg.min_ws, cfg.max_ws));
   p[6] = (float)sqrt(sig_ws(x[6], cfg.min_ws, cfg.max_ws));

@@ -43,7 +43,7 @@ static int do_init(int device) {
   }
   if (device >= n) return set_error(IA3_EINVAL, "device %d out of range (%d devices)", device, n);
   IA3_HIP(hipSetDevice(device));
-  if (g_stream && g_pid == getpid()) { hipStreamDestroy(g_stream); g_stream = nullptr; }
+  if (g_stream && g_pid == getpid()) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   IA3_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = device;
   g_pid = getpid();
@@ -70,7 +70,7 @@ void* ws_get(size_t bytes) {
   if (best >= 0 && g_ws[best].bytes <= 2 * bytes + (1 << 20)) { g_ws[best].busy = true; return g_ws[best].p; }
   void* p = nullptr;
   if (hipMalloc(&p, bytes) != hipSuccess) {
-    for (auto& e : g_ws) if (!e.busy && e.p) { hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+    for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
     if (hipMalloc(&p, bytes) != hipSuccess) { set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
   }
   for (auto& e : g_ws) if (!e.p) { e = {p, bytes, true}; return p; }
@@ -83,7 +83,7 @@ void ws_put(void* p) {
 }
 void ws_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& e : g_ws) if (!e.busy && e.p) { hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+  for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
 }
 
 // ---- profiling ----------------------------------------------------------------------------------
@@ -239,7 +239,7 @@ int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void*
 }
 void ia3_stack_free(ia3_stack* s) {
   if (!s) return;
-  if (s->owned && s->d) hipFree(s->d);
+  if (s->owned && s->d) (void)hipFree(s->d);
   delete s;
 }
 

@@ -62,7 +62,7 @@ template <class T, int ZC, int W>
 __global__ __launch_bounds__(256) void seed_detect(const T* __restrict__ mx, const T* __restrict__ mn,
                                                    int Z, int X, int Y, int edge, double th_low,
                                                    Cand* __restrict__ out, unsigned capacity,
-                                                   SeedCtl* __restrict__ ctl) {
+                                                   SeedCtl* __restrict__ ctl, int rule) {
   constexpr int LO = -(W / 2), HI = W - W / 2 - 1;
   const int y = blockIdx.x * 64 + (threadIdx.x & 63);
   const int x = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -86,8 +86,18 @@ __global__ __launch_bounds__(256) void seed_detect(const T* __restrict__ mx, con
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) { pmax[k] = pmax[k + 1]; pmin[k] = pmin[k + 1]; }
     const T cmax = ldc(mx, z, xs, ys, X, Y), cmin = ldc(mn, z, xs, ys, X, Y);
-    const float diff = (float)cmax - (float)cmin;
+    float diff = (float)cmax - (float)cmin;
     bool hit = inside && (vmax == cmax) && (vmin != cmin) && ((double)diff >= th_low);
+    if (rule == 1) {
+      // legacy visual_tools.py:362-369 get_seed_points_base: the rank-filter outputs are cast to int64
+      // (truncation) before the equality tests, the background minimum must be non-zero, and the height
+      // is the integer difference, compared with a strict '>'
+      const long long imax = (long long)vmax, imin = (long long)vmin;
+      const long long hh = imax - imin;
+      hit = inside && ((double)imax == (double)cmax) && ((double)imin != (double)cmin) && (imin != 0) &&
+            ((double)hh > th_low);
+      diff = (float)hh;
+    }
     if (edge > 0)
       hit = hit && z >= edge && z <= Z - edge && x >= edge && x <= X - edge && y >= edge && y <= Y - edge;
     const unsigned long long ballot = __ballot(hit);
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
 
 template <class T>
 void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, int edge, double th_low,
-                   Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s) {
-  if (W == 3) {
+                   Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s, int rule = 0) {
+  if (W == 3 && rule == 0) {
     constexpr int ZT = 64;   // planes per block; the two halo planes of a chunk are re-read
     dim3 gt((unsigned)((Y + 63) / 64), (unsigned)((X + 15) / 16), (unsigned)((Z + ZT - 1) / ZT));
     hipLaunchKernelGGL((seed_detect3_tiled<T, ZT>), gt, dim3(256), 0, s, (const T*)mx, (const T*)mn, Z, X, Y, edge, th_low,
@@ -215,7 +225,7 @@ void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, i
 #define IA3_SEED_CASE(WW)                                                                              \
   case WW:                                                                                             \
     hipLaunchKernelGGL((seed_detect<T, ZC, WW>), g, dim3(256), 0, s, (const T*)mx, (const T*)mn, Z, X, Y, \
-                       edge, th_low, out, capacity, ctl);                                              \
+                       edge, th_low, out, capacity, ctl, rule);                                        \
     break;
   switch (W) {
     IA3_SEED_CASE(1) IA3_SEED_CASE(2) IA3_SEED_CASE(3) IA3_SEED_CASE(4)
@@ -370,9 +380,187 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
   return IA3_OK;
 }
 
+// ---- legacy seeding (visual_tools.py:348-381 get_seed_points_base, :1775-1870 get_seed_in_distance) ----------
+// Filters + rule-1 detection on a resident stack; candidates come back in np.where order (z, x, y ascending).
+static int legacy_candidates(const ia3_stack* im, double gfilt, double bgfilt, int filt_size, double th_low,
+                             std::vector<Cand>& cand) {
+  hipStream_t s = stream();
+  const int Z = im->Z, X = im->X, Y = im->Y;
+  const size_t bytes = im->bytes;
+  if (filt_size < 1 || filt_size > 8) return set_error(IA3_EUNSUPPORTED, "filt_size %d not in 1..8", filt_size);
+  Scratch a(bytes), b(bytes), tmp(bytes);
+  if (!a.p || !b.p || !tmp.p) return IA3_ENOMEM;
+  const void* maxim = im->d;
+  const void* minim = im->d;
+  std::vector<double> w; int R, rc;
+  if (gfilt > 0) {     // `if gfilt_size:` — scipy defaults: mode='reflect', truncate=4
+    gaussian_taps(gfilt, 4.0, w, R);
+    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp.p);
+    if (rc) return rc;
+    maxim = a.p;
+  }
+  if (bgfilt > 0) {
+    gaussian_taps(bgfilt, 4.0, w, R);
+    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, b.p, tmp.p);
+    if (rc) return rc;
+    minim = b.p;
+  }
+  unsigned capacity = 1u << 16;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    Scratch buf(sizeof(SeedCtl) + (size_t)capacity * sizeof(Cand));
+    if (!buf.p) return IA3_ENOMEM;
+    SeedCtl* dctl = (SeedCtl*)buf.p;
+    Cand* dcand = (Cand*)((char*)buf.p + sizeof(SeedCtl));
+    IA3_HIP(hipMemsetAsync(dctl, 0, sizeof(SeedCtl), s));
+    if (im->dtype == IA3_F32)
+      launch_detect<float>(filt_size, maxim, minim, Z, X, Y, 0, th_low, dcand, capacity, dctl, s, 1);
+    else
+      launch_detect<uint16_t>(filt_size, maxim, minim, Z, X, Y, 0, th_low, dcand, capacity, dctl, s, 1);
+    IA3_KCHECK();
+    SeedCtl hctl;
+    IA3_HIP(hipMemcpyAsync(&hctl, dctl, sizeof(SeedCtl), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipStreamSynchronize(s));
+    if (hctl.n_cand <= capacity) {
+      cand.resize(hctl.n_cand);
+      if (hctl.n_cand) {
+        IA3_HIP(hipMemcpyAsync(cand.data(), dcand, (size_t)hctl.n_cand * sizeof(Cand), hipMemcpyDeviceToHost, s));
+        IA3_HIP(hipStreamSynchronize(s));
+      }
+      break;
+    }
+    if (attempt == 1) return set_error(IA3_ECAPACITY, "more than %u seed candidates", capacity);
+    capacity = hctl.n_cand + 1024;
+  }
+  std::sort(cand.begin(), cand.end(), [](const Cand& p, const Cand& q) {
+    if (p.z != q.z) return p.z < q.z;
+    if (p.x != q.x) return p.x < q.x;
+    return p.y < q.y;
+  });
+  return IA3_OK;
+}
+
+// get_seed_points_base's tail for one threshold: keep h > th, drop (x, y) columns seen more than hot_pix_th times
+static void legacy_base(const std::vector<Cand>& cand, double th, int hot_pix_th, std::vector<Cand>& out) {
+  out.clear();
+  for (auto& k : cand) if ((double)k.h > th) out.push_back(k);
+  if (hot_pix_th > 0 && !out.empty()) {
+    std::vector<std::pair<long long, int>> keys;
+    keys.reserve(out.size());
+    for (auto& k : out) keys.push_back({((long long)k.x << 32) | (unsigned)k.y, 0});
+    std::vector<long long> sorted;
+    sorted.reserve(keys.size());
+    for (auto& k : keys) sorted.push_back(k.first);
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<Cand> kept;
+    for (size_t i = 0; i < out.size(); ++i) {
+      auto r = std::equal_range(sorted.begin(), sorted.end(), keys[i].first);
+      if ((r.second - r.first) <= hot_pix_th) kept.push_back(out[i]);
+    }
+    out.swap(kept);
+  }
+}
+
+int seed_in_distance(const void* im, int dtype, int Z, int X, int Y, const double* center,
+                     const ia3_legacy_seed_params& p, std::vector<long long>& zxyh) {
+  const size_t es = dtype == IA3_F32 ? 4 : 2;
+  int lo[3] = {0, 0, 0}, hi[3] = {Z, X, Y};
+  double lc[3] = {0, 0, 0};
+  if (center) {   // visual_tools.py:1817-1830: half radius along z, truncation to int
+    const int dim[3] = {Z, X, Y};
+    for (int a = 0; a < 3; ++a) {
+      const double r = a == 0 ? p.seed_radius / 2 : p.seed_radius;
+      double l = center[a] - r; if (l < 0) l = 0;
+      double h = center[a] + r; if (h > dim[a]) h = dim[a];
+      lo[a] = (int)l; hi[a] = (int)h;
+      lc[a] = center[a] - lo[a];
+    }
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) { zxyh.clear(); return IA3_OK; }
+  }
+  const int cz = hi[0] - lo[0], cx = hi[1] - lo[1], cy = hi[2] - lo[2];
+  std::vector<char> crop((size_t)cz * cx * cy * es);
+  for (int z = 0; z < cz; ++z)
+    for (int x = 0; x < cx; ++x)
+      memcpy(crop.data() + ((size_t)z * cx + x) * cy * es,
+             (const char*)im + ((((size_t)(z + lo[0])) * X + (x + lo[1])) * Y + lo[2]) * es, (size_t)cy * es);
+  ia3_stack* st = nullptr;
+  int rc = ia3_stack_upload(crop.data(), dtype, cz, cx, cy, &st);
+  if (rc) return rc;
+  std::vector<Cand> cand, sel, seeds;
+  const bool dyn = center && p.dynamic;
+  // the non-dynamic calls (:1851-1858) do not forward background_gfilt_size: the base default (10) applies
+  const double bg = dyn ? p.background_gfilt_size : 10.0;
+  std::vector<double> levels;
+  if (dyn) {   // np.linspace(1, 1/iters, iters) * th_seed
+    const int n = p.dynamic_iters;
+    if (n < 1) { ia3_stack_free(st); return set_error(IA3_EINVAL, "dynamic_iters must be >= 1"); }
+    const double start = 1.0, stop = 1.0 / n;
+    const double div = n > 1 ? n - 1 : 1, delta = stop - start, step = delta / div;
+    for (int i = 0; i < n; ++i) {
+      double y = step != 0 ? i * step : (i / div) * delta;
+      levels.push_back(y + start);
+    }
+    if (n > 1) levels[n - 1] = stop;
+    for (auto& l : levels) l = p.th_seed * l;
+  } else {
+    levels.push_back(p.th_seed);
+  }
+  double th_low = levels[0];
+  for (double l : levels) th_low = l < th_low ? l : th_low;
+  rc = legacy_candidates(st, p.gfilt_size, bg, p.filt_size, th_low, cand);
+  ia3_stack_free(st);
+  if (rc) return rc;
+  if (dyn) {
+    for (double th : levels) {
+      legacy_base(cand, th, p.hot_pix_th, sel);
+      seeds.clear();
+      for (auto& k : sel) {
+        const double dz = k.z - lc[0], dx = k.x - lc[1], dy = k.y - lc[2];
+        if (sqrt(dz * dz + dx * dx + dy * dy) < p.seed_radius) {
+          Cand c = k; c.z += lo[0]; c.x += lo[1]; c.y += lo[2];
+          seeds.push_back(c);
+        }
+      }
+      const int n = (int)seeds.size();
+      if (p.num_seeds > 0 && n >= (p.num_seeds < p.min_dynamic_seeds ? p.num_seeds : p.min_dynamic_seeds)) break;
+      if (p.num_seeds == 0 && n >= p.min_dynamic_seeds) break;
+    }
+  } else {
+    // :1851-1858: crop coordinates are returned as they are (no offset, no distance test) in these branches
+    legacy_base(cand, p.th_seed, p.hot_pix_th, seeds);
+  }
+  if (seeds.size() > 1) {
+    // np.argsort(h) ascending, last num_seeds, flipped.  Equal heights: stable order assumed (NumPy's default
+    // sort leaves it implementation-defined)
+    std::stable_sort(seeds.begin(), seeds.end(), [](const Cand& a, const Cand& b) { return a.h < b.h; });
+    if (p.num_seeds > 0 && (size_t)p.num_seeds < seeds.size()) seeds.erase(seeds.begin(), seeds.end() - p.num_seeds);
+    std::reverse(seeds.begin(), seeds.end());
+  }
+  zxyh.resize(seeds.size() * 4);
+  for (size_t i = 0; i < seeds.size(); ++i) {
+    zxyh[4 * i] = seeds[i].z; zxyh[4 * i + 1] = seeds[i].x; zxyh[4 * i + 2] = seeds[i].y; zxyh[4 * i + 3] = (long long)seeds[i].h;
+  }
+  return IA3_OK;
+}
+
 }  // namespace ia3k
 
 extern "C" {
+
+int ia3_seed_in_distance(const void* im, int dtype, int Z, int X, int Y, const double* center,
+                         const ia3_legacy_seed_params* p, int64_t* out_zxyh, int capacity, int* n_out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !p || !n_out) return set_error(IA3_EINVAL, "null argument");
+  if (dtype != IA3_F32 && dtype != IA3_U16) return set_error(IA3_EINVAL, "dtype must be IA3_U16 or IA3_F32");
+  std::vector<long long> o;
+  rc = ia3k::seed_in_distance(im, dtype, Z, X, Y, center, *p, o); if (rc) return rc;
+  const int n = (int)(o.size() / 4);
+  *n_out = n;
+  if (n > capacity) return set_error(IA3_ECAPACITY, "seed buffer too small: need %d rows", n);
+  if (n && !out_zxyh) return set_error(IA3_EINVAL, "null output");
+  for (size_t i = 0; i < o.size(); ++i) out_zxyh[i] = (int64_t)o[i];
+  return IA3_OK;
+}
+
 
 int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p, double* out_zxyh, int capacity,
                      int* n_out, double* th_used) {

@@ -120,6 +120,27 @@ int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_
 int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p,
                      double* out_zxyh, int capacity, int* n_out, double* th_used);
 
+/* ---- legacy per-cell seeding: visual_tools.py:1775-1870 get_seed_in_distance (+ :348-381 get_seed_points_base),
+ * the seeder of classes/__init__.py:57-88 `_fit_single_image`.  Crop of +-seed_radius (x, y) / +-seed_radius/2 (z)
+ * around `center` (NULL: whole image), scipy-default Gaussian filters (reflect, truncate 4), int64-truncated
+ * rank-filter tests, strict '>' threshold lowered over np.linspace(1, 1/dynamic_iters, dynamic_iters) until enough
+ * seeds lie within seed_radius, brightest num_seeds first.  th_seed is the resolved threshold (the shim evaluates
+ * seed_by_per).  out_zxyh: capacity x 4 int64 [z, x, y, h]. */
+typedef struct ia3_legacy_seed_params {
+  int num_seeds;                 /* 0 = keep all */
+  double seed_radius;            /* 30 */
+  double gfilt_size;             /* 0.75 */
+  double background_gfilt_size;  /* 10 */
+  int filt_size;                 /* 3 */
+  double th_seed;                /* 300 */
+  int dynamic;                   /* 1 */
+  int dynamic_iters;             /* 10 */
+  int min_dynamic_seeds;         /* 2 */
+  int hot_pix_th;                /* 4 */
+} ia3_legacy_seed_params;
+int ia3_seed_in_distance(const void* im, int dtype, int Z, int X, int Y, const double* center,
+                         const ia3_legacy_seed_params* p, int64_t* out_zxyh, int capacity, int* n_out);
+
 /* ---- fitting: External/Fitting_v4.py:559-683 iter_fit_seed_points (+ GaussianFit :165-396) ---- */
 typedef struct ia3_fit_params {
   int radius_fit;            /* 5 */
@@ -128,6 +149,11 @@ typedef struct ia3_fit_params {
   int n_max_iter;            /* 10 */
   double max_dist_th;        /* 0.1 */
   double min_w, max_w, init_w; /* 0.5, 4, 1.5 */
+  /* 0: External/Fitting_v4.py (production).  1: External/Fitting_v3.py:50-262,312-425, the fitter behind the
+   * legacy classes/__init__.py:57-88 `_fit_single_image`: per-axis start widths init_w_zxy (the reference's
+   * global _sigma_zxy = 1.35, 1.9, 1.9), its to_center (:81-87) and MINPACK's default maxfev. */
+  int model_variant;
+  double init_w_zxy[3];
 } ia3_fit_params;
 
 typedef struct ia3_fitter ia3_fitter;

@@ -65,6 +65,54 @@ CASES = {
 }
 
 
+LEGACY = dict(shape=[30, 160, 160], n=14, seed=11, layout="clustered", dtype="uint16", margin=[5, 12, 12],
+              n_territories=2)
+# (_seeding_args, label) tuples: positional arguments after (im, center) of get_seed_in_distance
+LEGACY_SEEDING = {
+    "default": (0, 30, 0.75, 10, 3, False, 95, 300, True, 10, 2, 1, 4, True),
+    "top3": (3, 30, 0.75, 10, 3, False, 95, 300, True, 10, 2, 1, 4, True),
+    "static": (0, 30, 0.75, 10, 3, False, 95, 300, False, 10, 2, 1, 4, True),
+    "r12_th2000": (0, 12, 0.75, 10, 3, False, 95, 2000, True, 10, 2, 1, 4, True),
+    "many_dynamic": (0, 30, 0.75, 10, 3, False, 95, 6000, True, 10, 8, 1, 4, True),
+}
+LEGACY_FIT_ARGS = (5, 1., 2.5, 10, 0.1)
+
+
+def legacy_golden(meta):
+    """(a12) classes/__init__.py:57-88: the reference's visual_tools.get_seed_in_distance and
+    Fitting_v3.iter_fit_seed_points run in the order _fit_single_image calls them."""
+    F3, vt = ref_loader.load_legacy()
+    spec = dict(LEGACY)
+    im, c, h = synth.make_fov(tuple(spec["shape"]), spec["n"], spec["seed"], layout=spec["layout"],
+                              dtype=np.dtype(spec["dtype"]), margin=tuple(spec["margin"]),
+                              n_territories=spec["n_territories"])
+    coords = np.array([c[:7].mean(0), c[7:].mean(0), [3., 150., 20.], [15., 20., 60.]])
+    d = {"coords": coords, "crc": crc(im)}
+    for name, sa in LEGACY_SEEDING.items():
+        for i, cc in enumerate(coords):
+            d["seeds_%s_%d" % (name, i)] = quiet(vt.get_seed_in_distance, im, cc, *sa)
+    d["seeds_whole_per"] = quiet(vt.get_seed_in_distance, im, None, 0, 30, 0.75, 10, 3, True, 95, 300, True, 10, 2, 1, 4, True)
+    d["base_bg5"] = quiet(vt.get_seed_points_base, im, 0.75, 5, 3, 500, 2, True)
+    sa = LEGACY_SEEDING["default"][:-1] + (False,)
+    norm = np.nanmedian(im)
+    for i, cc in enumerate(coords):
+        s = quiet(vt.get_seed_in_distance, im, cc, *sa)
+        if len(s) == 0:
+            d["fit_%d" % i] = np.zeros((0, 11), np.float32)
+            continue
+        f = F3.iter_fit_seed_points(im, s.T, *LEGACY_FIT_ARGS)
+        quiet(f.firstfit)
+        d["first_%d" % i] = np.array(f.ps, dtype=np.float32)
+        quiet(f.repeatfit)
+        sp = np.array(f.ps)
+        sp[:, 0] = sp[:, 0] / norm
+        d["fit_%d" % i] = sp
+        d["n_iter_%d" % i] = f.n_iter
+    np.savez_compressed(os.path.join(OUT, "legacy.npz"), **d)
+    meta["legacy"] = {"image": LEGACY, "seeding": {k: list(v) for k, v in LEGACY_SEEDING.items()},
+                      "fitting_args": list(LEGACY_FIT_ARGS)}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -190,6 +238,8 @@ def main():
         dr2, pt2, pr2 = R.matching.check_paired_centers(pt, pr, outlier_sigma=1.5)
         d["check_drift"], d["check_tar"], d["check_ref"] = dr2, pt2, pr2
     np.savez_compressed(os.path.join(OUT, "drift.npz"), **d)
+
+    legacy_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -406,6 +406,10 @@ class iter_fit_seed_points(object):
         self.min_w, self.max_w, self.init_w = min_w, max_w, init_w
         self.voronoi = voronoi
 
+    def _gfit(self, im_, X, center, delta_center):
+        return GaussianFit(im_, X, center=center, delta_center=delta_center,
+                           min_w=self.min_w, max_w=self.max_w, init_w=self.init_w)
+
     def _nearest_is_me(self, X_full, ic):
         pts = X_full.T
         if self.voronoi == "ckdtree":
@@ -436,8 +440,7 @@ class iter_fit_seed_points(object):
                 keep = self._nearest_is_me(X_full, ic)
                 X = X_full[:, keep]
                 im_ = self.im[X[0], X[1], X[2]]
-                obj = GaussianFit(im_, X, center=[zc, xc, yc], delta_center=self.min_delta_center,
-                                  min_w=self.min_w, max_w=self.max_w, init_w=self.init_w)
+                obj = self._gfit(im_, X, [zc, xc, yc], self.min_delta_center)
                 obj.fit()
                 self.gparms.append([im_, X, [zc, xc, yc]])
                 self.success.append(obj.success)
@@ -469,8 +472,7 @@ class iter_fit_seed_points(object):
                     im_ = self.im_add[z, x, y]
                     if self.success_old[ic]:
                         im_ = self.ims_rec[ic] + im_
-                    obj = GaussianFit(im_, X, center=[zc, xc, yc], delta_center=self.max_delta_center,
-                                      min_w=self.min_w, max_w=self.max_w, init_w=self.init_w)
+                    obj = self._gfit(im_, X, [zc, xc, yc], self.max_delta_center)
                     obj.fit()
                     self.success[ic] = obj.success
                     if obj.success:
@@ -901,3 +903,207 @@ def bleedthrough_correction(ims, bleed_profile, output_dtype=np.uint16):
         nim[nim < np.iinfo(output_dtype).min] = np.iinfo(output_dtype).min
         outs.append(nim.astype(output_dtype))
     return outs
+
+
+# ----------------------------------------------------------------------------------------------
+# (a12) legacy per-cell path: visual_tools.py:348-381,1775-1870 ; External/Fitting_v3.py ;
+#       classes/__init__.py:57-88
+# ----------------------------------------------------------------------------------------------
+
+
+def legacy_get_seed_points_base(im, gfilt_size=0.75, background_gfilt_size=10, filt_size=3,
+                                th_seed=300, hot_pix_th=0, return_h=False):
+    """visual_tools.py:348-381 (scipy.ndimage filters restated above; rank filters of any size go through
+    scipy.ndimage directly, whose output for max/min is exact)."""
+    from scipy.ndimage import maximum_filter, minimum_filter
+    max_im = gaussian_filter(im, gfilt_size) if gfilt_size else im
+    min_im = gaussian_filter(im, background_gfilt_size) if background_gfilt_size else im
+    max_filt = np.array(maximum_filter(max_im, filt_size), dtype=np.int64)
+    min_filt = np.array(minimum_filter(min_im, filt_size), dtype=np.int64)
+    im_plt2 = (max_filt == max_im) & (min_filt != min_im) & (min_filt != 0)
+    z, x, y = np.where(im_plt2)
+    keep = (max_filt[z, x, y] - min_filt[z, x, y]) > th_seed
+    x, y, z = x[keep], y[keep], z[keep]
+    h = max_filt[z, x, y] - min_filt[z, x, y]
+    if hot_pix_th > 0:
+        xy = x.astype(np.int64) * (int(im.shape[2]) + 1) + y          # same grouping as the str([x,y]) keys
+        xy_, inv, cts_ = np.unique(xy, return_inverse=True, return_counts=True)
+        keep = ~(cts_ > hot_pix_th)[inv] if len(xy) else np.zeros(0, dtype=bool)
+        x, y, z, h = x[keep], y[keep], z[keep], h[keep]
+    return np.array([z, x, y, h]) if return_h else np.array([z, x, y])
+
+
+def legacy_get_seed_in_distance(im, center=None, num_seeds=0, seed_radius=30, gfilt_size=0.75,
+                                background_gfilt_size=10, filt_size=3, seed_by_per=False,
+                                th_seed_percentile=95, th_seed=300, dynamic=True, dynamic_iters=10,
+                                min_dynamic_seeds=2, distance_to_edge=1, hot_pix_th=4, return_h=False):
+    """visual_tools.py:1775-1870 (np.float/np.int read as float/int)."""
+    from scipy.stats import scoreatpercentile
+    from scipy.spatial.distance import cdist
+    if center is not None and len(center) != 3:
+        raise ValueError('wrong input dimension of center!')
+    _dim = np.shape(im)
+    _im = im.copy()
+    if seed_by_per:
+        _im_ints = _im[np.isnan(_im) == False].astype(float)
+        _th_seed = scoreatpercentile(_im_ints, th_seed_percentile) - scoreatpercentile(_im_ints, 100 - th_seed_percentile)
+    else:
+        _th_seed = th_seed
+    if center is not None:
+        _center = np.array(center, dtype=float)
+        _limits = np.zeros([2, 3], dtype=int)
+        _limits[0, 1:] = np.array([np.max([x, y]) for x, y in zip(np.zeros(2), _center[1:] - seed_radius)], dtype=int)
+        _limits[0, 0] = np.array(np.max([0, _center[0] - seed_radius / 2]), dtype=int)
+        _limits[1, 1:] = np.array([np.min([x, y]) for x, y in zip(_dim[1:], _center[1:] + seed_radius)], dtype=int)
+        _limits[1, 0] = np.array(np.min([_dim[0], _center[0] + seed_radius / 2]), dtype=int)
+        _local_center = _center - _limits[0]
+        _cim = _im[_limits[0, 0]:_limits[1, 0], _limits[0, 1]:_limits[1, 1], _limits[0, 2]:_limits[1, 2]]
+        if dynamic:
+            for _dy_ratio in np.linspace(1, 1 / dynamic_iters, dynamic_iters):
+                _cand = legacy_get_seed_points_base(_cim, gfilt_size=gfilt_size,
+                                                    background_gfilt_size=background_gfilt_size, filt_size=filt_size,
+                                                    th_seed=th_seed * _dy_ratio,
+                                                    hot_pix_th=hot_pix_th, return_h=True)
+                _distance = cdist(_cand[:3].transpose(), _local_center[np.newaxis, :3]).transpose()[0]
+                _seeds = _cand[:, _distance < seed_radius]
+                _seeds[:3, :] += _limits[0][:, np.newaxis]
+                if num_seeds > 0 and _seeds.shape[1] >= min(num_seeds, min_dynamic_seeds):
+                    break
+                elif num_seeds == 0 and _seeds.shape[1] >= min_dynamic_seeds:
+                    break
+        else:
+            _seeds = legacy_get_seed_points_base(_cim, gfilt_size=gfilt_size, filt_size=filt_size, th_seed=th_seed,
+                                                 hot_pix_th=hot_pix_th, return_h=True)
+    else:
+        _seeds = legacy_get_seed_points_base(_im, gfilt_size=gfilt_size, filt_size=filt_size, th_seed=_th_seed,
+                                             hot_pix_th=hot_pix_th, return_h=True)
+    if _seeds.shape[1] > 1:
+        _order = np.argsort(_seeds[-1], kind="stable")   # the reference's default sort leaves ties unspecified
+        _seeds = _seeds[:, np.flipud(_order[-num_seeds:])]
+    return _seeds[:3].transpose() if not return_h else _seeds[:4].transpose()
+
+
+class GaussianFitV3(GaussianFit):
+    """External/Fitting_v3.py:50-262 where it differs from v4: per-axis start widths (:71-79), unguarded sigmoids,
+    to_center as written (:81-87), no background clip, leastsq with MINPACK's default maxfev."""
+
+    def __init__(self, im, X, center=None, n_aprox=10, min_w=0.5, max_w=4., delta_center=3.,
+                 init_w=(1.35, 1.9, 1.9), weight_sigma=0):
+        assert not weight_sigma
+        self.min_w = min_w * min_w
+        self.max_w = max_w * max_w
+        self.delta_center = delta_center
+        self.im = np.array(im, dtype=np.float32)
+        self.x, self.y, self.z = np.array(X, dtype=np.float32)
+        argsort_im = np.argsort(im)
+        if center is None:
+            center = np.median(X[:, argsort_im][:, -n_aprox:], -1)
+        self.center_est = center
+        sorted_im = im[argsort_im]
+        eps = np.exp(-10.)
+        bk_guess = np.log(np.max([np.mean(sorted_im[:n_aprox]), eps]))
+        h_guess = np.log(np.max([np.mean(sorted_im[-n_aprox:]), eps]))
+        init_w = np.array(init_w[:3]).copy()
+        for _i, _iw in enumerate(init_w):
+            if _iw ** 2 > max_w or _iw ** 2 < min_w:
+                init_w[_i] = 1.5 ** 2
+            init_w[_i] = np.log((self.max_w - init_w[_i] ** 2) / (init_w[_i] ** 2 - self.min_w))
+        self.p_ = np.array([bk_guess, h_guess, 0, 0, 0, init_w[0], init_w[1], init_w[2], 0, 0], dtype=np.float32)
+        self.to_natural_paramaters()
+        self.success = False
+
+    def _centers(self, c0_, c1_, c2_):
+        d = self.delta_center
+        c0 = 2. * d * np.exp(-c0_) / (1. + np.exp(-c0_)) - d + self.center_est[0]
+        c1 = 2. * d * np.exp(-c1_) / (1. + np.exp(-c1_)) - d + self.center_est[1]
+        c2 = 2. * d * np.exp(-c1_) / (1. + np.exp(-c2_)) - d + self.center_est[2]
+        return c0, c1, c2
+
+    def _geom(self, parms):
+        g = list(GaussianFit._geom(self, parms))
+        xc, yc, zc = self._centers(parms[2], parms[3], parms[4])
+        g[27], g[28], g[29] = self.x - xc, self.y - yc, self.z - zc
+        return tuple(g)
+
+    def calc_f(self, parms):
+        self.p_ = parms
+        g = self._geom(parms)
+        bk, h = g[0], g[1]
+        x2c, y2c, z2c, xyc, xzc, yzc, xt, yt, zt = g[21:30]
+        xsigmax = x2c * xt * xt + y2c * yt * yt + z2c * zt * zt + xyc * xt * yt + xzc * xt * zt + yzc * yt * zt
+        self.f0 = np.exp(h - 0.5 * xsigmax)
+        self.f = np.exp(bk) + self.f0
+        return self.f
+
+    def to_natural_paramaters(self, parms=None):
+        if parms is None:
+            parms = self.p_
+        bk, h, xp, yp, zp, w1, w2, w3, pp, tp = parms
+        bkf, hf = np.exp(bk), np.exp(h)
+        t, p = _sig_sine(tp), _sig_sine(pp)
+        w1f, w2f, w3f = (np.sqrt(_sig_ws(w, self.min_w, self.max_w)) for w in (w1, w2, w3))
+        xc, yc, zc = self._centers(xp, yp, zp)
+        eps = np.mean(np.abs(self.calc_eps(parms)))
+        self.p = np.array([hf, xc, yc, zc, bkf, w1f, w2f, w3f, t, p, eps], dtype=np.float32)
+        return self.p
+
+    def fit(self):
+        from scipy.optimize import leastsq
+        if len(self.p_) > len(self.im):
+            self.success = False
+        else:
+            parmsf, _ = leastsq(self.calc_eps, self.p_, Dfun=self.calc_jac)
+            self.p_ = parmsf
+            self.to_natural_paramaters()
+            self.center = self.p[1:4]
+            self.success = True
+
+
+class iter_fit_seed_points_v3(iter_fit_seed_points):
+    """External/Fitting_v3.py:312-425: same loop as v4 with GaussianFitV3 and `closest` (cdist + argmin over all
+    centres = lowest index on ties) for the first-fit Voronoi cells."""
+
+    def __init__(self, im, centers, radius_fit=5, min_delta_center=1., max_delta_center=2.5, n_max_iter=10,
+                 max_dist_th=0.1, init_w=(1.35, 1.9, 1.9), weight_sigma=0):
+        iter_fit_seed_points.__init__(self, im, centers, radius_fit, min_delta_center, max_delta_center, n_max_iter,
+                                      max_dist_th, voronoi="lowest_index")
+        self.init_w3 = init_w
+
+    def _nearest_is_me(self, X_full, ic):
+        from scipy.spatial.distance import cdist
+        dists = cdist(X_full.T, self.centers)
+        center_id = np.argmin(cdist([self.centers[ic]], self.centers)[0, :])
+        return np.argmin(dists, axis=-1) == center_id
+
+    def firstfit(self):
+        if len(self.centers) == 0:
+            raise ValueError(f"{len(self.centers)} points have been seeded, exit.")
+        iter_fit_seed_points.firstfit(self)
+
+    def _gfit(self, im_, X, center, delta_center):
+        return GaussianFitV3(im_, X, center=center, delta_center=delta_center, init_w=self.init_w3)
+
+
+def fit_single_image(_im, _id, _chrom_coords, _seeding_args, _fitting_args, _check_fitting=True,
+                     _normalization=True):
+    """classes/__init__.py:57-88."""
+    _spots_for_chrom = []
+    if _normalization:
+        _norm_cst = np.nanmedian(_im)
+    for _chrom_coord in _chrom_coords:
+        if _im is None:
+            _spots_for_chrom.append(np.array([]))
+            continue
+        _seeds = legacy_get_seed_in_distance(_im, _chrom_coord, *_seeding_args)
+        if len(_seeds) == 0:
+            _spots_for_chrom.append(np.array([]))
+            continue
+        _fitter = iter_fit_seed_points_v3(_im, _seeds.T, *_fitting_args)
+        _fitter.firstfit()
+        if _check_fitting:
+            _fitter.repeatfit()
+        _spots = np.array(_fitter.ps)
+        if _normalization:
+            _spots[:, 0] = _spots[:, 0] / _norm_cst
+        _spots_for_chrom.append(_spots)
+    return _spots_for_chrom

@@ -101,5 +101,21 @@ def load_reference():
     align = load("IA3.correction_tools.alignment", REF + "/correction_tools/alignment.py")
     ns = types.SimpleNamespace(F4=F4, fitting=fitting, filter=filt, translate=trans,
                                alignment_tools=at, matching=matching, alignment=align)
+    ns._load, ns._ext, ns._root = load, ext, root
     _loaded = ns
     return ns
+
+
+def load_legacy():
+    """Additionally execute the reference's External/Fitting_v3.py and visual_tools.py (the legacy per-cell
+    path, classes/__init__.py:57-88).  Returns (Fitting_v3 module, visual_tools module)."""
+    ns = load_reference()
+    if getattr(ns, "F3", None) is not None:
+        return ns.F3, ns.visual_tools
+    ns._ext._sigma_zxy = [1.35, 1.9, 1.9]
+    F3 = ns._load("IA3.External.Fitting_v3", REF + "/External/Fitting_v3.py")
+    ns._ext.Fitting_v3 = F3
+    vt = ns._load("IA3.visual_tools", REF + "/visual_tools.py")
+    ns._root.visual_tools = vt
+    ns.F3, ns.visual_tools = F3, vt
+    return F3, vt

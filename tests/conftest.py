@@ -53,3 +53,14 @@ def has_gpu():
 @pytest.fixture(scope="session")
 def cases():
     return _meta()["cases"]
+
+
+def build_legacy():
+    """Input of tests/golden/legacy.npz (mirror of oracle/make_golden.py::legacy_golden)."""
+    from imageanalysis3_amd import synth
+    m = _meta()["legacy"]
+    spec = m["image"]
+    im, c, h = synth.make_fov(tuple(spec["shape"]), spec["n"], spec["seed"], layout=spec["layout"],
+                              dtype=np.dtype(spec["dtype"]), margin=tuple(spec["margin"]),
+                              n_territories=spec["n_territories"])
+    return im, m

@@ -9,21 +9,33 @@
 
 using namespace ia3;
 
+static double* g_trace = nullptr; static int g_trace_cap = 0, g_trace_n = 0;
+extern "C" void ia3cpu_trace(double* buf, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+extern "C" int ia3cpu_trace_count() { return g_trace_n; }
+
 struct CpuEval {
   const float* im; const double* cz; const double* cx; const double* cy; int n; FitCfg cfg;
   double eval(const double* x, double* A, double* g) {
     Geom gm; make_geom(x, cfg, gm);
     double ss = 0;
+    int nbad = 0;   // as WaveEval::eval in fit.hip: MINPACK's enorm turns two infinities (or a NaN) into NaN
     if (A) { for (int k = 0; k < NTRI; ++k) A[k] = 0; for (int k = 0; k < NP; ++k) g[k] = 0; }
     for (int v = 0; v < n; ++v) {
       double J[NP];
       double F = A ? model_jac(gm, cz[v], cx[v], cy[v], J) : model_f0(gm, cz[v], cx[v], cy[v]);
       double r = (gm.ebk_f + F) - (double)im[v];
+      if (r != r) nbad += 2; else if (r - r != 0.0) nbad += 1;
       ss += r * r;
       if (A) {
         for (int i = 0; i < NP; ++i) { g[i] += J[i] * r; for (int j = i; j < NP; ++j) A[tri(i, j)] += J[i] * J[j]; }
       }
     }
+    if (g_trace && g_trace_n < g_trace_cap) {
+      for (int k = 0; k < NP; ++k) g_trace[11 * g_trace_n + k] = x[k];
+      g_trace[11 * g_trace_n + 10] = sqrt(ss);
+      ++g_trace_n;
+    }
+    if (nbad >= 2) return NAN;
     return sqrt(ss);
   }
 };
@@ -43,6 +55,31 @@ extern "C" int ia3cpu_gaussfit(const double* vals, const int* coords, int n, con
   LMResult r = lm_solve(ev, w, 1.49012e-8, 1.49012e-8, 0.0, 1000, 100.0);
   to_natural(w.x, ev.cfg, p_out);
   // eps = mean |f - im| at the solution
+  Geom gm; make_geom(w.x, ev.cfg, gm);
+  double s = 0;
+  for (int v = 0; v < n; ++v) s += fabs((gm.ebk_f + model_f0(gm, cz[v], cx[v], cy[v])) - (double)im[v]);
+  p_out[10] = (float)(s / n);
+  for (int k = 0; k < NP; ++k) x_out[k] = w.x[k];
+  info_nfev[0] = r.info; info_nfev[1] = r.nfev; info_nfev[2] = r.iter;
+  return 0;
+}
+
+// legacy model (FitCfg::variant = 1, External/Fitting_v3.py): start widths iw3[] already in w_ space
+extern "C" int ia3cpu_gaussfit_v3(const double* vals, const int* coords, int n, const double* center,
+                                  double delta, const double* iw3, int kind, float* p_out, double* x_out,
+                                  int* info_nfev) {
+  if (n < NP) return 1;
+  std::vector<float> im(n); std::vector<double> cz(n), cx(n), cy(n), sorted(vals, vals + n);
+  for (int v = 0; v < n; ++v) { im[v] = (float)vals[v]; cz[v] = coords[3 * v]; cx[v] = coords[3 * v + 1]; cy[v] = coords[3 * v + 2]; }
+  std::sort(sorted.begin(), sorted.end());
+  CpuEval ev; ev.im = im.data(); ev.cz = cz.data(); ev.cx = cx.data(); ev.cy = cy.data(); ev.n = n;
+  ev.cfg.min_ws = 0.25; ev.cfg.max_ws = 16.0; ev.cfg.delta = delta; ev.cfg.init_w = 1.5;
+  ev.cfg.variant = 1;
+  for (int k = 0; k < 3; ++k) { ev.cfg.c0[k] = center[k]; ev.cfg.iw[k] = iw3[k]; }
+  LMWork w;
+  init_guess(sorted.data(), sorted.data() + n - 10, kind, ev.cfg, w.x);
+  LMResult r = lm_solve(ev, w, 1.49012e-8, 1.49012e-8, 0.0, 100 * (NP + 1), 100.0);
+  to_natural(w.x, ev.cfg, p_out);
   Geom gm; make_geom(w.x, ev.cfg, gm);
   double s = 0;
   for (int v = 0; v < n; ++v) s += fabs((gm.ebk_f + model_f0(gm, cz[v], cx[v], cy[v])) - (double)im[v]);

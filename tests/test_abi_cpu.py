@@ -24,11 +24,29 @@ def test_header_symbols_exported():
     assert sorted(set(_lib.EXPORTS)) == names, (set(names) ^ set(_lib.EXPORTS))
 
 
-def test_struct_layout_matches_header():
-    """ctypes mirrors of ia3_seed_params / ia3_fit_params have the C layout (x86-64 SysV)."""
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors of the parameter structs have the layout gcc gives include/ia3.h (sizes + every offset)."""
+    import subprocess
     from imageanalysis3_amd import _lib
-    assert C.sizeof(_lib.SeedParams) == 3 * 8 + 9 * 4 + 4 + 8 + 8 + 8 + 8  # doubles, ints(+pad), ptr,int(+pad) x2
-    assert C.sizeof(_lib.FitParams) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    pairs = [("ia3_seed_params", _lib.SeedParams), ("ia3_fit_params", _lib.FitParams),
+             ("ia3_legacy_seed_params", _lib.LegacySeedParams)]
+    lines = []
+    for cname, ct in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f in ct._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f[0]))
+        lines.append('printf("\\n");')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ia3.h"\nint main(void){%s return 0;}\n'
+                   % "".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    for (cname, ct), line in zip(pairs, out):
+        tok = line.split()
+        assert tok[0] == cname and int(tok[1]) == C.sizeof(ct), (cname, tok[1], C.sizeof(ct))
+        for f, off in zip(ct._fields_, tok[2:]):
+            assert getattr(ct, f[0]).offset == int(off), (cname, f[0])
 
 
 def test_no_gpu_fails_loudly():

@@ -476,3 +476,66 @@ def test_full_size_fov_properties():
     assert len(ts) > 150 and d.max() < 1e-3
     rel = np.abs(ts[:, :8].astype(np.float64) - t[j, :8]) / np.abs(t[j, :8])
     assert rel.max() < 1e-4
+
+
+# ---- (a12) legacy per-cell path: visual_tools.get_seed_in_distance + Fitting_v3 + _fit_single_image --------
+def _tie_canon(s):
+    s = np.asarray(s)
+    return s[np.lexsort((s[:, 2], s[:, 1], s[:, 0], -s[:, 3]))] if len(s) else s.reshape(0, 4)
+
+
+def test_legacy_seed_in_distance_golden():
+    from conftest import build_legacy
+    from imageanalysis3_amd import visual_tools as vt
+    im, m = build_legacy()
+    g = load_golden("legacy.npz")
+    for name, sa in m["seeding"].items():
+        for i, cc in enumerate(g["coords"]):
+            got = vt.get_seed_in_distance(im, cc, *sa)
+            ref = g["seeds_%s_%d" % (name, i)]
+            assert got.dtype == np.int64 and got.shape == ref.shape, (name, i, got.shape, ref.shape)
+            assert np.array_equal(got[:, 3], ref[:, 3]), (name, i)          # brightest first, same heights
+            assert np.array_equal(_tie_canon(got), _tie_canon(ref)), (name, i)
+    got = vt.get_seed_in_distance(im, None, 0, 30, 0.75, 10, 3, True, 95, 300, True, 10, 2, 1, 4, True)
+    assert np.array_equal(_tie_canon(got), _tie_canon(g["seeds_whole_per"]))
+    assert np.array_equal(vt.get_seed_points_base(im, 0.75, 5, 3, 500, 2, True), g["base_bg5"])
+    with pytest.raises(ValueError):
+        vt.get_seed_in_distance(im, [1, 2])
+    # float32 stack: integer-valued maxima only (the int64 cast of the reference), same as the oracle
+    import np_oracle as O
+    imf = im.astype(np.float32)
+    a = vt.get_seed_in_distance(imf, g["coords"][0], 0, 30, 0.75, 10, 3, False, 95, 300, True, 10, 2, 1, 4, True)
+    b = O.legacy_get_seed_in_distance(imf, g["coords"][0], 0, 30, 0.75, 10, 3, False, 95, 300, True, 10, 2, 1, 4, True)
+    assert np.array_equal(_tie_canon(a), _tie_canon(b))
+
+
+def test_legacy_fit_single_image_golden():
+    from conftest import build_legacy
+    from imageanalysis3_amd.classes import _fit_single_image
+    from imageanalysis3_amd.External import Fitting_v3
+    im, m = build_legacy()
+    g = load_golden("legacy.npz")
+    sa = tuple(m["seeding"]["default"][:-1]) + (False,)
+    fa = tuple(m["fitting_args"])
+    out = _fit_single_image(im, 0, g["coords"], sa, fa)
+    assert len(out) == len(g["coords"])
+    for i, sp in enumerate(out):
+        ref = g["fit_%d" % i]
+        if len(ref) == 0:
+            assert len(sp) == 0
+            continue
+        assert sp.shape == ref.shape
+        np.testing.assert_allclose(sp[:, :8], ref[:, :8], rtol=RTOL, atol=1e-4)
+        np.testing.assert_allclose(sp[:, 8:], ref[:, 8:], rtol=1e-3, atol=2e-3)
+    # first fit alone + sweep count
+    from imageanalysis3_amd import visual_tools as vt
+    s = vt.get_seed_in_distance(im, g["coords"][0], *sa)
+    f = Fitting_v3.iter_fit_seed_points(im, s.T, *fa)
+    f.firstfit()
+    np.testing.assert_allclose(np.array(f.ps)[:, :8], g["first_0"][:, :8], rtol=RTOL, atol=1e-4)
+    f.repeatfit()
+    assert f.n_iter == int(g["n_iter_0"])
+    with pytest.raises(ValueError):
+        Fitting_v3.iter_fit_seed_points(im, np.zeros((3, 0)), *fa).firstfit()
+    with pytest.raises(NotImplementedError):
+        Fitting_v3.iter_fit_seed_points(im, s.T, *fa, weight_sigma=1.)

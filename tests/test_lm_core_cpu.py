@@ -77,3 +77,34 @@ def test_nfev_matches_minpack(lm):
 def test_too_few_voxels_fails(lm):
     rc, p, x, info = cfit(lm, np.arange(9.0), np.zeros((3, 9), int), [0, 0, 0], 1.0, 0)
     assert rc == 1
+
+
+def test_legacy_v3_model_matches_reference_rows(lm):
+    """FitCfg::variant 1 (Fitting_v3's to_center and per-axis start widths) against the reference's own
+    first-fit rows of the legacy golden case."""
+    from conftest import build_legacy
+    im, m = build_legacy()
+    g = load_golden("legacy.npz")
+    sa = tuple(m["seeding"]["default"][:-1]) + (False,)
+    iw = np.array([np.log((16.0 - w * w) / (w * w - 0.25)) for w in (1.35, 1.9, 1.9)])
+    for i in (0, 3):
+        seeds = O.legacy_get_seed_in_distance(im, g["coords"][i], *sa)
+        f = O.iter_fit_seed_points_v3(im, seeds.T, *m["fitting_args"])
+        zb, xb, yb = O.ball_offsets(5)
+        for ic, (zc, xc, yc) in enumerate(f.centers):
+            z, x, y = O._in_dim(int(zc) + zb, int(xc) + xb, int(yc) + yb, *im.shape)
+            X_full = np.array([z, x, y], dtype=int)
+            X = X_full[:, f._nearest_is_me(X_full, ic)]
+            vals = im[X[0], X[1], X[2]]
+            p = np.zeros(11, np.float32); xo = np.zeros(10); info = np.zeros(3, np.int32)
+            v = np.ascontiguousarray(vals, dtype=np.float64)
+            co = np.ascontiguousarray(X.T, dtype=np.int32)
+            c = np.array([zc, xc, yc], dtype=np.float64)
+            rc = lm.ia3cpu_gaussfit_v3(v.ctypes.data_as(C.c_void_p), co.ctypes.data_as(C.c_void_p), C.c_int(len(v)),
+                                       c.ctypes.data_as(C.c_void_p), C.c_double(1.0), iw.ctypes.data_as(C.c_void_p),
+                                       C.c_int(1), p.ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p),
+                                       info.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            ref = g["first_%d" % i][ic].astype(np.float64)
+            rel = np.abs(p[:8] - ref[:8]) / np.abs(ref[:8])
+            assert rel.max() <= 1e-5, (i, ic, rel, info)

@@ -152,3 +152,37 @@ def test_phase_xcorr_known_answer():
         assert np.allclose(shift, -d, atol=0.06), (norm, shift)
     shift, _, _ = O.phase_cross_correlation(ref, src, upsample_factor=1)
     assert np.array_equal(shift, np.round(-d + 1e-9)) or np.allclose(shift, -d, atol=0.51)
+
+
+# ---- (a12) legacy per-cell path -----------------------------------------------------------------------------
+def _legacy_rows(s):
+    s = np.asarray(s)
+    return s[np.lexsort((s[:, 2], s[:, 1], s[:, 0], -s[:, 3]))] if len(s) else s.reshape(0, 4)
+
+
+def test_legacy_seeding_oracle_vs_reference_golden():
+    from conftest import build_legacy
+    im, m = build_legacy()
+    g = load_golden("legacy.npz")
+    assert np.uint32(zlib.crc32(im.tobytes())) == g["crc"]
+    for name, sa in m["seeding"].items():
+        for i, cc in enumerate(g["coords"]):
+            got = O.legacy_get_seed_in_distance(im, cc, *sa)
+            assert np.array_equal(got, g["seeds_%s_%d" % (name, i)]), (name, i)
+    got = O.legacy_get_seed_in_distance(im, None, 0, 30, 0.75, 10, 3, True, 95, 300, True, 10, 2, 1, 4, True)
+    assert np.array_equal(got, g["seeds_whole_per"])
+    assert np.array_equal(O.legacy_get_seed_points_base(im, 0.75, 5, 3, 500, 2, True), g["base_bg5"])
+
+
+def test_legacy_fit_single_image_oracle_vs_reference_golden():
+    from conftest import build_legacy
+    im, m = build_legacy()
+    g = load_golden("legacy.npz")
+    sa = tuple(m["seeding"]["default"][:-1]) + (False,)
+    out = O.fit_single_image(im, 0, g["coords"], sa, tuple(m["fitting_args"]))
+    for i, sp in enumerate(out):
+        ref = g["fit_%d" % i]
+        if len(ref) == 0:
+            assert len(sp) == 0
+        else:
+            assert np.array_equal(sp, ref, equal_nan=True), i
