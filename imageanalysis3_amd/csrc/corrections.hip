@@ -9,6 +9,7 @@
 // two middle ranks NumPy averages.
 #include "ia3_rt.h"
 #include <math.h>
+#include <vector>
 
 using namespace ia3rt;
 
@@ -138,18 +139,16 @@ __global__ __launch_bounds__(256) void bleed_k(ChanPtrs ch, int C, int Z, size_t
 
 }  // namespace
 
-extern "C" {
+namespace ia3k {
 
-// corrections.py:479-487 Z_Shift_Correction(im.astype(float32), dtype=uint16): out (uint16) = im / median_z * median
-int ia3_z_shift_correction(const void* im, int dtype, int Z, int X, int Y, void* out_u16, float* medians_out) {
-  ia3_stack* s = nullptr;
-  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
+// med[z] for the Z planes and med[Z] for the whole stack (device array of Z+1 floats): np.median in float32
+int stack_medians(const ia3_stack* s, float* dmed) {
   hipStream_t st = stream();
-  const size_t plane = (size_t)X * Y, n = plane * Z;
+  const int Z = s->Z;
+  const size_t plane = (size_t)s->X * s->Y, n = plane * Z;
   const int n_prob = 2 * (Z + 1);
-  Scratch dst((size_t)n_prob * sizeof(SelState)), dh((size_t)n_prob * RB * sizeof(unsigned int)),
-      dmed((size_t)(Z + 1) * sizeof(float)), dout(n * sizeof(uint16_t));
-  if (!dst.p || !dh.p || !dmed.p || !dout.p) { ia3_stack_free(s); return IA3_ENOMEM; }
+  Scratch dst((size_t)n_prob * sizeof(SelState)), dh((size_t)n_prob * RB * sizeof(unsigned int));
+  if (!dst.p || !dh.p) return IA3_ENOMEM;
   std::vector<SelState> hs(n_prob);
   for (int z = 0; z <= Z; ++z) {
     const unsigned long long cnt = z < Z ? plane : n;
@@ -163,18 +162,49 @@ int ia3_z_shift_correction(const void* im, int dtype, int Z, int X, int Y, void*
     ProfScope ps("zshift_median");
     for (int pass = 0; pass < 3 && e == hipSuccess; ++pass) {
       e = hipMemsetAsync(dh.p, 0, (size_t)n_prob * RB * sizeof(unsigned int), st);
-      if (dtype == IA3_F32) hipLaunchKernelGGL((select_hist_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)s->d, Z, plane, pass, (const SelState*)dst.p, dh.as<unsigned int>());
+      if (s->dtype == IA3_F32) hipLaunchKernelGGL((select_hist_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)s->d, Z, plane, pass, (const SelState*)dst.p, dh.as<unsigned int>());
       else hipLaunchKernelGGL((select_hist_k<uint16_t>), dim3(gx, Z), dim3(256), 0, st, (const uint16_t*)s->d, Z, plane, pass, (const SelState*)dst.p, dh.as<unsigned int>());
       hipLaunchKernelGGL(select_pick_k, dim3((n_prob + 63) / 64), dim3(64), 0, st, dst.as<SelState>(), (const unsigned int*)dh.p, n_prob, pass);
     }
-    hipLaunchKernelGGL(select_finish_k, dim3((Z + 64) / 64), dim3(64), 0, st, (const SelState*)dst.p, Z, dmed.as<float>());
+    hipLaunchKernelGGL(select_finish_k, dim3((Z + 64) / 64), dim3(64), 0, st, (const SelState*)dst.p, Z, dmed);
   }
+  if (e == hipSuccess) e = hipGetLastError();
+  // hs is read by the (pageable, hence already staged) H2D copy above; nothing else host-side is pending
+  if (e != hipSuccess) return set_error(IA3_EHIP, "median selection failed: %s", hipGetErrorString(e));
+  return IA3_OK;
+}
+
+int stack_median_all(const ia3_stack* s, float* med_all) {
+  Scratch dmed((size_t)(s->Z + 1) * sizeof(float));
+  if (!dmed.p) return IA3_ENOMEM;
+  int rc = stack_medians(s, dmed.as<float>()); if (rc) return rc;
+  IA3_HIP(hipMemcpyAsync(med_all, dmed.as<float>() + s->Z, sizeof(float), hipMemcpyDeviceToHost, stream()));
+  IA3_HIP(hipStreamSynchronize(stream()));
+  return IA3_OK;
+}
+
+}  // namespace ia3k
+
+extern "C" {
+
+// corrections.py:479-487 Z_Shift_Correction(im.astype(float32), dtype=uint16): out (uint16) = im / median_z * median
+int ia3_z_shift_correction(const void* im, int dtype, int Z, int X, int Y, void* out_u16, float* medians_out) {
+  ia3_stack* s = nullptr;
+  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
+  hipStream_t st = stream();
+  const size_t plane = (size_t)X * Y, n = plane * Z;
+  Scratch dmed((size_t)(Z + 1) * sizeof(float)), dout(n * sizeof(uint16_t));
+  if (!dmed.p || !dout.p) { ia3_stack_free(s); return IA3_ENOMEM; }
+  rc = ia3k::stack_medians(s, dmed.as<float>());
+  if (rc) { ia3_stack_free(s); return rc; }
+  unsigned gx = (unsigned)((plane + 256 * 16 - 1) / (256 * 16));
+  if (gx < 1) gx = 1;
   {
     ProfScope ps("zshift_apply");
     if (dtype == IA3_F32) hipLaunchKernelGGL((zshift_apply_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)s->d, Z, plane, (const float*)dmed.p, dout.as<uint16_t>());
     else hipLaunchKernelGGL((zshift_apply_k<uint16_t>), dim3(gx, Z), dim3(256), 0, st, (const uint16_t*)s->d, Z, plane, (const float*)dmed.p, dout.as<uint16_t>());
   }
-  if (e == hipSuccess) e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out_u16, dout.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess && medians_out) e = hipMemcpyAsync(medians_out, dmed.p, (size_t)(Z + 1) * sizeof(float), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -48,24 +48,45 @@ def bleedthrough_correction(ims, bleed_profile, output_dtype=np.uint16):
     return outs
 
 
+def _background_edges(dtype, bin_size):
+    """The reference's bin edges (io_tools/load.py:655-658) as the float64 vector the device entry takes."""
+    info = np.iinfo(dtype)
+    return np.ascontiguousarray(np.arange(info.min, info.max, bin_size), dtype=np.float64)
+
+
+def _stack3(im):
+    if not isinstance(im, np.ndarray):
+        raise TypeError("im should be a numpy.ndarray")
+    a = im if im.ndim == 3 else im.reshape((1,) * (3 - im.ndim) + im.shape) if im.ndim < 3 else im.reshape(-1, *im.shape[-2:])
+    return L.as_stack_array(a)
+
+
 def find_image_background(im, dtype=_image_dtype, bin_size=10, make_plot=False, max_iter=10):
-    """Histogram-peak background level (io_tools/load.py:642-687)."""
-    import scipy.signal
+    """Histogram-peak background level (io_tools/load.py:642-687), computed by ``ia3_find_background(_dev)``
+    (background.hip).  ``im``: uint16/float32 ndarray or a resident ``DeviceStack``.  ``make_plot`` is accepted
+    for signature compatibility and ignored (plotting is out of scope)."""
     if dtype is None:
         dtype = im.dtype
-    _cts, _bins = np.histogram(im, bins=np.arange(np.iinfo(dtype).min, np.iinfo(dtype).max, bin_size))
-    _peaks = []
-    _height = np.size(im) / 50
-    _iter = 0
-    while len(_peaks) == 0:
-        _height = _height / 2
-        _peaks, _params = scipy.signal.find_peaks(_cts, height=_height)
-        _iter += 1
-        if _iter > max_iter:
-            break
-    if _iter > max_iter:
-        _background = np.nanmedian(im)
+    edges = _background_edges(dtype, bin_size)
+    out = C.c_double(0.0)
+    if isinstance(im, L.DeviceStack):
+        L.check(L.lib().ia3_find_background_dev(im._h, L.dptr(edges), len(edges), int(max_iter), C.byref(out)))
     else:
-        _sel_peak = _peaks[np.argmax(_params['peak_heights'])]
-        _background = (_bins[_sel_peak] + _bins[_sel_peak + 1]) / 2
-    return _background
+        a = _stack3(im)
+        L.check(L.lib().ia3_find_background(L.ptr(a), L.dtype_code(a), a.shape[0], a.shape[1], a.shape[2],
+                                            L.dptr(edges), len(edges), int(max_iter), C.byref(out)))
+    return np.float64(out.value)
+
+
+def find_local_backgrounds(stack, centers_zxy, crop_size, dtype=_image_dtype, bin_size=10, make_plot=False,
+                           max_iter=10):
+    """``[find_image_background(im[generate_neighboring_crop(c, crop_size).to_slices()], ...) for c in centers]``
+    (spot_tools/fitting.py:249-256) in one launch on a resident stack."""
+    if dtype is None:
+        dtype = stack.dtype
+    edges = _background_edges(dtype, bin_size)
+    c = np.ascontiguousarray(centers_zxy, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(len(c), dtype=np.float64)
+    L.check(L.lib().ia3_local_background_dev(stack._h, L.ptr(c), len(c), int(crop_size), L.dptr(edges), len(edges),
+                                             int(max_iter), L.dptr(out)))
+    return out

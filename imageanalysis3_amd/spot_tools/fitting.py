@@ -130,29 +130,25 @@ def fit_fov_image(im, channel, seeds=None,
         _fitter.firstfit()
         _fitter.repeatfit()
         _spots = np.array(_fitter.ps)
+        _spots = _spots[np.sum(np.isnan(_spots), axis=1) == 0]               # :232
+        if remove_boundary_points:                                           # :234-237
+            _kept = (_spots[:, 1:4] > np.zeros(3)).all(1) * (_spots[:, 1:4] < np.array(np.shape(im))).all(1)
+            _spots = _spots[np.where(_kept)[0]]
+        # intensity normalisation on the copy that is still resident (background.hip)
+        if normalize_background and not normalize_local:                     # :240-245
+            from ..io_tools.load import find_image_background
+            _back = find_image_background(_stack, **background_args)
+            if verbose:
+                print(f"normalize total background:{_back:.2f}, ", end='')
+            _spots[:, 0] = _spots[:, 0] / _back
+        elif normalize_local:                                                # :246-258
+            from ..io_tools.load import find_local_backgrounds
+            _backs = find_local_backgrounds(_stack, _spots[:, 1:4], fit_radius * 2, **background_args)
+            if verbose:
+                print("normalize local background for each spot, ", end='')
+            _spots[:, 0] = _spots[:, 0] / np.array(_backs)
     finally:
         _stack.free()
-    _spots = _spots[np.sum(np.isnan(_spots), axis=1) == 0]                   # :232
-    if remove_boundary_points:                                               # :234-237
-        _kept = (_spots[:, 1:4] > np.zeros(3)).all(1) * (_spots[:, 1:4] < np.array(np.shape(im))).all(1)
-        _spots = _spots[np.where(_kept)[0]]
-    if normalize_background and not normalize_local:                         # :240-245
-        from ..io_tools.load import find_image_background
-        _back = find_image_background(im, **background_args)
-        if verbose:
-            print(f"normalize total background:{_back:.2f}, ", end='')
-        _spots[:, 0] = _spots[:, 0] / _back
-    elif normalize_local:                                                    # :246-258
-        from ..io_tools.load import find_image_background
-        from ..io_tools.crop import generate_neighboring_crop
-        _backs = []
-        for _pt in _spots:
-            _crop = generate_neighboring_crop(_pt[1:4], crop_size=fit_radius * 2,
-                                              single_im_size=np.array(np.shape(im)))
-            _backs.append(find_image_background(im[_crop.to_slices()], **background_args))
-        if verbose:
-            print("normalize local background for each spot, ", end='')
-        _spots[:, 0] = _spots[:, 0] / np.array(_backs)
     if verbose:
         print(f"{len(_spots)} fitted in {time.time()-_fit_time:.3f}s.")
     return _spots

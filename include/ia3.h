@@ -120,6 +120,20 @@ int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_
 int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p,
                      double* out_zxyh, int capacity, int* n_out, double* th_used);
 
+/* ---- background level: io_tools/load.py:642-687 find_image_background -----------------------------------
+ * counts = np.histogram(im, bins=edges); highest strict local maximum of the counts (scipy.signal.find_peaks,
+ * height halved from size/50 at most max_iter times); background = centre of that bin; np.nanmedian(im) when no
+ * bin qualifies.  edges: the reference's np.arange(iinfo(dtype).min, iinfo(dtype).max, bin_size) as float64
+ * (n_edges <= 16001). */
+int ia3_find_background(const void* im, int dtype, int Z, int X, int Y, const double* edges, int n_edges,
+                        int max_iter, double* background);
+int ia3_find_background_dev(const ia3_stack* im, const double* edges, int n_edges, int max_iter, double* background);
+/* spot_tools/fitting.py:246-258 (normalize_local=True): the same statistic over
+ * io_tools/crop.py:59-88 generate_neighboring_crop(center, crop_size) for each of n centres (n x 3 float32, the
+ * fitted [z,x,y] columns of the spot table), one block per spot. */
+int ia3_local_background_dev(const ia3_stack* im, const float* centers_zxy, int n, int crop_size,
+                             const double* edges, int n_edges, int max_iter, double* backgrounds);
+
 /* ---- legacy per-cell seeding: visual_tools.py:1775-1870 get_seed_in_distance (+ :348-381 get_seed_points_base),
  * the seeder of classes/__init__.py:57-88 `_fit_single_image`.  Crop of +-seed_radius (x, y) / +-seed_radius/2 (z)
  * around `center` (NULL: whole image), scipy-default Gaussian filters (reflect, truncate 4), int64-truncated

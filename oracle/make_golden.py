@@ -113,6 +113,56 @@ def legacy_golden(meta):
                       "fitting_args": list(LEGACY_FIT_ARGS)}
 
 
+NORM_CASES = ["c1_u16", "c1_f32", "hot_u16", "edge_f32"]
+
+
+def special_background_images():
+    """Small stacks that drive find_image_background (io_tools/load.py:642-687) through its corners."""
+    rng = np.random.RandomState(4)
+    d = {}
+    d["const"] = np.full((6, 12, 12), 500, np.uint16)                      # single bin > edge rule -> still a peak
+    d["const0"] = np.zeros((6, 12, 12), np.uint16)                         # everything in bin 0: no peak -> median
+    d["plateau"] = np.repeat(np.array([100, 110, 120, 130], np.uint16), 216).reshape(6, 12, 12)   # flat top
+    d["two_peaks_tie"] = np.repeat(np.array([100, 300, 500, 700], np.uint16), [300, 132, 300, 132]).reshape(6, 12, 12)
+    d["top_edge"] = np.full((6, 12, 12), 65530, np.uint16)                 # == last edge: closed last bin
+    d["above_range"] = np.full((6, 12, 12), 65534, np.uint16)              # dropped by the histogram
+    x = rng.normal(420., 35., size=(8, 20, 20))
+    d["noise_u16"] = np.clip(x, 0, 65535).astype(np.uint16)
+    d["noise_f32"] = x.astype(np.float32)
+    y = x.astype(np.float32).copy(); y[0, :3, :3] = np.nan
+    d["nan_f32"] = y
+    d["sparse"] = (rng.randint(0, 6000, size=(4, 8, 8)) * 10).astype(np.uint16)   # every count 0 or 1-2
+    return d
+
+
+def norm_golden(meta):
+    """Background normalisation of fit_fov_image (spot_tools/fitting.py:240-258) and find_image_background."""
+    R = ref_loader.load_reference()
+    load, crop = ref_loader.load_io()
+    d = {}
+    for name in NORM_CASES:
+        im = case_image(CASES[name])
+        plain = quiet(R.fitting.fit_fov_image, im, "647", th_seed=600, verbose=False)
+        loc = quiet(R.fitting.fit_fov_image, im, "647", th_seed=600, normalize_local=True, verbose=False)
+        glo = quiet(R.fitting.fit_fov_image, im, "647", th_seed=600, normalize_background=True, verbose=False)
+        d[name + "_plain"] = plain
+        d[name + "_local"] = loc
+        d[name + "_global"] = glo
+        d[name + "_back"] = np.float64(quiet(load.find_image_background, im))
+        d[name + "_back_b25_i3"] = np.float64(quiet(load.find_image_background, im, bin_size=25, max_iter=3))
+        backs = []
+        for pt in plain:
+            c = crop.generate_neighboring_crop(pt[1:4], crop_size=10, single_im_size=np.array(im.shape))
+            backs.append(load.find_image_background(im[c.to_slices()]))
+        d[name + "_backs"] = np.array(backs, dtype=np.float64)
+    sp = special_background_images()
+    for k, im in sp.items():
+        d["special_" + k] = np.float64(quiet(load.find_image_background, im))
+        d["special_i1_" + k] = np.float64(quiet(load.find_image_background, im, max_iter=1))
+    np.savez_compressed(os.path.join(OUT, "norm.npz"), **d)
+    meta["norm_cases"] = NORM_CASES
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -240,6 +290,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "drift.npz"), **d)
 
     legacy_golden(meta)
+    norm_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

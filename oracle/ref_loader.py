@@ -119,3 +119,31 @@ def load_legacy():
     ns._root.visual_tools = vt
     ns.F3, ns.visual_tools = F3, vt
     return F3, vt
+
+
+def load_io():
+    """Execute the reference's io_tools/crop.py, io_tools/load.py and classes/preprocess.py (for the background
+    normalisation of fit_fov_image, spot_tools/fitting.py:240-258).  Returns (load module, crop module)."""
+    ns = load_reference()
+    if getattr(ns, "io_load", None) is not None:
+        return ns.io_load, ns.io_crop
+    import sys
+    load_legacy()   # classes/preprocess.py:330 imports DaxReader from the real visual_tools
+    if "h5py" not in sys.modules:
+        sys.modules["h5py"] = types.ModuleType("h5py")   # imported at preprocess.py:335, unused on this path
+    G = {k: getattr(ns._root, k) for k in ("_distance_zxy", "_image_size", "_allowed_colors", "_corr_channels",
+                                           "_correction_folder", "_num_buffer_frames", "_num_empty_frames",
+                                           "_image_dtype")}
+    io = sys.modules["IA3.io_tools"]
+    io.__dict__.update(G)
+    cl = types.ModuleType("IA3.classes")
+    cl.__path__ = []
+    sys.modules["IA3.classes"] = cl
+    crop = ns._load("IA3.io_tools.crop", REF + "/io_tools/crop.py")
+    io.crop = crop
+    load = ns._load("IA3.io_tools.load", REF + "/io_tools/load.py")
+    io.load = load
+    pre = ns._load("IA3.classes.preprocess", REF + "/classes/preprocess.py")
+    cl.preprocess = pre
+    ns.io_load, ns.io_crop = load, crop
+    return load, crop

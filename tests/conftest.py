@@ -64,3 +64,22 @@ def build_legacy():
                               dtype=np.dtype(spec["dtype"]), margin=tuple(spec["margin"]),
                               n_territories=spec["n_territories"])
     return im, m
+
+
+def special_background_images():
+    """Mirror of oracle/make_golden.py::special_background_images."""
+    rng = np.random.RandomState(4)
+    d = {}
+    d["const"] = np.full((6, 12, 12), 500, np.uint16)
+    d["const0"] = np.zeros((6, 12, 12), np.uint16)
+    d["plateau"] = np.repeat(np.array([100, 110, 120, 130], np.uint16), 216).reshape(6, 12, 12)
+    d["two_peaks_tie"] = np.repeat(np.array([100, 300, 500, 700], np.uint16), [300, 132, 300, 132]).reshape(6, 12, 12)
+    d["top_edge"] = np.full((6, 12, 12), 65530, np.uint16)
+    d["above_range"] = np.full((6, 12, 12), 65534, np.uint16)
+    x = rng.normal(420., 35., size=(8, 20, 20))
+    d["noise_u16"] = np.clip(x, 0, 65535).astype(np.uint16)
+    d["noise_f32"] = x.astype(np.float32)
+    y = x.astype(np.float32).copy(); y[0, :3, :3] = np.nan
+    d["nan_f32"] = y
+    d["sparse"] = (rng.randint(0, 6000, size=(4, 8, 8)) * 10).astype(np.uint16)
+    return d

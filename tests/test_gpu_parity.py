@@ -539,3 +539,42 @@ def test_legacy_fit_single_image_golden():
         Fitting_v3.iter_fit_seed_points(im, np.zeros((3, 0)), *fa).firstfit()
     with pytest.raises(NotImplementedError):
         Fitting_v3.iter_fit_seed_points(im, s.T, *fa, weight_sigma=1.)
+
+
+# ---- background level / intensity normalisation (background.hip) -------------------------------------------
+def test_find_image_background_golden_bit_exact():
+    from conftest import special_background_images
+    from imageanalysis3_amd.io_tools.load import find_image_background
+    g = load_golden("norm.npz")
+    for k, im in special_background_images().items():
+        assert find_image_background(im) == g["special_" + k], k
+        assert find_image_background(im, max_iter=1) == g["special_i1_" + k], k
+    for name in ["c1_u16", "c1_f32", "hot_u16", "edge_f32"]:
+        im = build_case(name)
+        assert find_image_background(im) == g[name + "_back"], name
+        assert find_image_background(im, bin_size=25, max_iter=3) == g[name + "_back_b25_i3"], name
+    # non-uniform edges go through the binary search: same answer as NumPy on the oracle
+    import np_oracle as O
+    im = build_case("c1_u16")
+    assert find_image_background(im, bin_size=7) == O.find_image_background(im, bin_size=7)
+    assert find_image_background(im[3], bin_size=10) == O.find_image_background(im[3], bin_size=10)   # 2-D input
+
+
+@pytest.mark.parametrize("name", ["c1_u16", "c1_f32", "hot_u16", "edge_f32"])
+def test_local_background_and_normalised_rows_golden(name):
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.io_tools.load import find_local_backgrounds
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    g = load_golden("norm.npz")
+    im = build_case(name)
+    st = L.DeviceStack.upload(im)
+    try:
+        backs = find_local_backgrounds(st, g[name + "_plain"][:, 1:4], 10)
+    finally:
+        st.free()
+    assert np.array_equal(backs, g[name + "_backs"])            # integer histogram work: bit-exact
+    for key, kw in (("_local", dict(normalize_local=True)), ("_global", dict(normalize_background=True))):
+        rows = fit_fov_image(im, "647", th_seed=600, verbose=False, **kw)
+        ref = g[name + key]
+        ia, ib = match_rows(rows, ref)
+        np.testing.assert_allclose(rows[ia][:, :8], ref[ib][:, :8], rtol=RTOL, atol=1e-4)

@@ -186,3 +186,26 @@ def test_legacy_fit_single_image_oracle_vs_reference_golden():
             assert len(sp) == 0
         else:
             assert np.array_equal(sp, ref, equal_nan=True), i
+
+
+# ---- background normalisation (fitting.py:240-258, io_tools/load.py:642-687) ----------------------------------
+def test_find_image_background_oracle_vs_reference_golden():
+    from conftest import special_background_images
+    g = load_golden("norm.npz")
+    for k, im in special_background_images().items():
+        assert O.find_image_background(im) == g["special_" + k], k
+        assert O.find_image_background(im, max_iter=1) == g["special_i1_" + k], k
+    for name in ("c1_u16", "c1_f32"):
+        im = build_case(name)
+        assert O.find_image_background(im) == g[name + "_back"]
+        assert O.find_image_background(im, bin_size=25, max_iter=3) == g[name + "_back_b25_i3"]
+
+
+@pytest.mark.parametrize("name", ["c1_u16", "edge_f32"])
+def test_fit_fov_image_normalised_oracle_vs_reference_golden(name):
+    g = load_golden("norm.npz")
+    im = build_case(name)
+    loc = O.fit_fov_image(im, "647", th_seed=600, normalize_local=True)
+    assert np.array_equal(loc, g[name + "_local"])
+    glo = O.fit_fov_image(im, "647", th_seed=600, normalize_background=True)
+    assert np.array_equal(glo, g[name + "_global"])
