@@ -48,9 +48,10 @@ def parse():
 
 def algorithmic_bytes(kernel, shape, esize=4):
     """ALGORITHMIC HBM bytes of one launch: every Gaussian axis pass reads and writes the
-    stack once (8 B/voxel for f32); seed_detect reads the two filtered stacks (8 B/voxel)."""
+    stack once (8 B/voxel for f32), and so does the fused three-axis short-filter kernel; seed_detect reads the
+    two filtered stacks (8 B/voxel)."""
     vox = float(shape[0]) * shape[1] * shape[2]
-    if kernel.startswith("gauss_axis"):
+    if kernel.startswith("gauss_axis") or kernel.startswith("gauss_fused3"):
         return 2 * esize * vox
     if kernel == "seed_detect":
         return 2 * esize * vox
@@ -147,9 +148,11 @@ def main():
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": dom_n,
                     "note": "exact scipy.ndimage arithmetic (f64, no FMA) makes the Gaussian passes "
                             "f64-VALU-bound: see valu_frac"}
-            if dom_name.startswith("gauss_axis"):
+            if dom_name.startswith("gauss_axis") or dom_name.startswith("gauss_fused3"):
                 R = int(dom_name.split("_R")[1])
                 ops = (3 * R + 1) * float(shape[0]) * shape[1] * shape[2]   # add,mul,add per tap pair + 1
+                if dom_name.startswith("gauss_fused3"):
+                    ops *= 3                                                  # three axes in one launch
                 roof["valu_frac"] = round(ops / avg_s / (F64_VALU_PEAK_TFLOPS / 2 * 1e12), 4)
         filt_seed_ms = sum(v for k, v in stage_ms.items() if k.startswith("gauss") or k == "seed_detect")
         vox_bytes = 4.0 * shape[0] * shape[1] * shape[2]

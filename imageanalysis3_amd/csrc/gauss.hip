@@ -14,8 +14,10 @@
 // instructions per tap pair with the taps in SGPRs and no LDS/VMEM traffic.
 //   - axes 0/1 (strided): lanes run along the contiguous y axis, every window load is a coalesced
 //     256 B row segment per wave; the reflect/nearest index mapping is wave-uniform (scalar).
-//   - axis 2 (contiguous): a wave owns 64 rows; 64x32 tiles are transposed through LDS so that every lane
-//     slides the same register window along its own row while global access stays row-coalesced.
+//   - axis 2 (contiguous), short filters (HBM-bound): a wave owns 64 rows; 64x32 tiles are transposed through
+//     LDS so that every lane slides the same register window along its own row while global access stays
+//     row-coalesced.  Long filters (VALU-bound, R >= 16): the axis-1 pass stores each plane transposed and the
+//     axis-2 pass is the strided kernel over that transposed plane, storing transposed again.
 #include "ia3_rt.h"
 
 namespace {
@@ -49,7 +51,13 @@ __global__ void border_map_k(int* bmap, int count, int R, int len, int mode) {
 // A thread walks one segment [blockIdx.z*seg, +seg) of its line in chunks of K outputs with a sliding register
 // window: after a chunk the window shifts by K (2R register moves) and only K new inputs are loaded, so every
 // input is read once per segment instead of (K+2R)/K times.
-template <class T, int R, int K>
+// TR: the output is written TRANSPOSED inside each outer slab, out[outer][p][q] instead of out[outer][q][p] (every
+// lane stores its K consecutive outputs as one contiguous K*sizeof(T) piece).  Two transposing passes in a row
+// (axis 1, then axis 2 run as a strided pass over the transposed slab) give the contiguous axis the same
+// register-window kernel as the other two.
+template <class T, int K> struct OutVec { T v[K]; } __attribute__((packed, aligned(4)));
+
+template <class T, int R, int K, bool TR = false>
 __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T* __restrict__ out,
                                                      int inner, size_t stride, int len,
                                                      size_t outer_stride, Taps taps,
@@ -76,58 +84,28 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
     }
+    if constexpr (TR) {
+      T* o = out + (size_t)blockIdx.y * outer_stride + (size_t)p * len + q0;
+      if (q0 + K <= q_end) {
+        OutVec<T, K> v;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (q0 + k < q_end) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
+        for (int k = 0; k < K; ++k) v.v[k] = cvt<T>(acc[k]);
+        *reinterpret_cast<OutVec<T, K>*>(o) = v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (q0 + k < q_end) o[k] = cvt<T>(acc[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (q0 + k < q_end) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
+    }
 #pragma unroll
     for (int i = 0; i < 2 * R; ++i) win[i] = win[i + K];
 #pragma unroll
     for (int i = 0; i < K; ++i) win[2 * R + i] = (double)nxt[i];
   }
-}
-
-// ---- contiguous axis, long filters: one block = one segment of 256*K outputs of one row, window read from an
-// LDS-staged row with stride K (odd) words.  Kept for R >= 16 where the register-window variant below spills.
-template <class T, int R, int K>
-__global__ __launch_bounds__(256) void gauss_contig_row(const T* __restrict__ in, T* __restrict__ out,
-                                                    int len, Taps taps,
-                                                    const int* __restrict__ bmap) {
-  constexpr int SEG = 256 * K;
-  __shared__ float tile[SEG + 2 * R];
-  const size_t row = (size_t)blockIdx.y * len;
-  const int s0 = blockIdx.x * SEG;
-  for (int i = threadIdx.x; i < SEG + 2 * R; i += 256) {
-    int q = s0 - R + i;
-    float v = 0.f;
-    if (q < len + R) v = (float)ld<T>(in, row + bmap[q + R]);
-    tile[i] = v;
-  }
-  __syncthreads();
-  const int o0 = threadIdx.x * K;
-  const bool active = s0 + o0 < len;   // no early return: every thread reaches the barriers below
-  double acc[K];
-  if (active) {
-    double win[K + 2 * R];
-#pragma unroll
-    for (int i = 0; i < K + 2 * R; ++i) win[i] = (double)tile[o0 + i];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = win[k + R] * taps.w[0];
-#pragma unroll
-    for (int j = R; j >= 1; --j) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
-    }
-  }
-  // stage the K outputs back through LDS so the global store is coalesced
-  __syncthreads();
-  T* tout = reinterpret_cast<T*>(tile);
-  if (active) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) tout[o0 + k] = cvt<T>(acc[k]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < SEG; i += 256)
-    if (s0 + i < len) out[row + s0 + i] = tout[i];
 }
 
 // ---- contiguous axis: a wave owns 64 rows and walks a y-segment with the same sliding register window ------
@@ -241,9 +219,122 @@ __global__ __launch_bounds__(256) void highpass_k(const T* __restrict__ im, cons
   }
 }
 
+// ---- short filters, all three axes in one kernel --------------------------------------------------------------
+// The three passes of a short filter are HBM-bound (10 f64 ops per 8 B for R = 3), so running them back to back
+// costs three reads and three writes of the stack.  Here a 256-thread block owns a TX x TY (x, y) tile and marches
+// along z: the (TX+2R) x (TY+2R) halo tile of the axis-0 result of plane z is produced from a (2R+1)-deep register
+// window of raw planes (each thread owns ~11 positions of the halo tile), quantised to the stack dtype exactly as
+// the standalone pass would store it, and parked in LDS; the axis-1 pass reads it out of LDS (TX x (TY+2R)
+// outputs, quantised, second LDS tile) and the axis-2 pass reads that and stores to HBM with lanes along y.  Every
+// intermediate value is the one the three-kernel path produces (same order of operations, same rounding to the
+// stack dtype between axes); traffic drops from 6 to ~2.3 stack transfers.
+template <class T, int R>
+__global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T* __restrict__ out, int Z, int X, int Y,
+                                                    Taps taps, const int* __restrict__ mz, const int* __restrict__ mx,
+                                                    const int* __restrict__ my, int zseg) {
+  constexpr int TX = 32, TY = 64, W = 2 * R + 1;
+  constexpr int EX = TX + 2 * R, EY = TY + 2 * R;          // halo tile
+  constexpr int NPOS = EX * EY, SL = (NPOS + 255) / 256;   // positions per thread
+  constexpr int NX1 = TX * EY, S1 = (NX1 + 255) / 256;     // axis-1 outputs per thread
+  constexpr int S2 = TX * TY / 256;                        // axis-2 outputs per thread
+  __shared__ float A[EX][EY + 1];
+  __shared__ float B[TX][EY + 1];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.y * TX, y0 = blockIdx.x * TY;
+  const int z_begin = blockIdx.z * zseg;
+  const int z_end = z_begin + zseg < Z ? z_begin + zseg : Z;
+  const size_t plane = (size_t)X * Y;
+  // in-plane offsets of this thread's halo positions (border-mapped: mx/my[i] = source index of position i - R)
+  int off[SL];
+#pragma unroll
+  for (int k = 0; k < SL; ++k) {
+    const int pos = tid + 256 * k;
+    const int xx = pos / EY, yy = pos - xx * EY;
+    off[k] = pos < NPOS ? mx[x0 + xx] * Y + my[y0 + yy] : 0;
+  }
+  T win[SL][W];   // raw planes z-R .. z+R of every owned position
+#pragma unroll
+  for (int j = 0; j < W - 1; ++j) {
+    const size_t pz = (size_t)mz[z_begin + j] * plane;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) win[k][j] = in[pz + off[k]];
+  }
+  for (int z = z_begin; z < z_end; ++z) {
+    {
+      const size_t pz = (size_t)mz[z + W - 1] * plane;
+#pragma unroll
+      for (int k = 0; k < SL; ++k) win[k][W - 1] = in[pz + off[k]];
+    }
+    // axis 0 on the halo tile
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int pos = tid + 256 * k;
+      if (pos < NPOS) {
+        double acc = (double)win[k][R] * taps.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) acc = acc + ((double)win[k][R - j] + (double)win[k][R + j]) * taps.w[j];
+        const int xx = pos / EY, yy = pos - xx * EY;
+        A[xx][yy] = (float)cvt<T>(acc);
+      }
+#pragma unroll
+      for (int j = 0; j < W - 1; ++j) win[k][j] = win[k][j + 1];
+    }
+    __syncthreads();
+    // axis 1: outputs (x, yy) for x in [0,TX), yy in [0,EY)
+#pragma unroll
+    for (int k = 0; k < S1; ++k) {
+      const int o = tid + 256 * k;
+      if (o < NX1) {
+        const int x = o / EY, yy = o - x * EY;
+        double acc = (double)A[x + R][yy] * taps.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) acc = acc + ((double)A[x + R - j][yy] + (double)A[x + R + j][yy]) * taps.w[j];
+        B[x][yy] = (float)cvt<T>(acc);
+      }
+    }
+    __syncthreads();
+    // axis 2: outputs (x, y), lanes along y
+    T* po = out + (size_t)z * plane;
+#pragma unroll
+    for (int k = 0; k < S2; ++k) {
+      const int o = tid + 256 * k;
+      const int x = o / TY, y = o - x * TY;
+      double acc = (double)B[x][y + R] * taps.w[0];
+#pragma unroll
+      for (int j = R; j >= 1; --j) acc = acc + ((double)B[x][y + R - j] + (double)B[x][y + R + j]) * taps.w[j];
+      if (x0 + x < X && y0 + y < Y) po[(size_t)(x0 + x) * Y + (y0 + y)] = cvt<T>(acc);
+    }
+    // the next plane's A is written only after every thread has passed the barrier above (A is dead after axis 1),
+    // B only after the next plane's first barrier: no third barrier needed
+  }
+}
+
 template <class T, int R, int KS, int KC>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
+  if constexpr (R <= 6) {
+    // maps must cover the halo of the last (partial) tile: positions up to ceil(len/tile)*tile + 2R
+    static const std::string nf = "gauss_fused3_R" + std::to_string(R);
+    ia3rt::ProfScope ps(nf.c_str());
+    const int fz = Z + 2 * R + 1, fx = ((X + 31) / 32) * 32 + 2 * R, fy = ((Y + 63) / 64) * 64 + 2 * R;
+    ia3rt::Scratch fm((size_t)(fz + fx + fy) * sizeof(int));
+    if (!fm.p) return IA3_ENOMEM;
+    int* qz = fm.as<int>();
+    int* qx = qz + fz;
+    int* qy = qx + fx;
+    hipLaunchKernelGGL(border_map_k, dim3((fz + 255) / 256), dim3(256), 0, s, qz, fz, R, Z, mode);
+    hipLaunchKernelGGL(border_map_k, dim3((fx + 255) / 256), dim3(256), 0, s, qx, fx, R, X, mode);
+    hipLaunchKernelGGL(border_map_k, dim3((fy + 255) / 256), dim3(256), 0, s, qy, fy, R, Y, mode);
+    const unsigned bx = (unsigned)((Y + 63) / 64), by = (unsigned)((X + 31) / 32);
+    // split z when the (x, y) tiling alone cannot fill the chip (each z chunk re-reads 2R halo planes)
+    int zseg = Z;
+    while ((long long)bx * by * ((Z + zseg - 1) / zseg) < 1024 && zseg / 2 >= 4 * R) zseg = (zseg + 1) / 2;
+    dim3 g(bx, by, (unsigned)((Z + zseg - 1) / zseg));
+    hipLaunchKernelGGL((gauss3_fused<T, R>), g, dim3(256), 0, s, src, dst, Z, X, Y, t, (const int*)qz, (const int*)qx,
+                       (const int*)qy, zseg);
+    (void)tmp;
+    return 0;
+  }
   // border maps for the three axes: positions -R .. len + R + 2K (sliding-window prefetch overshoots by < 2K)
   const int cz = Z + 2 * R + 3 * KS, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * 9;
   ia3rt::Scratch maps((size_t)(cz + cx + cy) * sizeof(int));
@@ -270,6 +361,24 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
     hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg);
   }
+  if constexpr (R >= 16) {
+    // long filters are f64-VALU-bound: give the contiguous axis the register-window kernel too, by transposing
+    // each plane on the way out of the axis-1 pass and again on the way out of the axis-2 pass
+    {  // axis 1: dst -> tmp, written transposed per plane: tmp[z][y][x]
+      ia3rt::ProfScope ps(nx.c_str());
+      const int seg = seg_for(X, (long long)Y * Z);
+      dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg);
+    }
+    {  // axis 2: tmp[z][y][x] -> dst[z][x][y]: lanes along x, filter along y with stride X, transposed store
+      ia3rt::ProfScope ps(ny.c_str());
+      const int seg = seg_for(Y, (long long)X * Z);
+      dim3 g((unsigned)((X + 255) / 256), (unsigned)Z, (unsigned)((Y + seg - 1) / seg));
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)tmp, dst, X, (size_t)X, Y, plane, t, (const int*)my, seg);
+    }
+    return 0;
+  }
+  // short filters are HBM-bound: keep every store row-coalesced
   // axis 1: dst -> tmp
   {
     ia3rt::ProfScope ps(nx.c_str());
@@ -282,11 +391,6 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     ia3rt::ProfScope ps(ny.c_str());
     const size_t rows = (size_t)Z * X;
     constexpr int KY = KC;
-    if constexpr (R >= 16) {   // long filters: LDS-staged row variant (K = 9 outputs per thread)
-      dim3 g((unsigned)((Y + 256 * 9 - 1) / (256 * 9)), (unsigned)rows, 1);
-      hipLaunchKernelGGL((gauss_contig_row<T, R, 9>), g, dim3(256), 0, s, (const T*)tmp, dst, Y, t, (const int*)my);
-      return 0;
-    }
     int seg = ((Y + 31) / 32) * 32;
     const int min_seg = ((8 * R + 31) / 32) * 32;
     while ((long long)((rows + 63) / 64) * ((Y + seg - 1) / seg) < 256LL * 24 && seg / 2 >= min_seg) seg = ((seg / 2 + 31) / 32) * 32;
