@@ -51,19 +51,22 @@ __global__ void border_map_k(int* bmap, int count, int R, int len, int mode) {
 // A thread walks one segment [blockIdx.z*seg, +seg) of its line in chunks of K outputs with a sliding register
 // window: after a chunk the window shifts by K (2R register moves) and only K new inputs are loaded, so every
 // input is read once per segment instead of (K+2R)/K times.
-// TR: the output is written TRANSPOSED inside each outer slab, out[outer][p][q] instead of out[outer][q][p] (every
-// lane stores its K consecutive outputs as one contiguous K*sizeof(T) piece).  Two transposing passes in a row
-// (axis 1, then axis 2 run as a strided pass over the transposed slab) give the contiguous axis the same
-// register-window kernel as the other two.
-template <class T, int K> struct OutVec { T v[K]; } __attribute__((packed, aligned(4)));
-
+// TR: the output is written TRANSPOSED inside each outer slab, out[outer][p][q] instead of out[outer][q][p].  Each
+// wave parks four chunks (32 consecutive q of its 64 lines) in a private 64 x 32 LDS tile and writes it out as
+// 128-B row pieces, two rows per store instruction, so the transposed store stays coalesced.  Two transposing
+// passes in a row (axis 1, then axis 2 run as a strided pass over the transposed slab) give the contiguous axis
+// the same register-window kernel as the other two.
 template <class T, int R, int K, bool TR = false>
 __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T* __restrict__ out,
                                                      int inner, size_t stride, int len,
                                                      size_t outer_stride, Taps taps,
                                                      const int* __restrict__ bmap, int seg) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= inner) return;
+  constexpr int TQ = 32;                       // q extent of the transposing tile
+  static_assert(!TR || TQ % K == 0, "tile must hold whole chunks");
+  __shared__ float tile[TR ? 4 : 1][TR ? 64 : 1][TR ? TQ + 1 : 1];
+  const int p_raw = blockIdx.x * 256 + threadIdx.x;
+  if (!TR && p_raw >= inner) return;
+  const int p = p_raw < inner ? p_raw : inner - 1;   // TR: lanes past the end load a valid line and store nothing
   const size_t base = (size_t)blockIdx.y * outer_stride + p;
   const int q_begin = blockIdx.z * seg;
   const int q_end = q_begin + seg < len ? q_begin + seg : len;
@@ -85,16 +88,23 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
       for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
     }
     if constexpr (TR) {
-      T* o = out + (size_t)blockIdx.y * outer_stride + (size_t)p * len + q0;
-      if (q0 + K <= q_end) {
-        OutVec<T, K> v;
+      const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const int cq = ((q0 - q_begin) / K) % (TQ / K);     // chunk slot inside the tile (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < K; ++k) v.v[k] = cvt<T>(acc[k]);
-        *reinterpret_cast<OutVec<T, K>*>(o) = v;
-      } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (q0 + k < q_end) o[k] = cvt<T>(acc[k]);
+      for (int k = 0; k < K; ++k) tile[wv][ln][cq * K + k] = (float)cvt<T>(acc[k]);   // exact in a float
+      if (cq == TQ / K - 1 || q0 + K >= q_end) {
+        __builtin_amdgcn_wave_barrier();
+        const int qt0 = q0 - cq * K;
+        const int nq = q_end - qt0 < TQ ? q_end - qt0 : TQ;
+        const int col = ln & 31, hrow = ln >> 5;
+        const int pw = blockIdx.x * 256 + wv * 64;
+        T* o = out + (size_t)blockIdx.y * outer_stride + qt0 + col;
+#pragma unroll 8
+        for (int r2 = 0; r2 < 32; ++r2) {
+          const int row = 2 * r2 + hrow;
+          if (col < nq && pw + row < inner) o[(size_t)(pw + row) * len] = (T)tile[wv][row][col];
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     } else {
 #pragma unroll
