@@ -133,15 +133,30 @@ def align_image(
     Returns (drift (3,) float64, flag): drift = ref - src (add to source coordinates); flag 1 = the
     crops disagreed and the mean of the three mutually closest drifts is returned.
 
-    ndarray inputs only: loading .dax files (``correct_fov_image``) is the caller's job."""
+    ``src_im`` / ``ref_im``: ndarrays, or .dax filenames which are corrected through
+    ``io_tools.load.correct_fov_image`` with ``correction_args`` (pass the illumination profile there)."""
     from ..spot_tools.fitting import fit_fov_image, select_sparse_centers
     _correction_args = {_k: _v for _k, _v in _default_align_corr_args.items()}
     _correction_args.update(correction_args)
     _fitting_args = {_k: _v for _k, _v in _default_align_fitting_args.items()}
     _fitting_args.update(fitting_args)
+    _all_channels0 = [str(_ch) for _ch in all_channels]
+    _ref_all_channels0 = _all_channels0 if ref_all_channels is None else [str(_ch) for _ch in ref_all_channels]
+
+    def _load(_f, _chs):                                                     # :577-607
+        import os
+        from ..io_tools.load import correct_fov_image
+        if not os.path.isfile(_f) or _f.split('.')[-1] != 'dax':
+            raise IOError(f"input image: {_f} should be a .dax file!")
+        return correct_fov_image(_f, [str(drift_channel)], all_channels=_chs, calculate_drift=False,
+                                 return_drift=False, verbose=detailed_verbose,
+                                 **{_k: _v for _k, _v in _correction_args.items() if _k != 'correction_folder'})[0][0]
+    if isinstance(src_im, str):
+        src_im = _load(src_im, _all_channels0)
+    if isinstance(ref_im, str):
+        ref_im = _load(ref_im, _ref_all_channels0)
     if not isinstance(src_im, np.ndarray) or not isinstance(ref_im, np.ndarray):
-        raise IOError(f"Wrong input file type, {type(src_im)} / {type(ref_im)} should be np.ndarray "
-                      "(.dax loading is outside the accelerated path)")
+        raise IOError(f"Wrong input file type, {type(src_im)} / {type(ref_im)} should be .dax file or np.ndarray")
     if np.shape(src_im) != np.shape(ref_im):
         raise IndexError(f"shape of target image:{np.shape(src_im)} and reference image:{np.shape(ref_im)} doesnt match!")
     if crop_list is None:

@@ -267,4 +267,73 @@ int ia3_bleedthrough_correct(const void* const* ims_u16, int C, int Z, int X, in
   return IA3_OK;
 }
 
+
+// ---- device-resident variants (the chain of io_tools/load.py:323-384 on stacks that stay in HBM) ---------------
+// profiles are device buffers made by ia3_buffer_upload (constant over a run: uploaded once)
+
+int ia3_z_shift_correction_dev(const ia3_stack* im, ia3_stack* out_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !out_u16) return set_error(IA3_EINVAL, "null stack");
+  if (out_u16->dtype != IA3_U16 || out_u16->Z != im->Z || out_u16->X != im->X || out_u16->Y != im->Y)
+    return set_error(IA3_EINVAL, "output must be a uint16 stack of the input's shape");
+  hipStream_t st = stream();
+  const int Z = im->Z;
+  const size_t plane = (size_t)im->X * im->Y;
+  Scratch dmed((size_t)(Z + 1) * sizeof(float));
+  if (!dmed.p) return IA3_ENOMEM;
+  rc = ia3k::stack_medians(im, dmed.as<float>()); if (rc) return rc;
+  unsigned gx = (unsigned)((plane + 256 * 16 - 1) / (256 * 16));
+  if (gx < 1) gx = 1;
+  {
+    ProfScope ps("zshift_apply");
+    if (im->dtype == IA3_F32) hipLaunchKernelGGL((zshift_apply_k<float>), dim3(gx, Z), dim3(256), 0, st, (const float*)im->d, Z, plane, (const float*)dmed.p, (uint16_t*)out_u16->d);
+    else hipLaunchKernelGGL((zshift_apply_k<uint16_t>), dim3(gx, Z), dim3(256), 0, st, (const uint16_t*)im->d, Z, plane, (const float*)dmed.p, (uint16_t*)out_u16->d);
+  }
+  IA3_KCHECK();
+  IA3_HIP(hipStreamSynchronize(st));   // dmed returns to the pool
+  return IA3_OK;
+}
+
+int ia3_illumination_correct_dev(const ia3_stack* im_u16, const void* profile_dev, int prof_dtype, ia3_stack* out_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im_u16 || !profile_dev || !out_u16) return set_error(IA3_EINVAL, "null argument");
+  if (im_u16->dtype != IA3_U16 || out_u16->dtype != IA3_U16) return set_error(IA3_EINVAL, "uint16 stacks expected");
+  if (out_u16->Z != im_u16->Z || out_u16->X != im_u16->X || out_u16->Y != im_u16->Y) return set_error(IA3_EINVAL, "shape mismatch");
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  const size_t plane = (size_t)im_u16->X * im_u16->Y;
+  unsigned gx = (unsigned)((plane + 255) / 256);
+  ProfScope ps("illumination");
+  if (prof_dtype == 1) hipLaunchKernelGGL((illum_k<float>), dim3(gx), dim3(256), 0, stream(), (const uint16_t*)im_u16->d, im_u16->Z, plane, (const float*)profile_dev, (uint16_t*)out_u16->d);
+  else hipLaunchKernelGGL((illum_k<double>), dim3(gx), dim3(256), 0, stream(), (const uint16_t*)im_u16->d, im_u16->Z, plane, (const double*)profile_dev, (uint16_t*)out_u16->d);
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+int ia3_bleedthrough_correct_dev(ia3_stack* const* ims_u16, int C, const void* profile_dev, int prof_dtype,
+                                 ia3_stack* const* outs_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!ims_u16 || !profile_dev || !outs_u16) return set_error(IA3_EINVAL, "null argument");
+  if (C < 1 || C > MAXC) return set_error(IA3_EUNSUPPORTED, "1..%d channels supported, got %d", MAXC, C);
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  ChanPtrs ch;
+  for (int j = 0; j < C; ++j) {
+    if (!ims_u16[j] || !outs_u16[j]) return set_error(IA3_EINVAL, "null channel");
+    if (ims_u16[j]->dtype != IA3_U16 || outs_u16[j]->dtype != IA3_U16) return set_error(IA3_EINVAL, "uint16 stacks expected");
+    if (ims_u16[j]->Z != ims_u16[0]->Z || ims_u16[j]->X != ims_u16[0]->X || ims_u16[j]->Y != ims_u16[0]->Y ||
+        outs_u16[j]->Z != ims_u16[0]->Z || outs_u16[j]->X != ims_u16[0]->X || outs_u16[j]->Y != ims_u16[0]->Y)
+      return set_error(IA3_EINVAL, "shape mismatch");
+    for (int k = 0; k < C; ++k)
+      if (outs_u16[j]->d == ims_u16[k]->d) return set_error(IA3_EINVAL, "outputs must not alias inputs (every output mixes all inputs)");
+    ch.in[j] = (const uint16_t*)ims_u16[j]->d;
+    ch.out[j] = (uint16_t*)outs_u16[j]->d;
+  }
+  const size_t plane = (size_t)ims_u16[0]->X * ims_u16[0]->Y;
+  unsigned gx = (unsigned)((plane + 255) / 256);
+  ProfScope ps("bleedthrough");
+  if (prof_dtype == 1) hipLaunchKernelGGL((bleed_k<float>), dim3(gx), dim3(256), 0, stream(), ch, C, ims_u16[0]->Z, plane, (const float*)profile_dev);
+  else hipLaunchKernelGGL((bleed_k<double>), dim3(gx), dim3(256), 0, stream(), ch, C, ims_u16[0]->Z, plane, (const double*)profile_dev);
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
 }  // extern "C"

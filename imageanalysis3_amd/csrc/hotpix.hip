@@ -10,6 +10,8 @@
 // sequential dependence between adjacent hot columns without any synchronisation.
 #include "ia3_rt.h"
 #include <algorithm>
+#include <math.h>
+#include <vector>
 
 namespace {
 
@@ -67,23 +69,70 @@ __global__ void hot_fix_k(T* __restrict__ im, int Z, int X, int Y, const int* __
 
 using namespace ia3rt;
 
-extern "C" int ia3_remove_hot_pixels(const void* im, int dtype, int Z, int X, int Y, double hot_pix_th,
-                                     double hot_th, void* out, int* n_hot) {
-  ia3_stack* s = nullptr;
-  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
+namespace {
+
+// uint16 storage, float32 arithmetic: the chain of io_tools/load.py:323-334 calls
+// corrections.Remove_Hot_Pixels(im.astype(np.float32), dtype=np.uint16, ...): votes and replacement means are float32,
+// later candidates see the UNROUNDED float32 replacements of earlier ones, and the cast to uint16 (truncation)
+// happens once at the end.  idx_of[x*Y+y] = candidate rank of an interior hot column (else -1); repl[k*Z+z] keeps
+// the float32 replacement of candidate k in plane z.
+__global__ __launch_bounds__(256) void hot_vote_u16f_k(const uint16_t* __restrict__ im, int Z, int X, int Y, double hot_th,
+                                                       int* __restrict__ votes) {
+  const int y = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int x = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= X || y >= Y) return;
+  const int xm = x == 0 ? X - 1 : x - 1, xp = x == X - 1 ? 0 : x + 1, ym = y == 0 ? Y - 1 : y - 1;
+  int cnt = 0;
+  for (int z = 0; z < Z; ++z) {
+    const uint16_t* pl = im + (size_t)z * X * Y;
+    cnt += Arith<float>::hot((float)pl[(size_t)x * Y + y], (float)pl[(size_t)xm * Y + y], (float)pl[(size_t)xp * Y + y],
+                             (float)pl[(size_t)x * Y + ym], hot_th);
+  }
+  votes[(size_t)x * Y + y] = cnt;
+}
+
+__global__ void hot_mark_k(int* __restrict__ idx_of, const int* __restrict__ cand, int n, int Y) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) idx_of[(size_t)cand[2 * k] * Y + cand[2 * k + 1]] = k;
+}
+
+__global__ void hot_fix_u16f_k(uint16_t* __restrict__ im, int Z, int X, int Y, const int* __restrict__ cand, int n,
+                               const int* __restrict__ idx_of, float* __restrict__ repl) {
+  const int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= Z) return;
+  uint16_t* pl = im + (size_t)z * X * Y;
+  auto val = [&](int x, int y, int k) -> float {
+    const int j = idx_of[(size_t)x * Y + y];
+    return (j >= 0 && j < k) ? repl[(size_t)j * Z + z] : (float)pl[(size_t)x * Y + y];
+  };
+  for (int k = 0; k < n; ++k) {
+    const int x = cand[2 * k], y = cand[2 * k + 1];
+    repl[(size_t)k * Z + z] = Arith<float>::mean4(val(x + 1, y, k), val(x - 1, y, k), val(x, y + 1, k), val(x, y - 1, k));
+  }
+  for (int k = 0; k < n; ++k) {   // _nim.astype(np.uint16)
+    const float v = repl[(size_t)k * Z + z];
+    pl[(size_t)cand[2 * k] * Y + cand[2 * k + 1]] = (fabsf(v) < 2147483648.f) ? (uint16_t)(int)v : (uint16_t)0;
+  }
+}
+
+int hot_pixels_inplace(ia3_stack* s, double hot_pix_th, double hot_th, int float_arith, int* n_hot) {
   hipStream_t st = stream();
+  const int dtype = s->dtype, Z = s->Z, X = s->X, Y = s->Y;
   const size_t plane = (size_t)X * Y;
+  if (float_arith && dtype != IA3_U16) float_arith = 0;   // a float32 stack already computes in float32
   std::vector<int> votes(plane);
+  Scratch dv(plane * sizeof(int));
+  if (!dv.p) return IA3_ENOMEM;
   {
-    Scratch dv(plane * sizeof(int));
-    if (!dv.p) { ia3_stack_free(s); return IA3_ENOMEM; }
+    ProfScope ps("hot_vote");
     dim3 g((unsigned)((Y + 63) / 64), (unsigned)((X + 3) / 4));
     if (dtype == IA3_F32) hipLaunchKernelGGL((hot_vote_k<float>), g, dim3(256), 0, st, (const float*)s->d, Z, X, Y, hot_th, dv.as<int>());
+    else if (float_arith) hipLaunchKernelGGL(hot_vote_u16f_k, g, dim3(256), 0, st, (const uint16_t*)s->d, Z, X, Y, hot_th, dv.as<int>());
     else hipLaunchKernelGGL((hot_vote_k<uint16_t>), g, dim3(256), 0, st, (const uint16_t*)s->d, Z, X, Y, hot_th, dv.as<int>());
-    hipError_t e = hipMemcpyAsync(votes.data(), dv.p, plane * sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { ia3_stack_free(s); return set_error(IA3_EHIP, "hot pixel vote failed: %s", hipGetErrorString(e)); }
   }
+  hipError_t e = hipMemcpyAsync(votes.data(), dv.p, plane * sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel vote failed: %s", hipGetErrorString(e));
   std::vector<int> cand;  // np.where order: x ascending, then y
   int total = 0;
   const double th = hot_pix_th * (double)Z;
@@ -94,17 +143,46 @@ extern "C" int ia3_remove_hot_pixels(const void* im, int dtype, int Z, int X, in
         if (x > 0 && y > 0 && x < X - 1 && y < Y - 1) { cand.push_back(x); cand.push_back(y); }
       }
   if (n_hot) *n_hot = total;
-  if (!cand.empty()) {
-    Scratch dc(cand.size() * sizeof(int));
-    if (!dc.p) { ia3_stack_free(s); return IA3_ENOMEM; }
-    hipError_t e = hipMemcpyAsync(dc.p, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, st);
-    int n = (int)(cand.size() / 2);
-    if (dtype == IA3_F32) hipLaunchKernelGGL((hot_fix_k<float>), dim3((Z + 63) / 64), dim3(64), 0, st, (float*)s->d, Z, X, Y, dc.as<int>(), n);
-    else hipLaunchKernelGGL((hot_fix_k<uint16_t>), dim3((Z + 63) / 64), dim3(64), 0, st, (uint16_t*)s->d, Z, X, Y, dc.as<int>(), n);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { ia3_stack_free(s); return set_error(IA3_EHIP, "hot pixel fix failed: %s", hipGetErrorString(e)); }
+  if (cand.empty()) return IA3_OK;
+  const int n = (int)(cand.size() / 2);
+  Scratch dc(cand.size() * sizeof(int));
+  if (!dc.p) return IA3_ENOMEM;
+  e = hipMemcpyAsync(dc.p, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel list upload failed: %s", hipGetErrorString(e));
+  ProfScope ps("hot_fix");
+  if (dtype == IA3_F32) {
+    hipLaunchKernelGGL((hot_fix_k<float>), dim3((Z + 63) / 64), dim3(64), 0, st, (float*)s->d, Z, X, Y, dc.as<int>(), n);
+  } else if (!float_arith) {
+    hipLaunchKernelGGL((hot_fix_k<uint16_t>), dim3((Z + 63) / 64), dim3(64), 0, st, (uint16_t*)s->d, Z, X, Y, dc.as<int>(), n);
+  } else {
+    Scratch dr((size_t)n * Z * sizeof(float));
+    if (!dr.p) return IA3_ENOMEM;
+    e = hipMemsetAsync(dv.p, 0xFF, plane * sizeof(int), st);   // -1 everywhere
+    if (e != hipSuccess) return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(hot_mark_k, dim3((n + 255) / 256), dim3(256), 0, st, dv.as<int>(), dc.as<int>(), n, Y);
+    hipLaunchKernelGGL(hot_fix_u16f_k, dim3((Z + 63) / 64), dim3(64), 0, st, (uint16_t*)s->d, Z, X, Y, dc.as<int>(), n,
+                       (const int*)dv.p, dr.as<float>());
+    e = hipStreamSynchronize(st);   // dr/dv go back to the pool after this scope
+    if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel fix failed: %s", hipGetErrorString(e));
   }
-  rc = ia3_stack_download(s, out);
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+}  // namespace
+
+extern "C" int ia3_remove_hot_pixels_dev(ia3_stack* im, double hot_pix_th, double hot_th, int float_arith, int* n_hot) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im) return set_error(IA3_EINVAL, "null stack");
+  return hot_pixels_inplace(im, hot_pix_th, hot_th, float_arith, n_hot);
+}
+
+extern "C" int ia3_remove_hot_pixels(const void* im, int dtype, int Z, int X, int Y, double hot_pix_th,
+                                     double hot_th, void* out, int* n_hot) {
+  ia3_stack* s = nullptr;
+  int rc = ia3_stack_upload(im, dtype, Z, X, Y, &s); if (rc) return rc;
+  rc = hot_pixels_inplace(s, hot_pix_th, hot_th, 0, n_hot);
+  if (rc == IA3_OK) rc = ia3_stack_download(s, out);
   ia3_stack_free(s);
   return rc;
 }

@@ -215,6 +215,37 @@ int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack
   }
   return IA3_OK;
 }
+// io_tools/load.py:524-550 split_im_by_channels on a resident raw movie: frames start, start+step, ... (Z of them)
+int ia3_stack_deinterleave(const ia3_stack* raw, int start, int step, int Z, ia3_stack** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!raw || !out) return set_error(IA3_EINVAL, "null argument");
+  if (start < 0 || step < 1 || Z < 1 || (long long)start + (long long)(Z - 1) * step >= raw->Z)
+    return set_error(IA3_EINVAL, "frames %d + k*%d (k < %d) fall outside a movie of %d frames", start, step, Z, raw->Z);
+  rc = ia3_stack_alloc(raw->dtype, Z, raw->X, raw->Y, out); if (rc) return rc;
+  const size_t pb = (size_t)raw->X * raw->Y * esize(raw->dtype);
+  hipError_t e = hipMemcpy2DAsync((*out)->d, pb, (const char*)raw->d + (size_t)start * pb, pb * step, pb, Z,
+                                  hipMemcpyDeviceToDevice, g_stream);
+  if (e != hipSuccess) {
+    ia3_stack_free(*out); *out = nullptr;
+    return set_error(IA3_EHIP, "frame gather failed: %s", hipGetErrorString(e));
+  }
+  return IA3_OK;
+}
+// plain device buffers for data that stays constant over a run (illumination / bleedthrough / chromatic profiles)
+int ia3_buffer_upload(const void* host, size_t bytes, void** devptr) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!host || !devptr || bytes == 0) return set_error(IA3_EINVAL, "bad buffer arguments");
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, g_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+  if (e != hipSuccess) { (void)hipFree(d); return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); }
+  *devptr = d;
+  return IA3_OK;
+}
+void ia3_buffer_free(void* devptr) {
+  if (devptr && g_pid == getpid()) { (void)hipStreamSynchronize(g_stream); (void)hipFree(devptr); }
+}
 int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out) {
   int rc = ensure_init(); if (rc) return rc;
   rc = check_shape(dtype, Z, X, Y); if (rc) return rc;

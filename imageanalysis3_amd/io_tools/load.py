@@ -90,3 +90,332 @@ def find_local_backgrounds(stack, centers_zxy, crop_size, dtype=_image_dtype, bi
     L.check(L.lib().ia3_local_background_dev(stack._h, L.ptr(c), len(c), int(crop_size), L.dptr(edges), len(edges),
                                              int(max_iter), L.dptr(out)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# correct_fov_image (io_tools/load.py:166-522): the whole per-image chain on stacks that stay in HBM
+# ---------------------------------------------------------------------------------------------------------------
+
+def read_dax(dax_filename):
+    """The raw movie of a .dax/.inf pair as a (frames, width, height) uint16 array — what the reference's
+    ``DaxReader(dax_filename).loadAll()`` returns (visual_tools.py:974-1083; host file I/O only)."""
+    import os
+    import re
+    inf = os.path.splitext(dax_filename)[0] + ".inf"
+    h = w = n = None
+    big = False
+    with open(inf, "r") as f:
+        for line in f:
+            m = re.match(r'frame dimensions = ([\d]+) x ([\d]+)', line)
+            if m:
+                h, w = int(m.group(1)), int(m.group(2))
+            m = re.match(r'number of frames = ([\d]+)', line)
+            if m:
+                n = int(m.group(1))
+            m = re.search(r' (big|little) endian', line)
+            if m:
+                big = m.group(1) == "big"
+    if not h:
+        h = w = 256
+    data = np.fromfile(dax_filename, dtype='>u2' if big else '<u2')
+    if n is None:
+        n = data.size // (h * w)
+    return np.ascontiguousarray(data[:n * h * w].reshape(n, w, h).astype(np.uint16, copy=False))
+
+
+def get_num_frame(dax_filename, frame_per_color=None, buffer_frame=10, empty_frame=0, verbose=False):
+    """io_tools/load.py:17-45 — ([frames, dx, dy], number of colours) from the .inf file."""
+    import os
+    from .. import _image_size
+    if frame_per_color is None:
+        frame_per_color = _image_size[0]
+    if '.dax' not in dax_filename:
+        raise ValueError(f"Wrong input type, .dax file expected for {dax_filename}")
+    if not os.path.isfile(dax_filename):
+        raise IOError(f"input file:{dax_filename} doesn't exist!")
+    _num_frame, _num_color, _dx, _dy = 0, 0, 0, 0
+    with open(dax_filename.replace('.dax', '.inf'), 'r') as _info_hd:
+        for _line in _info_hd.readlines():
+            _line = _line.rstrip()
+            if "number of frames" in _line:
+                _num_frame = int(_line.split('=')[1])
+                _num_color = (_num_frame - 2 * buffer_frame - empty_frame) / frame_per_color
+                if _num_color != int(_num_color):
+                    raise ValueError("Wrong num_color, should be integer!")
+                _num_color = int(_num_color)
+            if "frame dimensions" in _line:
+                _dx = int(_line.split('=')[1].split('x')[0])
+                _dy = int(_line.split('=')[1].split('x')[1])
+    return [_num_frame, _dx, _dy], _num_color
+
+
+def _channel_starts(sel_channels, all_channels, num_buffer_frames, num_empty_frames):
+    """First frame of every selected channel (io_tools/load.py:534-540)."""
+    _all = [str(_ch) for _ch in all_channels]
+    _n = len(_all)
+    starts = []
+    for _ch in sel_channels:
+        if str(_ch) not in _all:
+            raise ValueError(f"Wrong input channel:{_ch}, should be within {_all}")
+        _i = _all.index(str(_ch))
+        starts.append(num_empty_frames + num_buffer_frames + (_i - num_empty_frames - num_buffer_frames) % _n)
+    return starts
+
+
+def split_im_by_channels(im, sel_channels, all_channels, single_im_size=None,
+                         num_buffer_frames=10, num_empty_frames=0, skip_frame0=False):
+    """io_tools/load.py:524-550.  ``im``: raw movie as ndarray (returns ndarrays) or resident ``DeviceStack``
+    (returns resident stacks gathered on the device)."""
+    from .. import _image_size
+    if single_im_size is None:
+        single_im_size = _image_size
+    if isinstance(sel_channels, (str, int)):
+        sel_channels = [sel_channels]
+    if isinstance(all_channels, (str, int)):
+        all_channels = [all_channels]
+    _n = len(all_channels)
+    starts = _channel_starts(sel_channels, all_channels, num_buffer_frames, num_empty_frames)
+    if skip_frame0:
+        starts = [_s + _n if _s == num_buffer_frames else _s for _s in starts]
+    Z = int(single_im_size[0])
+    if isinstance(im, L.DeviceStack):
+        outs = []
+        for _s in starts:
+            h = C.c_void_p()
+            L.check(L.lib().ia3_stack_deinterleave(im._h, int(_s), int(_n), Z, C.byref(h)))
+            outs.append(L.DeviceStack(h, (Z,) + tuple(im.shape[1:]), im.dtype))
+        return outs
+    return [im[_s:_s + Z * _n:_n].copy() for _s in starts]
+
+
+class DeviceBuffer(object):
+    """A run-constant array (correction profile) resident in HBM."""
+
+    def __init__(self, arr):
+        self.arr = np.ascontiguousarray(arr)
+        self.dtype_code = 1 if self.arr.dtype == np.float32 else 2
+        if self.arr.dtype not in (np.float32, np.float64):
+            self.arr = self.arr.astype(np.float64)
+            self.dtype_code = 2
+        p = C.c_void_p()
+        L.check(L.lib().ia3_buffer_upload(L.ptr(self.arr), C.c_size_t(self.arr.nbytes), C.byref(p)))
+        self.ptr = p
+
+    def free(self):
+        if self.ptr is not None:
+            L.lib().ia3_buffer_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _as_buffer(p):
+    return p if isinstance(p, DeviceBuffer) else DeviceBuffer(p)
+
+
+def correct_fov_image(dax_filename, sel_channels,
+                      load_file_lock=None,
+                      single_im_size=None, all_channels=None,
+                      num_buffer_frames=10, num_empty_frames=0,
+                      drift=None, calculate_drift=False,
+                      drift_channel='488', ref_filename=None,
+                      use_autocorr=True, drift_args={},
+                      corr_channels=None, correction_folder=None,
+                      warp_image=True,
+                      hot_pixel_corr=True, hot_pixel_th=4, z_shift_corr=False,
+                      illumination_corr=True, illumination_profile=None,
+                      bleed_corr=True, bleed_profile=None,
+                      chromatic_ref_channel='647', chromatic_corr=True, chromatic_profile=None,
+                      gaussian_highpass=False, gauss_sigma=3, gauss_truncate=2,
+                      normalization=False, output_dtype=np.uint16,
+                      return_drift=False, verbose=True, return_device=False):
+    """io_tools/load.py:166-522 — correct one field of view: split channels, hot pixels, z-shift, bleedthrough,
+    illumination, (bead drift), warp with drift + chromatic field, (Gaussian high-pass).
+
+    The raw movie is uploaded ONCE as uint16 and every stage runs on resident stacks (hotpix.hip, corrections.hip,
+    warp.hip, gauss.hip); only the selected channels come back (or stay resident with ``return_device=True`` — feed
+    them to ``ia3_fit_fov_dev`` / ``fit_fov_image``).  ``dax_filename`` may also be the raw (frames, X, Y) uint16
+    movie itself.  Profiles must be passed in (ndarray or ``DeviceBuffer``; upload them once per run with
+    ``DeviceBuffer``): reading the reference's pickled profile folder is outside the accelerated path, as are
+    ``warp_image=False`` (coordinate-space chromatic functions) and ``normalization=True``."""
+    import os
+    import time
+    from .. import _image_size, _allowed_colors, _corr_channels
+    single_im_size = _image_size if single_im_size is None else single_im_size
+    all_channels = _allowed_colors if all_channels is None else all_channels
+    corr_channels = _corr_channels if corr_channels is None else corr_channels
+    if isinstance(dax_filename, np.ndarray):
+        _raw_im = dax_filename
+    else:
+        if not os.path.isfile(dax_filename):
+            raise IOError(f"Dax file: {dax_filename} is not a file, exit!")
+        if not isinstance(dax_filename, str) or dax_filename[-4:] != '.dax':
+            raise IOError(f"Dax file: {dax_filename} has wrong data type, exit!")
+        _raw_im = None
+    if verbose:
+        print(f"- correct the whole fov for image: {dax_filename if _raw_im is None else 'array'}")
+        _total_start = time.time()
+    if isinstance(sel_channels, (str, int)):
+        sel_channels = [str(sel_channels)]
+    else:
+        sel_channels = [str(ch) for ch in sel_channels]
+    single_im_size = np.array(single_im_size, dtype=int)
+    all_channels = [str(ch) for ch in all_channels]
+    num_buffer_frames, num_empty_frames = int(num_buffer_frames), int(num_empty_frames)
+    if drift is None:
+        drift = np.zeros(len(single_im_size), dtype=np.float32)
+    else:
+        drift = np.array(drift, dtype=np.float32)
+    if len(drift) != len(single_im_size):
+        raise IndexError("drift should have the same dimension as single_im_size.")
+    corr_channels = [str(ch) for ch in sorted(corr_channels, key=lambda v: -int(v)) if str(ch) in all_channels]
+    _overlap_channels = [_ch for _ch in corr_channels if _ch in sel_channels]
+    _load_channels = [_ch for _ch in corr_channels] if (len(_overlap_channels) > 0 and bleed_corr) else []
+    for _ch in sel_channels:
+        if _ch not in _load_channels:
+            _load_channels.append(_ch)
+    _drift_channel = str(drift_channel)
+    if _drift_channel not in all_channels:
+        raise ValueError(f"Wrong input of drift_channel:{_drift_channel}, should be among {all_channels}")
+    if calculate_drift and _drift_channel not in _load_channels:
+        _load_channels.append(_drift_channel)
+    if not warp_image:
+        raise NotImplementedError("warp_image=False (generate_chromatic_function) is outside the accelerated path")
+    if normalization:
+        raise NotImplementedError("normalization=True is outside the accelerated path")
+    if np.dtype(output_dtype) != np.uint16:
+        raise NotImplementedError("output_dtype other than uint16 is outside the accelerated path")
+    # profiles
+    if illumination_corr:
+        if illumination_profile is None:
+            raise NotImplementedError("pass illumination_profile (loading the correction folder is out of scope)")
+        if not isinstance(illumination_profile, dict):
+            raise TypeError("Wrong input type of illumination_profile, should be dict!")
+        for _ch in _load_channels:
+            if _ch not in illumination_profile:
+                raise KeyError(f"channel:{_ch} not given in illumination_profile")
+    _do_bleed = bleed_corr and len(_overlap_channels) > 0
+    if _do_bleed:
+        if bleed_profile is None:
+            raise NotImplementedError("pass bleed_profile (loading the correction folder is out of scope)")
+        if not isinstance(bleed_profile, DeviceBuffer):
+            bleed_profile = np.array(bleed_profile, dtype=np.float32)
+            _nc = len(corr_channels)
+            if bleed_profile.shape != (_nc, _nc, single_im_size[-2], single_im_size[-1]):
+                raise IndexError(f"Wrong input shape for bleed_profile: {bleed_profile.shape}, should be "
+                                 f"{(_nc, _nc, single_im_size[-2], single_im_size[-1])}")
+    if chromatic_corr and len(_overlap_channels) > 0:
+        if chromatic_profile is None:
+            raise NotImplementedError("pass chromatic_profile (loading the correction folder is out of scope)")
+        if not isinstance(chromatic_profile, dict):
+            raise TypeError("Wrong input type of chromatic_profile, should be dict!")
+        for _ch in _load_channels:
+            if _ch in corr_channels and _ch not in chromatic_profile:
+                raise KeyError(f"channel:{_ch} not given in chromatic_profile")
+    # load + upload once
+    if _raw_im is None:
+        if load_file_lock is not None:
+            load_file_lock.acquire()
+        try:
+            _raw_im = read_dax(dax_filename)
+        finally:
+            if load_file_lock is not None:
+                load_file_lock.release()
+    if _raw_im.dtype != np.uint16 or _raw_im.ndim != 3:
+        raise TypeError("the raw movie should be a (frames, X, Y) uint16 array")
+    _num_color = (_raw_im.shape[0] - 2 * num_buffer_frames - num_empty_frames) / single_im_size[0]
+    if _num_color != int(_num_color):
+        raise ValueError("Wrong num_color, should be integer!")
+    _num_color = int(_num_color)
+    lib = L.lib()
+    _raw = L.DeviceStack.upload(np.ascontiguousarray(_raw_im))
+    _owned = []      # resident stacks to release
+    try:
+        _ims = split_im_by_channels(_raw, _load_channels, all_channels[:_num_color], single_im_size=single_im_size,
+                                    num_buffer_frames=num_buffer_frames, num_empty_frames=num_empty_frames)
+        _owned.extend(_ims)
+        _raw.free()
+        if hot_pixel_corr:                                                   # :323-334
+            for _im in _ims:
+                nh = C.c_int(0)
+                L.check(lib.ia3_remove_hot_pixels_dev(_im._h, C.c_double(0.5), C.c_double(float(hot_pixel_th)), 1,
+                                                      C.byref(nh)))
+        if z_shift_corr:                                                     # :337-345
+            for _im in _ims:
+                L.check(lib.ia3_z_shift_correction_dev(_im._h, _im._h))
+        if _do_bleed:                                                        # :348-370
+            _bp = _as_buffer(bleed_profile)
+            _idx = [_load_channels.index(_ch) for _ch in corr_channels]
+            _outs = [L.DeviceStack.empty(_ims[_i].shape, np.uint16) for _i in _idx]
+            _owned.extend(_outs)
+            arr_in = (C.c_void_p * len(_idx))(*[_ims[_i]._h for _i in _idx])
+            arr_out = (C.c_void_p * len(_idx))(*[_o._h for _o in _outs])
+            L.check(lib.ia3_bleedthrough_correct_dev(arr_in, len(_idx), _bp.ptr, _bp.dtype_code, arr_out))
+            for _i, _o in zip(_idx, _outs):
+                _ims[_i] = _o
+        if illumination_corr:                                                # :373-384
+            for _i, _ch in enumerate(_load_channels):
+                _ip = _as_buffer(illumination_profile[_ch])
+                L.check(lib.ia3_illumination_correct_dev(_ims[_i]._h, _ip.ptr, _ip.dtype_code, _ims[_i]._h))
+        if calculate_drift:                                                  # :387-417
+            from ..correction_tools.alignment import align_image
+            _updated_drift_args = {_k: _v for _k, _v in drift_args.items()}
+            _updated_drift_args.update({'all_channels': all_channels, 'ref_all_channels': all_channels,
+                                        'drift_channel': drift_channel})
+            _drift_corr_args = {'single_im_size': single_im_size, 'num_buffer_frames': num_buffer_frames,
+                                'num_empty_frames': num_empty_frames}
+            if illumination_corr:
+                _drift_corr_args['illumination_profile'] = illumination_profile
+            _drift, _drift_flag = align_image(_ims[_load_channels.index(_drift_channel)].download(), ref_filename,
+                                              use_autocorr=use_autocorr, correction_args=_drift_corr_args,
+                                              verbose=verbose, **_updated_drift_args)
+        else:
+            _drift = drift.copy()
+            _drift_flag = 0
+        _chromatic_channels = [_ch for _ch in corr_channels if _ch in sel_channels and _ch != chromatic_ref_channel]
+        for _ch in sel_channels:                                             # :424-453
+            # the reference's resampling block sits INSIDE its `if verbose:` (:436-453 are indented under the
+            # print of :435), so a silent call returns unwarped images; kept, so outputs match call for call
+            if ((chromatic_corr and _ch in _chromatic_channels) or _drift.any()) and verbose:
+                _i = _load_channels.index(_ch)
+                _field, _fdt = None, 0
+                if chromatic_corr and _ch in _chromatic_channels and chromatic_profile[_ch] is not None:
+                    _fb = _as_buffer(chromatic_profile[_ch])
+                    if _fb.arr.shape != (3,) + tuple(_ims[_i].shape):
+                        raise IndexError(f"chromatic_profile[{_ch}] shape {_fb.arr.shape} should be "
+                                         f"{(3,) + tuple(_ims[_i].shape)}")
+                    _field, _fdt = _fb.ptr, _fb.dtype_code
+                _d = np.ascontiguousarray(_drift if _drift.any() else np.zeros(3), dtype=np.float64)
+                _out = L.DeviceStack.empty(_ims[_i].shape, np.uint16)
+                _owned.append(_out)
+                L.check(lib.ia3_warp3d_dev(_ims[_i]._h, L.dptr(_d), _field, _fdt, 3, L.MODE_NEAREST,
+                                           C.c_double(0.0), _out._h))
+                _ims[_i] = _out
+        if gaussian_highpass:                                                # :489-498 (every loaded channel)
+            w, r = L.gaussian_taps(gauss_sigma, gauss_truncate)
+            for _i, _im in enumerate(_ims):
+                _out = L.DeviceStack.empty(_im.shape, np.uint16)
+                _owned.append(_out)
+                L.check(lib.ia3_gaussian_highpass_dev(_im._h, C.c_double(gauss_sigma), C.c_double(gauss_truncate),
+                                                      L.dptr(w), int(r), _out._h))
+                _ims[_i] = _out
+        _sel = [_ims[_load_channels.index(_ch)] for _ch in sel_channels]
+        if return_device:
+            _sel_ims = _sel
+            _owned = [_o for _o in _owned if not any(_o is _s for _s in _sel)]
+        else:
+            _sel_ims = [_s.download() for _s in _sel]
+    finally:
+        for _o in _owned:
+            _o.free()
+        _raw.free()
+    if verbose:
+        print(f"-- finish correction in {time.time()-_total_start:.3f}s")
+    _return_args = [_sel_ims]
+    if return_drift:
+        _return_args.extend([_drift, _drift_flag])
+    return tuple(_return_args)

@@ -54,6 +54,11 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out);
 int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out);
 int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out); /* borrow device memory */
+/* io_tools/load.py:524-550 split_im_by_channels on a resident raw movie (frames, X, Y): frames start, start+step, .. */
+int ia3_stack_deinterleave(const ia3_stack* raw, int start, int step, int Z, ia3_stack** out);
+/* device buffers for run-constant data (correction profiles) */
+int ia3_buffer_upload(const void* host, size_t bytes, void** devptr);
+void ia3_buffer_free(void* devptr);
 int ia3_stack_download(const ia3_stack* s, void* host);
 int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void** devptr);
 void ia3_stack_free(ia3_stack* s);
@@ -119,6 +124,17 @@ int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_
                  double* out_zxyh, int capacity, int* n_out, double* th_used);
 int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p,
                      double* out_zxyh, int capacity, int* n_out, double* th_used);
+
+/* ---- the pre-correction chain of io_tools/load.py:323-384 on stacks that stay resident ---------------------------
+ * ia3_remove_hot_pixels_dev works in place; float_arith != 0 on a uint16 stack = the chain's
+ * corrections.Remove_Hot_Pixels(im.astype(np.float32), dtype=np.uint16) (float32 votes and means, one truncation at
+ * the end).  Profiles are device buffers from ia3_buffer_upload; prof_dtype 1 = float32, 2 = float64.  Outputs of the
+ * bleedthrough mix must not alias its inputs; the other two may run in place. */
+int ia3_remove_hot_pixels_dev(ia3_stack* im, double hot_pix_th, double hot_th, int float_arith, int* n_hot);
+int ia3_z_shift_correction_dev(const ia3_stack* im, ia3_stack* out_u16);
+int ia3_illumination_correct_dev(const ia3_stack* im_u16, const void* profile_dev, int prof_dtype, ia3_stack* out_u16);
+int ia3_bleedthrough_correct_dev(ia3_stack* const* ims_u16, int C, const void* profile_dev, int prof_dtype,
+                                 ia3_stack* const* outs_u16);
 
 /* ---- background level: io_tools/load.py:642-687 find_image_background -----------------------------------
  * counts = np.histogram(im, bins=edges); highest strict local maximum of the counts (scipy.signal.find_peaks,

@@ -163,6 +163,27 @@ def norm_golden(meta):
     meta["norm_cases"] = NORM_CASES
 
 
+def chain_golden(meta):
+    """io_tools/load.py:166-522 correct_fov_image run by the reference on a synthetic .dax movie."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import conftest as T
+    ref_loader.load_corrections()
+    load, _ = ref_loader.load_io()
+    case = T.build_chain_case()
+    d = {"raw_crc": crc(case["raw"])}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "movie.dax")
+        T.write_dax(path, case["raw"])
+        for name in T.CHAIN_VARIANTS:
+            sel, kw = T.chain_kwargs(case, name)
+            out = quiet(load.correct_fov_image, path, sel, **kw)
+            for ch, im in zip(sel, out[0]):
+                d["%s_%s" % (name, ch)] = im
+    np.savez_compressed(os.path.join(OUT, "chain.npz"), **d)
+    meta["chain_variants"] = list(T.CHAIN_VARIANTS)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -291,6 +312,7 @@ def main():
 
     legacy_golden(meta)
     norm_golden(meta)
+    chain_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -1107,3 +1107,53 @@ def fit_single_image(_im, _id, _chrom_coords, _seeding_args, _fitting_args, _che
             _spots[:, 0] = _spots[:, 0] / _norm_cst
         _spots_for_chrom.append(_spots)
     return _spots_for_chrom
+
+
+# ----------------------------------------------------------------------------------------------
+# (f1) io_tools/load.py:166-522 correct_fov_image on an in-memory raw movie (profiles passed in)
+# ----------------------------------------------------------------------------------------------
+
+
+def correct_fov_image(raw_im, sel_channels, single_im_size, all_channels, num_buffer_frames=10, num_empty_frames=0,
+                      drift=None, drift_channel='488', corr_channels=('750', '647', '561'), hot_pixel_corr=True,
+                      hot_pixel_th=4, z_shift_corr=False, illumination_corr=True, illumination_profile=None,
+                      bleed_corr=True, bleed_profile=None, chromatic_ref_channel='647', chromatic_corr=True,
+                      chromatic_profile=None, gaussian_highpass=False, gauss_sigma=3, gauss_truncate=2,
+                      output_dtype=np.uint16, verbose=True):
+    """The stage order, dtypes and conditions of the reference function (warp_image=True, no drift calculation,
+    no normalisation), composed from the restatements above."""
+    sel_channels = [str(c) for c in ([sel_channels] if isinstance(sel_channels, (str, int)) else sel_channels)]
+    all_channels = [str(c) for c in all_channels]
+    single_im_size = np.array(single_im_size, dtype=int)
+    drift = np.zeros(3, np.float32) if drift is None else np.array(drift, dtype=np.float32)
+    corr_channels = [str(c) for c in sorted(corr_channels, key=lambda v: -int(v)) if str(c) in all_channels]
+    overlap = [c for c in corr_channels if c in sel_channels]
+    load_channels = list(corr_channels) if (overlap and bleed_corr) else []
+    for c in sel_channels:
+        if c not in load_channels:
+            load_channels.append(c)
+    n_col = int((raw_im.shape[0] - 2 * num_buffer_frames - num_empty_frames) / single_im_size[0])
+    chs = all_channels[:n_col]
+    starts = [num_empty_frames + num_buffer_frames + (chs.index(c) - num_empty_frames - num_buffer_frames) % n_col
+              for c in load_channels]                                                       # :534-548
+    ims = [raw_im[s:s + single_im_size[0] * n_col:n_col].copy() for s in starts]
+    if hot_pixel_corr:                                                                      # :323-334
+        ims = [remove_hot_pixels(im.astype(np.float32), dtype=output_dtype, hot_th=hot_pixel_th) for im in ims]
+    if z_shift_corr:                                                                        # :337-345
+        ims = [z_shift_correction(im, dtype=output_dtype) for im in ims]
+    if overlap and bleed_corr:                                                              # :348-370
+        bp = np.array(bleed_profile, dtype=np.float32)
+        outs = bleedthrough_correction([ims[load_channels.index(c)] for c in corr_channels], bp, output_dtype)
+        for c, o in zip(corr_channels, outs):
+            ims[load_channels.index(c)] = o
+    if illumination_corr:                                                                   # :373-384
+        ims = [illumination_correction(im, illumination_profile[c], output_dtype) for im, c in zip(ims, load_channels)]
+    chrom_channels = [c for c in corr_channels if c in sel_channels and c != chromatic_ref_channel]
+    for c in sel_channels:                                                                  # :424-453
+        if ((chromatic_corr and c in chrom_channels) or drift.any()) and verbose:           # (sic: inside `if verbose`)
+            im = ims[load_channels.index(c)]
+            prof = chromatic_profile[c] if (chromatic_corr and c in chrom_channels and chromatic_profile[c] is not None) else None
+            ims[load_channels.index(c)] = warp_3d_image(im, drift, prof, warp_order=3, border_mode="nearest").astype(output_dtype)
+    if gaussian_highpass:                                                                   # :489-498
+        ims = [gaussian_high_pass_filter(im, gauss_sigma, gauss_truncate) for im in ims]
+    return [ims[load_channels.index(c)].astype(output_dtype).copy() for c in sel_channels]

@@ -147,3 +147,20 @@ def load_io():
     cl.preprocess = pre
     ns.io_load, ns.io_crop = load, crop
     return load, crop
+
+
+def load_corrections():
+    """Additionally execute the reference's corrections.py (Remove_Hot_Pixels / Z_Shift_Correction used by
+    io_tools/load.py:323-345) and rebind it where io_tools.load looks it up.  Returns the module."""
+    ns = load_reference()
+    if getattr(ns, "corrections", None) is not None:
+        return ns.corrections
+    import sys
+    load, crop = load_io()
+    ns._root._temp_folder = ""
+    ns._root.io_tools = sys.modules["IA3.io_tools"]
+    cor = ns._load("IA3.corrections", REF + "/corrections.py")
+    ns._root.corrections = cor
+    load.corrections = cor
+    ns.corrections = cor
+    return cor

@@ -83,3 +83,58 @@ def special_background_images():
     d["nan_f32"] = y
     d["sparse"] = (rng.randint(0, 6000, size=(4, 8, 8)) * 10).astype(np.uint16)
     return d
+
+
+def build_chain_case():
+    """Synthetic 4-colour .dax movie + correction profiles for the correct_fov_image chain
+    (mirror of oracle/make_golden.py::chain_golden).  Returns a dict."""
+    from imageanalysis3_amd import synth
+    Z, X, Y = 12, 64, 64
+    chs = ['750', '647', '561', '488']
+    nb = 2
+    ims = [synth.make_fov((Z, X, Y), 6, 30 + i, dtype=np.uint16, margin=(2, 6, 6))[0] for i in range(4)]
+    # hot columns: an isolated one, two adjacent ones (later candidates see earlier replacements), one on the border
+    for (x, y, v) in ((20, 21, 9000), (40, 30, 12000), (40, 31, 11000), (0, 5, 8000)):
+        for im in ims[:3]:
+            im[:, x, y] = v
+    frames = nb + Z * 4 + nb
+    raw = np.zeros((frames, X, Y), np.uint16)
+    for i in range(4):
+        start = nb + (i - nb) % 4
+        raw[start:start + Z * 4:4] = ims[i]
+    rng = np.random.RandomState(0)
+    illum = {c: (0.6 + 0.4 * rng.rand(X, Y)).astype(np.float32) for c in chs}
+    bleed = (np.eye(3)[:, :, None, None] + 0.05 * rng.rand(3, 3, X, Y)).astype(np.float32)
+    chrom = {c: (0.3 * rng.randn(3, Z, X, Y)).astype(np.float32) for c in chs[:3]}
+    chrom['647'] = None
+    return dict(Z=Z, X=X, Y=Y, chs=chs, nb=nb, raw=raw, illum=illum, bleed=bleed, chrom=chrom,
+                drift=[0.3, -1.2, 2.5])
+
+
+def write_dax(path, raw):
+    raw.astype('<u2').tofile(path)
+    with open(path[:-4] + ".inf", "w") as f:
+        f.write("information file for\n%s\nframe dimensions = %d x %d\nnumber of frames = %d\n little endian\n"
+                % (path, raw.shape[2], raw.shape[1], raw.shape[0]))
+
+
+CHAIN_VARIANTS = {
+    "full": dict(z_shift_corr=True, verbose=True),
+    "silent_no_warp": dict(z_shift_corr=False, verbose=False),
+    "highpass": dict(gaussian_highpass=True, verbose=True, bleed_corr=False, chromatic_corr=False),
+    "no_drift_647_only": dict(verbose=True, drift=None, sel=['647']),
+    "no_hot_f64_illum": dict(verbose=True, hot_pixel_corr=False, illum64=True),
+}
+
+
+def chain_kwargs(case, name):
+    v = dict(CHAIN_VARIANTS[name])
+    sel = v.pop("sel", ['750', '647'])
+    illum = case["illum"]
+    if v.pop("illum64", False):
+        illum = {k: a.astype(np.float64) for k, a in illum.items()}
+    kw = dict(single_im_size=[case["Z"], case["X"], case["Y"]], all_channels=case["chs"],
+              num_buffer_frames=case["nb"], num_empty_frames=0, drift=case["drift"], corr_channels=case["chs"][:3],
+              illumination_profile=illum, bleed_profile=case["bleed"], chromatic_profile=case["chrom"])
+    kw.update(v)
+    return sel, kw

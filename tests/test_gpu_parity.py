@@ -578,3 +578,62 @@ def test_local_background_and_normalised_rows_golden(name):
         ref = g[name + key]
         ia, ib = match_rows(rows, ref)
         np.testing.assert_allclose(rows[ia][:, :8], ref[ib][:, :8], rtol=RTOL, atol=1e-4)
+
+
+# ---- (f1) correct_fov_image: the whole pre-correction chain on resident uint16 stacks ----------------------------
+@pytest.mark.parametrize("name", ["full", "silent_no_warp", "highpass", "no_drift_647_only", "no_hot_f64_illum"])
+def test_correct_fov_image_chain_golden_bit_exact(name, tmp_path):
+    from conftest import build_chain_case, chain_kwargs, write_dax
+    from imageanalysis3_amd.io_tools.load import correct_fov_image
+    case = build_chain_case()
+    g = load_golden("chain.npz")
+    sel, kw = chain_kwargs(case, name)
+    path = str(tmp_path / "movie.dax")
+    write_dax(path, case["raw"])
+    out = correct_fov_image(path, sel, **kw)
+    assert isinstance(out, tuple) and len(out) == 1
+    for ch, im in zip(sel, out[0]):
+        ref = g["%s_%s" % (name, ch)]
+        assert im.dtype == np.uint16 and im.shape == ref.shape
+        assert np.array_equal(im, ref), (name, ch, int((im != ref).sum()))
+    # raw movie passed directly, results left resident and fed to the fitter without another upload
+    out2 = correct_fov_image(case["raw"], sel, return_device=True, return_drift=True, **kw)
+    stacks, drift, flag = out2
+    try:
+        assert flag == 0 and np.allclose(drift, kw["drift"] if kw["drift"] is not None else 0)
+        for ch, st in zip(sel, stacks):
+            assert np.array_equal(st.download(), g["%s_%s" % (name, ch)])
+    finally:
+        for st in stacks:
+            st.free()
+
+
+def test_correct_fov_image_argument_errors(tmp_path):
+    from conftest import build_chain_case, chain_kwargs
+    from imageanalysis3_amd.io_tools.load import correct_fov_image, split_im_by_channels, read_dax
+    case = build_chain_case()
+    sel, kw = chain_kwargs(case, "full")
+    with pytest.raises(IOError):
+        correct_fov_image(str(tmp_path / "missing.dax"), sel, **kw)
+    bad = dict(kw); bad["drift_channel"] = '405'
+    with pytest.raises(ValueError):
+        correct_fov_image(case["raw"], sel, **bad)
+    bad = dict(kw); bad["illumination_profile"] = {'750': case["illum"]['750']}
+    with pytest.raises(KeyError):
+        correct_fov_image(case["raw"], sel, **bad)
+    bad = dict(kw); bad["drift"] = [1., 2.]
+    with pytest.raises(IndexError):
+        correct_fov_image(case["raw"], sel, **bad)
+    with pytest.raises(NotImplementedError):
+        correct_fov_image(case["raw"], sel, warp_image=False, **kw)
+    # host split == device split
+    a = split_im_by_channels(case["raw"], ['561', '488'], case["chs"], [case["Z"], case["X"], case["Y"]], case["nb"], 0)
+    from imageanalysis3_amd import _lib as L
+    st = L.DeviceStack.upload(case["raw"])
+    try:
+        b = split_im_by_channels(st, ['561', '488'], case["chs"], [case["Z"], case["X"], case["Y"]], case["nb"], 0)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y.download())
+            y.free()
+    finally:
+        st.free()

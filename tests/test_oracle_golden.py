@@ -209,3 +209,16 @@ def test_fit_fov_image_normalised_oracle_vs_reference_golden(name):
     assert np.array_equal(loc, g[name + "_local"])
     glo = O.fit_fov_image(im, "647", th_seed=600, normalize_background=True)
     assert np.array_equal(glo, g[name + "_global"])
+
+
+# ---- (f1) correct_fov_image chain ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["full", "silent_no_warp", "highpass", "no_drift_647_only", "no_hot_f64_illum"])
+def test_correct_fov_image_chain_oracle_vs_reference_golden(name):
+    from conftest import build_chain_case, chain_kwargs
+    case = build_chain_case()
+    g = load_golden("chain.npz")
+    assert np.uint32(zlib.crc32(case["raw"].tobytes())) == g["raw_crc"]
+    sel, kw = chain_kwargs(case, name)
+    out = O.correct_fov_image(case["raw"], sel, **kw)
+    for ch, im in zip(sel, out):
+        assert im.dtype == np.uint16 and np.array_equal(im, g["%s_%s" % (name, ch)]), (name, ch)
