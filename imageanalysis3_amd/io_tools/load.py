@@ -240,8 +240,9 @@ def correct_fov_image(dax_filename, sel_channels,
     warp.hip, gauss.hip); only the selected channels come back (or stay resident with ``return_device=True`` — feed
     them to ``ia3_fit_fov_dev`` / ``fit_fov_image``).  ``dax_filename`` may also be the raw (frames, X, Y) uint16
     movie itself.  Profiles must be passed in (ndarray or ``DeviceBuffer``; upload them once per run with
-    ``DeviceBuffer``): reading the reference's pickled profile folder is outside the accelerated path, as are
-    ``warp_image=False`` (coordinate-space chromatic functions) and ``normalization=True``."""
+    ``DeviceBuffer``): reading the reference's pickled profile folder is outside the accelerated path, as is
+    ``normalization=True``.  With ``warp_image=False`` the images are left unwarped and one spot-translation
+    function per selected channel is returned (``chromatic_profile[ch]`` is then the constants dict)."""
     import os
     import time
     from .. import _image_size, _allowed_colors, _corr_channels
@@ -283,8 +284,6 @@ def correct_fov_image(dax_filename, sel_channels,
         raise ValueError(f"Wrong input of drift_channel:{_drift_channel}, should be among {all_channels}")
     if calculate_drift and _drift_channel not in _load_channels:
         _load_channels.append(_drift_channel)
-    if not warp_image:
-        raise NotImplementedError("warp_image=False (generate_chromatic_function) is outside the accelerated path")
     if normalization:
         raise NotImplementedError("normalization=True is outside the accelerated path")
     if np.dtype(output_dtype) != np.uint16:
@@ -377,7 +376,18 @@ def correct_fov_image(dax_filename, sel_channels,
             _drift = drift.copy()
             _drift_flag = 0
         _chromatic_channels = [_ch for _ch in corr_channels if _ch in sel_channels and _ch != chromatic_ref_channel]
-        for _ch in sel_channels:                                             # :424-453
+        _warp_functions = []
+        if not warp_image:                                                   # :454-486: translate spots instead
+            from ..correction_tools.chromatic import generate_chromatic_function
+            for _ch in sel_channels:
+                if (chromatic_corr and _ch in _chromatic_channels) or _drift.any():
+                    if chromatic_corr and _ch in _chromatic_channels:
+                        _warp_functions.append(generate_chromatic_function(chromatic_profile[_ch], _drift))
+                    else:
+                        _warp_functions.append(generate_chromatic_function(None, _drift))
+                else:
+                    _warp_functions.append(lambda _spots: _spots)
+        for _ch in (sel_channels if warp_image else []):                     # :424-453
             # the reference's resampling block sits INSIDE its `if verbose:` (:436-453 are indented under the
             # print of :435), so a silent call returns unwarped images; kept, so outputs match call for call
             if ((chromatic_corr and _ch in _chromatic_channels) or _drift.any()) and verbose:
@@ -416,6 +426,8 @@ def correct_fov_image(dax_filename, sel_channels,
     if verbose:
         print(f"-- finish correction in {time.time()-_total_start:.3f}s")
     _return_args = [_sel_ims]
+    if not warp_image:
+        _return_args.append(_warp_functions)
     if return_drift:
         _return_args.extend([_drift, _drift_flag])
     return tuple(_return_args)

@@ -184,6 +184,33 @@ def chain_golden(meta):
     meta["chain_variants"] = list(T.CHAIN_VARIANTS)
 
 
+def chromfn_inputs():
+    rng = np.random.RandomState(12)
+    orders = np.array([1, 2, 2])
+    ncol = {0: 1, 1: 4, 2: 10}
+    consts = [rng.randn(ncol[int(o)]) * (10.0 ** (-2 * np.arange(ncol[int(o)]) / ncol[int(o)] - 1)) for o in orders]
+    info = {'constants': consts, 'fitting_orders': orders, 'ref_center': np.array([15., 1024., 1024.])}
+    coords = rng.rand(40, 3) * np.array([30., 2048., 2048.])
+    spots = rng.rand(25, 11).astype(np.float32) * 100
+    drift = np.array([0.4, -1.7, 2.2], dtype=np.float32)
+    return info, coords, spots, drift
+
+
+def chromfn_golden(meta):
+    """correction_tools/chromatic.py:41-143 generate_chromatic_function on fixed inputs."""
+    ch = ref_loader.load_chromatic()
+    info, coords, spots, drift = chromfn_inputs()
+    d = {}
+    f = ch.generate_chromatic_function(info, drift)
+    d["coords"], d["spots"] = f(coords), f(spots)
+    f0 = ch.generate_chromatic_function(info, None)
+    d["coords_nodrift"] = f0(coords)
+    fd = ch.generate_chromatic_function(None, drift)
+    d["drift_only"] = fd(spots)
+    d["poly2"] = ch.generate_polynomial_data(coords[:7], 2)
+    np.savez_compressed(os.path.join(OUT, "chromfn.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -313,6 +340,7 @@ def main():
     legacy_golden(meta)
     norm_golden(meta)
     chain_golden(meta)
+    chromfn_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -164,3 +164,17 @@ def load_corrections():
     load.corrections = cor
     ns.corrections = cor
     return cor
+
+
+def load_chromatic():
+    """Execute the reference's correction_tools/chromatic.py (generate_chromatic_function)."""
+    ns = load_reference()
+    if getattr(ns, "chromatic", None) is not None:
+        return ns.chromatic
+    import sys
+    load_io()
+    ct = sys.modules["IA3.correction_tools"]
+    ct._drift_channel = '488'
+    ch = ns._load("IA3.correction_tools.chromatic", REF + "/correction_tools/chromatic.py")
+    ns.chromatic = ch
+    return ch

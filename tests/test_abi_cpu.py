@@ -105,3 +105,25 @@ def test_containers():
     b = ImageCrop_3d([[0, 10], [5, 20], [5, 20]], [30, 64, 64])
     assert list(b.inside([[5, 6, 7], [11, 6, 7]])) == [True, False]
     assert np.array_equal(b.translate_drift([0.4, -2.6, 3]).array, [[0, 10], [8, 23], [2, 17]])
+
+
+def test_chromatic_function_matches_reference_golden():
+    """correction_tools/chromatic.py:41-143 (host arithmetic on spot tables) against the reference's own output."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from make_golden import chromfn_inputs
+    from imageanalysis3_amd.correction_tools.chromatic import generate_chromatic_function, generate_polynomial_data
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "chromfn.npz")))
+    info, coords, spots, drift = chromfn_inputs()
+    f = generate_chromatic_function(info, drift)
+    assert np.array_equal(f(coords), g["coords"])
+    out = f(spots)
+    assert out.dtype == g["spots"].dtype and np.array_equal(out, g["spots"])
+    assert np.array_equal(generate_chromatic_function(info, None)(coords), g["coords_nodrift"])
+    assert np.array_equal(generate_chromatic_function(None, drift)(spots), g["drift_only"])
+    assert np.array_equal(generate_polynomial_data(coords[:7], 2), g["poly2"])
+    assert generate_chromatic_function(None, None)(spots) is spots
+    with pytest.raises(ValueError):
+        f(np.zeros((3, 5)))
+    with pytest.raises(TypeError):
+        generate_chromatic_function(3.0)

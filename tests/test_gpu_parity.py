@@ -625,7 +625,7 @@ def test_correct_fov_image_argument_errors(tmp_path):
     with pytest.raises(IndexError):
         correct_fov_image(case["raw"], sel, **bad)
     with pytest.raises(NotImplementedError):
-        correct_fov_image(case["raw"], sel, warp_image=False, **kw)
+        correct_fov_image(case["raw"], sel, normalization=True, **kw)
     # host split == device split
     a = split_im_by_channels(case["raw"], ['561', '488'], case["chs"], [case["Z"], case["X"], case["Y"]], case["nb"], 0)
     from imageanalysis3_amd import _lib as L
@@ -637,3 +637,25 @@ def test_correct_fov_image_argument_errors(tmp_path):
             y.free()
     finally:
         st.free()
+
+
+def test_correct_fov_image_translation_functions():
+    """warp_image=False (io_tools/load.py:454-486): images stay unwarped, one spot-translation function per channel."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from make_golden import chromfn_inputs
+    from conftest import build_chain_case, chain_kwargs
+    from imageanalysis3_amd.io_tools.load import correct_fov_image
+    case = build_chain_case()
+    g = load_golden("chain.npz")
+    gf = load_golden("chromfn.npz")
+    info, coords, spots, drift = chromfn_inputs()
+    sel, kw = chain_kwargs(case, "silent_no_warp")
+    kw["chromatic_profile"] = {'750': info, '647': None, '561': info}
+    kw["drift"] = drift
+    ims, funcs = correct_fov_image(case["raw"], sel, warp_image=False, **kw)
+    for ch, im in zip(sel, ims):
+        assert np.array_equal(im, g["silent_no_warp_%s" % ch])       # unwarped images
+    assert len(funcs) == 2
+    assert np.array_equal(funcs[0](spots), gf["spots"])               # 750: chromatic constants + drift
+    assert np.array_equal(funcs[1](spots), gf["drift_only"])          # 647 (reference channel): drift only
