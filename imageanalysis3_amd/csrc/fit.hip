@@ -581,16 +581,17 @@ void ia3_fit_destroy(ia3_fitter* f) {
   delete f;
 }
 
-int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const ia3_fit_params* p,
-                   ia3_fitter** out) {
+static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const double* d_centers_zxy, int n,
+                           const ia3_fit_params* p, ia3_fitter** out) {
   int rc = ensure_init(); if (rc) return rc;
-  if (!im || !p || !out || n < 0 || (n > 0 && !centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
+  if (!im || !p || !out || n < 0 || (n > 0 && !centers_zxy && !d_centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
   if (p->radius_fit < 1) return set_error(IA3_EINVAL, "radius_fit must be >= 1");
   std::vector<signed char> ball;
   int nball = build_ball(p->radius_fit, ball);
   if (nball > MAXBALL) return set_error(IA3_EUNSUPPORTED, "radius_fit %d gives %d voxels (> %d)", p->radius_fit, nball, MAXBALL);
-  for (int i = 0; i < 3 * n; ++i)
-    if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
+  if (centers_zxy)
+    for (int i = 0; i < 3 * n; ++i)
+      if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
   ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
   f->im = im; f->prm = *p; f->n = n; f->nball = nball;
   // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows | neighbour lists]
@@ -626,10 +627,12 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
   // stage the read-only part contiguously and ship it with one copy
   std::vector<char>& host = f->host_stage;
   host.assign(up_bytes, 0);
-  if (n) memcpy(host.data(), centers_zxy, sizeof(double) * 3 * (size_t)n);
+  if (n && centers_zxy) memcpy(host.data(), centers_zxy, sizeof(double) * 3 * (size_t)n);
   memcpy(host.data() + b_seeds, ball.data(), ball.size());
   hipStream_t st = stream();
   hipError_t e = hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && n && !centers_zxy)   // centres that never left the device (seed.hip's device finish)
+    e = hipMemcpyAsync(f->d_seeds, d_centers_zxy, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(zero0, 0, zero_bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(f->d_ps, 0xFF, b_ps, st);   // all-ones float32 = NaN: failed fits stay NaN rows (:636)
   if (e != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "fitter setup failed: %s", hipGetErrorString(e)); }
@@ -644,6 +647,22 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
   *out = f;
   return IA3_OK;
 }
+
+int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const ia3_fit_params* p,
+                   ia3_fitter** out) {
+  if (n > 0 && !centers_zxy) return set_error(IA3_EINVAL, "bad argument");
+  return fit_create_impl(im, centers_zxy, nullptr, n, p, out);
+}
+
+}  // extern "C"
+
+namespace ia3k {
+int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out) {
+  return fit_create_impl(im, nullptr, d_centers_zxy, n, p, out);
+}
+}  // namespace ia3k
+
+extern "C" {
 
 // Launch the work list for stages [stage0, stage1).  `fresh` re-arms the whole control block (claim = 0,
 // n_unconv = n, abort = 0); otherwise only the ticket counter is reset and n_unconv / done[] carry over.

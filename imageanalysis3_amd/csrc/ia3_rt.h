@@ -80,4 +80,20 @@ struct SeedOut {
   double th_used;
 };
 int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out);
+// same, with the seed list left on the device when the device-side finish applies (<= 8192 candidates, stack no
+// larger than 256 x 4096 x 4096): d_zxy = n x 3 float64 centres, d_h = n float64 heights inside `hold`; otherwise
+// on_device == false and `host` carries the list.
+struct SeedDev {
+  bool on_device = false;
+  int n = 0;
+  double th_used = 0;
+  const double* d_zxy = nullptr;
+  const double* d_h = nullptr;
+  void* hold = nullptr;     // scratch block that owns d_zxy / d_h; release with ws_put
+  SeedOut host;
+  ~SeedDev() { if (hold) ia3rt::ws_put(hold); }
+};
+int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
+// fitter from centres that are already resident (n x 3 float64)
+int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
 }  // namespace ia3k

@@ -10,17 +10,21 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
                                float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter) {
   int rc = ensure_init(); if (rc) return rc;
   if (!im || !sp || !fp || !n_rows) return set_error(IA3_EINVAL, "null argument");
-  ia3k::SeedOut so;
-  rc = ia3k::dog_seed(im, *sp, so); if (rc) return rc;
-  const int n = (int)(so.zxyh.size() / 4);
+  ia3k::SeedDev sd;
+  rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
+  const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
   if (n_seeds) *n_seeds = n;
   if (n_iter) *n_iter = 0;
   *n_rows = 0;
   if (n == 0) return IA3_OK;  // fitting.py:206-207
-  std::vector<double> c((size_t)n * 3);
-  for (int i = 0; i < n; ++i) { c[3 * i] = so.zxyh[4 * i]; c[3 * i + 1] = so.zxyh[4 * i + 1]; c[3 * i + 2] = so.zxyh[4 * i + 2]; }
   ia3_fitter* f = nullptr;
-  rc = ia3_fit_create(im, c.data(), n, fp, &f); if (rc) return rc;
+  if (sd.on_device) {
+    rc = ia3k::fit_create_dev(im, sd.d_zxy, n, fp, &f); if (rc) return rc;   // the seed list never left HBM
+  } else {
+    std::vector<double> c((size_t)n * 3);
+    for (int i = 0; i < n; ++i) { c[3 * i] = sd.host.zxyh[4 * i]; c[3 * i + 1] = sd.host.zxyh[4 * i + 1]; c[3 * i + 2] = sd.host.zxyh[4 * i + 2]; }
+    rc = ia3_fit_create(im, c.data(), n, fp, &f); if (rc) return rc;
+  }
   std::vector<float> ps((size_t)n * 11);
   rc = ia3_fit_run(f);
   if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);

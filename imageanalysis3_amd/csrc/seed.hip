@@ -236,6 +236,110 @@ void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, i
 
 }  // namespace
 
+namespace {
+
+// ---- tail of get_seeds on the device (fitting.py:113-150) ---------------------------------------------------------
+// level pick, hot-column vote, sort by height and truncation for up to FIN_CAP candidates, as four small kernels
+// of all-pairs work (n <= 8192: at most 67 M comparisons spread over 256 blocks): no sort network, no hash table,
+// and the seed list never leaves HBM between the detector and the fitter.
+constexpr unsigned FIN_CAP = 8192;
+constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
+struct FinCtl { unsigned n_alive; int chosen; unsigned pad[2]; };
+
+__device__ __forceinline__ unsigned fin_n(const SeedCtl* sctl) { return sctl->n_cand < FIN_CAP ? sctl->n_cand : FIN_CAP; }
+__device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h desc, then z, x, y desc (finish_seeds)
+  uint32_t u = __float_as_uint(k.h);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | ((unsigned long long)k.z << 24) | ((unsigned long long)k.x << 12) | (unsigned long long)k.y;
+}
+
+__global__ __launch_bounds__(1024) void fin_levels_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
+                                                     int min_dyn, FinCtl* __restrict__ fc) {
+  __shared__ unsigned cnt[MAXLEV];
+  if (threadIdx.x < MAXLEV) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned n = fin_n(sctl);
+  for (unsigned i = threadIdx.x; i < n; i += 1024) {
+    const double h = (double)c[i].h;
+    for (int l = 0; l < lev.n; ++l) if (h >= lev.th[l]) atomicAdd(&cnt[l], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int chosen = lev.n - 1;
+    for (int l = 0; l < lev.n; ++l) if ((long long)cnt[l] >= (long long)min_dyn) { chosen = l; break; }
+    fc->chosen = chosen;
+  }
+}
+
+// hotcnt[i] = number of kept candidates in the (x, y) column of kept candidate i
+__global__ __launch_bounds__(256) void fin_hot_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
+                                                 const FinCtl* __restrict__ fc, unsigned* __restrict__ hotcnt) {
+  __shared__ int tx[256], ty[256];
+  const unsigned n = fin_n(sctl);
+  const double th = lev.th[fc->chosen];
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const bool mine = i < n && (double)c[i].h >= th;
+  const int xi = i < n ? c[i].x : -1, yi = i < n ? c[i].y : -1;
+  const unsigned per = (n + FIN_S - 1) / FIN_S, j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+  unsigned cnt = 0;
+  for (unsigned jb = j0; jb < j1; jb += 256) {
+    const unsigned j = jb + threadIdx.x;
+    __syncthreads();
+    const bool kj = j < j1 && (double)c[j].h >= th;
+    tx[threadIdx.x] = kj ? c[j].x : -2;
+    ty[threadIdx.x] = kj ? c[j].y : -2;
+    __syncthreads();
+    const unsigned m = j1 - jb < 256 ? j1 - jb : 256;
+    for (unsigned t = 0; t < m; ++t) cnt += (tx[t] == xi && ty[t] == yi);
+  }
+  if (mine && cnt) atomicAdd(&hotcnt[i], cnt);
+}
+
+// rank[i] = number of surviving candidates that sort before candidate i; fc->n_alive = survivors
+__global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
+                                                  FinCtl* __restrict__ fc, const unsigned* __restrict__ hotcnt, int hot_th,
+                                                  unsigned* __restrict__ rank) {
+  __shared__ unsigned long long tk[256];
+  const unsigned n = fin_n(sctl);
+  const double th = lev.th[fc->chosen];
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const bool alive = i < n && (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
+  const unsigned long long ki = i < n ? fin_key(c[i]) : ~0ull;
+  const unsigned per = (n + FIN_S - 1) / FIN_S, j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+  unsigned r = 0;
+  for (unsigned jb = j0; jb < j1; jb += 256) {
+    const unsigned j = jb + threadIdx.x;
+    __syncthreads();
+    const bool aj = j < j1 && (double)c[j].h >= th && (hot_th <= 0 || hotcnt[j] < (unsigned)hot_th);
+    tk[threadIdx.x] = aj ? fin_key(c[j]) : 0ull;   // 0 sorts after every real key (a real key has bit 63 or a positive h)
+    __syncthreads();
+    const unsigned m = j1 - jb < 256 ? j1 - jb : 256;
+    for (unsigned t = 0; t < m; ++t) r += tk[t] > ki;
+  }
+  if (alive) {
+    if (r) atomicAdd(&rank[i], r);
+    if (blockIdx.y == 0) atomicAdd(&fc->n_alive, 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
+                                                     const FinCtl* __restrict__ fc, const unsigned* __restrict__ hotcnt,
+                                                     int hot_th, const unsigned* __restrict__ rank, int max_num,
+                                                     double* __restrict__ zxy, double* __restrict__ hh) {
+  const unsigned n = fin_n(sctl);
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double th = lev.th[fc->chosen];
+  const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
+  if (!alive) return;
+  const unsigned r = rank[i];
+  if (max_num > 0 && r >= (unsigned)max_num) return;
+  zxy[3 * r] = c[i].z; zxy[3 * r + 1] = c[i].x; zxy[3 * r + 2] = c[i].y;
+  hh[r] = (double)c[i].h;
+}
+
+}  // namespace
+
 using namespace ia3rt;
 
 namespace ia3k {
@@ -298,7 +402,7 @@ static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed
 
 static double now_ms() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
-int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
+static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out, SeedDev* dev) {
   hipStream_t s = stream();
   const bool dbg = getenv("IA3_DEBUG_TIMING") != nullptr;
   const double t0 = now_ms();
@@ -358,6 +462,48 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
         launch_detect<uint16_t>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, dcand, capacity, dctl, s);
     }
     IA3_KCHECK();
+    if (dev && attempt == 0 && Z <= 256 && X <= 4096 && Y <= 4096) {
+      // finish on the device; the host only learns how many seeds there are
+      const size_t o_hot = 16, o_rank = o_hot + 4 * (size_t)FIN_CAP, o_zxy = o_rank + 4 * (size_t)FIN_CAP,
+                   o_h = o_zxy + 24 * (size_t)FIN_CAP, fin_bytes = o_h + 8 * (size_t)FIN_CAP;
+      void* fin = ws_get(fin_bytes);
+      if (!fin) return IA3_ENOMEM;
+      char* fb = (char*)fin;
+      hipError_t fe = hipMemsetAsync(fin, 0, o_zxy, s);
+      if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(fe)); }
+      FinCtl* fc = (FinCtl*)fb;
+      unsigned* hot = (unsigned*)(fb + o_hot);
+      unsigned* rank = (unsigned*)(fb + o_rank);
+      const int hot_th = p.remove_hot_pixel ? p.hot_pixel_th : 0;
+      {
+        ProfScope pf("seed_finish");
+        hipLaunchKernelGGL(fin_levels_k, dim3(1), dim3(1024), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, p.min_dynamic_seeds, fc);
+        if (hot_th > 0)
+          hipLaunchKernelGGL(fin_hot_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc, hot);
+        hipLaunchKernelGGL(fin_rank_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, fc, (const unsigned*)hot, hot_th, rank);
+        hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_CAP / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc,
+                           (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h));
+      }
+      FinCtl hfc;
+      fe = hipGetLastError();
+      if (fe == hipSuccess) fe = hipMemcpyAsync(&hctl, dctl, sizeof(SeedCtl), hipMemcpyDeviceToHost, s);
+      if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
+      if (fe == hipSuccess) fe = hipStreamSynchronize(s);
+      if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe)); }
+      if (hctl.n_cand <= FIN_CAP && !hctl.overflow) {
+        int n = (int)hfc.n_alive;
+        if (p.max_num_seeds > 0 && p.max_num_seeds <= n) n = p.max_num_seeds;
+        dev->on_device = true;
+        dev->n = n;
+        dev->th_used = lev.th[hfc.chosen];
+        dev->d_zxy = (const double*)(fb + o_zxy);
+        dev->d_h = (const double*)(fb + o_h);
+        dev->hold = fin;
+        if (dbg) fprintf(stderr, "dog_seed: device finish, %u candidates -> %d seeds\n", hctl.n_cand, n);
+        return IA3_OK;
+      }
+      ws_put(fin);   // too many candidates: the host path below takes over (the detector's output is still in buf)
+    }
     IA3_HIP(hipMemcpyAsync(hbuf.data(), buf.p, hbuf.size(), hipMemcpyDeviceToHost, s));
     IA3_HIP(hipStreamSynchronize(s));
     memcpy(&hctl, hbuf.data(), sizeof(SeedCtl));
@@ -377,6 +523,30 @@ int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
   const double t2 = now_ms();
   finish_seeds(cand, lev, p, Y, out);
   if (dbg) fprintf(stderr, "dog_seed: launch gauss %.3f ms, detect+copy(sync) %.3f ms, finish %.3f ms (%zu cand)\n", t1 - t0, t2 - t1, now_ms() - t2, cand.size());
+  return IA3_OK;
+}
+
+int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out) {
+  return dog_seed_impl(im, p, out.host, &out);
+}
+
+int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out) {
+  SeedDev d;
+  int rc = dog_seed_impl(im, p, d.host, &d); if (rc) return rc;
+  if (!d.on_device) { out = std::move(d.host); return IA3_OK; }
+  out.th_used = d.th_used;
+  out.zxyh.assign((size_t)d.n * 4, 0.0);
+  if (d.n) {
+    std::vector<double> zxy((size_t)d.n * 3), hh((size_t)d.n);
+    hipStream_t s = stream();
+    IA3_HIP(hipMemcpyAsync(zxy.data(), d.d_zxy, zxy.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipMemcpyAsync(hh.data(), d.d_h, hh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < d.n; ++i) {
+      out.zxyh[4 * i] = zxy[3 * i]; out.zxyh[4 * i + 1] = zxy[3 * i + 1]; out.zxyh[4 * i + 2] = zxy[3 * i + 2];
+      out.zxyh[4 * i + 3] = hh[i];
+    }
+  }
   return IA3_OK;
 }
 
