@@ -19,6 +19,7 @@
 //     row-coalesced.  Long filters (VALU-bound, R >= 16): the axis-1 pass stores each plane transposed and the
 //     axis-2 pass is the strided kernel over that transposed plane, storing transposed again.
 #include "ia3_rt.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,6 +40,14 @@ template <> __device__ __forceinline__ float cvt<float>(double v) { return (floa
 template <> __device__ __forceinline__ uint16_t cvt<uint16_t>(double v) { return (uint16_t)(int)v; }
 
 struct Taps { double w[64]; };
+
+// f(integral_constant<0>), f(<1>), ... while f returns true
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_until(F& f) {
+  if constexpr (I < N) {
+    if (f(std::integral_constant<int, I>{})) static_for_until<I + 1, N>(f);
+  }
+}
 
 // bmap[i] = border-mapped source index of position (i - R), i in [0, count); positions past the
 // end of the last chunk are only ever loaded, never stored, and map to valid indices as well.
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
                                                      int inner, size_t stride, int len,
                                                      size_t outer_stride, Taps taps,
                                                      const int* __restrict__ bmap, int seg) {
-  constexpr int TQ = 32;                       // q extent of the transposing tile
+  constexpr int TQ = (K == 6 || K == 12) ? 24 : ((K == 10) ? 30 : 32);   // q extent of the transposing tile (a multiple of K)
   static_assert(!TR || TQ % K == 0, "tile must hold whole chunks");
   __shared__ float tile[TR ? 4 : 1][TR ? 64 : 1][TR ? TQ + 1 : 1];
   const int p_raw = blockIdx.x * 256 + threadIdx.x;
@@ -71,50 +80,69 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
   const int q_begin = blockIdx.z * seg;
   const int q_end = q_begin + seg < len ? q_begin + seg : len;
   // bmap[i] = border-mapped index of position i - R (wave-uniform -> scalar loads)
-  double win[K + 2 * R];
+  // The window is a ring of W = K + 2R registers.  When K divides W the chunk loop is unrolled W/K times and the
+  // ring is indexed with compile-time offsets, so sliding costs nothing; otherwise (ROT = 1) the window is shifted
+  // with 2R register moves per chunk.
+  constexpr int W = K + 2 * R;
+  constexpr int U = (W % K == 0) ? W / K : 1;   // chunks per unrolled body
+  double win[W];
 #pragma unroll
-  for (int i = 0; i < K + 2 * R; ++i) win[i] = ld<T>(in, base + (size_t)bmap[q_begin + i] * stride);
-  for (int q0 = q_begin; q0 < q_end; q0 += K) {
-    // prefetch the K inputs the next chunk adds (positions q0+K+R .. q0+2K+R-1)
-    T nxt[K];   // kept in the stack dtype (half the registers of f64) until they enter the window
+  for (int i = 0; i < W; ++i) win[i] = ld<T>(in, base + (size_t)bmap[q_begin + i] * stride);
+  for (int qq = q_begin; qq < q_end; qq += K * U) {
+    // the U chunks of one turn of the ring, expanded at compile time (static_for_until: stops at the segment end)
+    auto chunk = [&](auto cc) -> bool {
+      constexpr int c = decltype(cc)::value;
+      const int q0 = qq + c * K;
+      if (q0 >= q_end) return false;            // wave-uniform
+      constexpr int o = (U == 1) ? 0 : c * K;   // physical slot of logical window index 0
+      // prefetch the K inputs the next chunk adds (positions q0+K+R .. q0+2K+R-1)
+      T nxt[K];   // kept in the stack dtype (half the registers of f64) until they enter the window
 #pragma unroll
-    for (int i = 0; i < K; ++i) nxt[i] = in[base + (size_t)bmap[q0 + K + 2 * R + i] * stride];
-    double acc[K];
+      for (int i = 0; i < K; ++i) nxt[i] = in[base + (size_t)bmap[q0 + K + 2 * R + i] * stride];
+      double acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = win[k + R] * taps.w[0];
+      for (int k = 0; k < K; ++k) acc[k] = win[(o + k + R) % W] * taps.w[0];
 #pragma unroll
-    for (int j = R; j >= 1; --j) {
+      for (int j = R; j >= 1; --j) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[k + R - j] + win[k + R + j]) * taps.w[j];
-    }
-    if constexpr (TR) {
-      const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-      const int cq = ((q0 - q_begin) / K) % (TQ / K);     // chunk slot inside the tile (wave-uniform)
-#pragma unroll
-      for (int k = 0; k < K; ++k) tile[wv][ln][cq * K + k] = (float)cvt<T>(acc[k]);   // exact in a float
-      if (cq == TQ / K - 1 || q0 + K >= q_end) {
-        __builtin_amdgcn_wave_barrier();
-        const int qt0 = q0 - cq * K;
-        const int nq = q_end - qt0 < TQ ? q_end - qt0 : TQ;
-        const int col = ln & 31, hrow = ln >> 5;
-        const int pw = blockIdx.x * 256 + wv * 64;
-        T* o = out + (size_t)blockIdx.y * outer_stride + qt0 + col;
-#pragma unroll 8
-        for (int r2 = 0; r2 < 32; ++r2) {
-          const int row = 2 * r2 + hrow;
-          if (col < nq && pw + row < inner) o[(size_t)(pw + row) * len] = (T)tile[wv][row][col];
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[(o + k + R - j) % W] + win[(o + k + R + j) % W]) * taps.w[j];
       }
-    } else {
+      if constexpr (TR) {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const int cq = ((q0 - q_begin) / K) % (TQ / K);     // chunk slot inside the tile (wave-uniform)
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (q0 + k < q_end) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
-    }
+        for (int k = 0; k < K; ++k) tile[wv][ln][cq * K + k] = (float)cvt<T>(acc[k]);   // exact in a float
+        if (cq == TQ / K - 1 || q0 + K >= q_end) {
+          __builtin_amdgcn_wave_barrier();
+          const int qt0 = q0 - cq * K;
+          const int nq = q_end - qt0 < TQ ? q_end - qt0 : TQ;
+          const int col = ln & 31, hrow = ln >> 5;
+          const int pw = blockIdx.x * 256 + wv * 64;
+          T* op = out + (size_t)blockIdx.y * outer_stride + qt0 + col;
+#pragma unroll 8
+          for (int r2 = 0; r2 < 32; ++r2) {
+            const int row = 2 * r2 + hrow;
+            if (col < nq && pw + row < inner) op[(size_t)(pw + row) * len] = (T)tile[wv][row][col];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
 #pragma unroll
-    for (int i = 0; i < 2 * R; ++i) win[i] = win[i + K];
+        for (int k = 0; k < K; ++k)
+          if (q0 + k < q_end) out[base + (size_t)(q0 + k) * stride] = cvt<T>(acc[k]);
+      }
+      if constexpr (U == 1) {
 #pragma unroll
-    for (int i = 0; i < K; ++i) win[2 * R + i] = (double)nxt[i];
+        for (int i = 0; i < 2 * R; ++i) win[i] = win[i + K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) win[2 * R + i] = (double)nxt[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) win[(o + i) % W] = (double)nxt[i];   // the K oldest slots take the new inputs
+      }
+      return true;
+    };
+    static_for_until<0, U>(chunk);
   }
 }
 
@@ -319,7 +347,8 @@ __global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T*
   }
 }
 
-template <class T, int R, int KS, int KC>
+// KZ / KS / KC: outputs per chunk of the axis-0 pass, of the other strided passes, of the LDS-transposed pass
+template <class T, int R, int KS, int KC, int KZ = KS>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
   if constexpr (R <= 6) {
@@ -346,7 +375,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     return 0;
   }
   // border maps for the three axes: positions -R .. len + R + 2K (sliding-window prefetch overshoots by < 2K)
-  const int cz = Z + 2 * R + 3 * KS, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * 9;
+  const int cz = Z + 2 * R + 3 * KZ, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * 9;
   ia3rt::Scratch maps((size_t)(cz + cx + cy) * sizeof(int));
   if (!maps.p) return IA3_ENOMEM;
   int* mz = maps.as<int>();
@@ -358,18 +387,19 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   static const std::string nz = "gauss_axis0_R" + std::to_string(R), nx = "gauss_axis1_R" + std::to_string(R),
                            ny = "gauss_axis2_R" + std::to_string(R);
   // segment length along the filter axis: a multiple of K, long enough to amortise the 2R-deep window fill
-  auto seg_for = [](int len, long long lines) {
-    int seg = ((len + KS - 1) / KS) * KS;                 // whole line
-    const int min_seg = ((8 * R + KS - 1) / KS) * KS;     // halo re-read <= 25 %
-    while (lines * ((len + seg - 1) / seg) < 256LL * 256 * 8 && seg / 2 >= min_seg) seg = ((seg / 2 + KS - 1) / KS) * KS;
+  auto seg_for_k = [](int len, long long lines, int kk) {
+    int seg = ((len + kk - 1) / kk) * kk;                 // whole line
+    const int min_seg = ((8 * R + kk - 1) / kk) * kk;     // halo re-read <= 25 %
+    while (lines * ((len + seg - 1) / seg) < 256LL * 256 * 8 && seg / 2 >= min_seg) seg = ((seg / 2 + kk - 1) / kk) * kk;
     return seg;
   };
+  auto seg_for = [&](int len, long long lines) { return seg_for_k(len, lines, KS); };
   // axis 0: src -> dst
   {
     ia3rt::ProfScope ps(nz.c_str());
-    const int seg = seg_for(Z, (long long)plane);
+    const int seg = seg_for_k(Z, (long long)plane, KZ);
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
-    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg);
+    hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg);
   }
   if constexpr (R >= 16) {
     // long filters are f64-VALU-bound: give the contiguous axis the register-window kernel too, by transposing
@@ -447,7 +477,7 @@ int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int 
       case 3:  return run_fixed<T, 3, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
       case 6:  return run_fixed<T, 6, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
       case 10: return run_fixed<T, 10, 12, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 30: return run_fixed<T, 30, 8, 8>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 30: return run_fixed<T, 30, 8, 8, 6>(src, Z, X, Y, t, mode, dst, tmp, s);
       default: break;
     }
   }
