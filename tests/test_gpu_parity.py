@@ -65,6 +65,24 @@ def test_gaussian_filter_bit_exact(name, sigma, truncate, mode):
     assert np.array_equal(got, ref), "%d voxels differ" % (got != ref).sum()
 
 
+@pytest.mark.parametrize("shape", [(7, 45, 83), (33, 70, 130), (5, 31, 65), (64, 33, 257), (3, 8, 8)])
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16])
+def test_gaussian_filter_ragged_shapes_bit_exact(shape, dtype):
+    """Partial tiles of the fused short-filter kernel, partial segments / transposing tiles of the long one, axes
+    shorter than the filter radius (the border map wraps more than once), every fixed radius and the generic path."""
+    from scipy import ndimage as ndi
+    from imageanalysis3_amd.correction_tools.filter import gaussian_filter
+    rng = np.random.RandomState(shape[1] * 7 + shape[2])
+    a = rng.gamma(2.0, 300.0, size=shape)
+    im = a.astype(np.float32) if dtype == np.float32 else np.clip(a, 0, 65535).astype(np.uint16)
+    for sigma, truncate, mode in [(0.75, 4.0, "reflect"), (0.75, 4.0, "nearest"), (7.5, 4.0, "reflect"),
+                                  (7.5, 4.0, "nearest"), (3, 2, "nearest"), (5, 2, "reflect"), (1.1, 4.0, "reflect")]:
+        got = gaussian_filter(im, sigma, mode=mode, truncate=truncate)
+        ref = ndi.gaussian_filter(im, sigma, mode=mode, truncate=truncate)
+        assert got.dtype == im.dtype
+        assert np.array_equal(got, ref), (shape, sigma, mode, int((got != ref).sum()))
+
+
 def test_gaussian_filter_matches_scipy_directly():
     from scipy import ndimage as ndi
     from imageanalysis3_amd.correction_tools.filter import gaussian_filter
@@ -115,6 +133,40 @@ def test_get_seeds_golden(name):
     assert np.array_equal(np.sort(top[:, 3]), np.sort(ref[:, 3]))
     s3 = get_seeds(im, th_seed=600)
     assert s3.shape == (len(g["seeds_h"]), 3)
+
+
+@pytest.mark.parametrize("shape,dtype", [((9, 45, 83), np.float32), ((30, 70, 130), np.uint16), ((12, 33, 257), np.float32)])
+def test_get_seeds_ragged_shapes_vs_oracle(shape, dtype):
+    """Tile edges of the detector and of the fused filter on shapes that are no multiple of anything."""
+    import np_oracle as O
+    from imageanalysis3_amd import synth
+    from imageanalysis3_amd.spot_tools.fitting import get_seeds
+    im, c, h = synth.make_fov(shape, 12, 77, dtype=dtype, margin=(2, 5, 5), min_sep=6.0)
+    for kw in (dict(th_seed=600), dict(th_seed=300, min_edge_distance=0, remove_hot_pixel=False),
+               dict(th_seed=5000, use_dynamic_th=True, min_dynamic_seeds=8), dict(th_seed=600, max_num_seeds=5)):
+        got = get_seeds(im, return_h=True, **kw)
+        ref = O.get_seeds(im, return_h=True, **kw)
+        assert got.shape == ref.shape, (kw, got.shape, ref.shape)
+        if "max_num_seeds" in kw:
+            assert np.array_equal(np.sort(got[:, 3]), np.sort(ref[:, 3]))
+        else:
+            assert np.array_equal(seed_set(got), seed_set(ref)), kw
+
+
+def test_get_seeds_many_candidates_host_finish_path():
+    """More than 8192 candidates: the device finish declines and the host tail takes over; same seeds either way."""
+    import np_oracle as O
+    from imageanalysis3_amd.spot_tools.fitting import get_seeds
+    from imageanalysis3_amd import synth
+    im = synth.make_fov((40, 160, 200), 20, 5)[0]
+    for kw in (dict(th_seed=-1000.0, use_dynamic_th=False, remove_hot_pixel=False, min_edge_distance=0),
+               dict(th_seed=-1000.0, use_dynamic_th=False, remove_hot_pixel=True, hot_pixel_th=3),
+               dict(th_seed=-500.0, use_dynamic_th=True, dynamic_niters=4, min_dynamic_seeds=100000)):
+        got = get_seeds(im, return_h=True, **kw)
+        ref = O.get_seeds(im, return_h=True, **kw)
+        assert len(ref) > 8192 or kw.get("remove_hot_pixel"), len(ref)
+        assert got.shape == ref.shape, (kw, got.shape, ref.shape)
+        assert np.array_equal(seed_set(got), seed_set(ref)), kw
 
 
 def test_get_seeds_errors_and_empty():
