@@ -2,8 +2,8 @@
 
 Everything here is built from integer hashing (splitmix64) and IEEE-754
 ``+ - * /``, ``floor`` and ``ldexp`` only — no libm ``exp/log/cos`` — so the
-same stack is produced bit-for-bit on any host and by the HIP twin
-(``ia3_synth_fov`` in ``csrc/synth.hip``, compiled with ``-ffp-contract=off``).
+same stack is produced bit-for-bit on any host (fixtures are regenerated from the generator's
+arguments on the GPU box instead of being shipped).
 Golden fixtures under ``tests/golden`` store only *outputs*; inputs are
 regenerated from ``(shape, n, seed, layout)``.
 
@@ -80,7 +80,7 @@ def background(shape, seed, bg=400.0, noise=15.0, z0=0, z1=None):
     return out
 
 
-# ---- deterministic exp for x <= 0 (pure IEEE ops; twin of dexp() in csrc/synth.hip) ----
+# ---- deterministic exp for x <= 0 (pure IEEE ops, no libm: identical on every host) ----
 _LOG2E = 1.4426950408889634
 _LN2_HI = 6.93147180369123816490e-01
 _LN2_LO = 1.90821492927058770002e-10
