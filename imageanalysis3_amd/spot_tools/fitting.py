@@ -101,26 +101,28 @@ def fit_fov_image(im, channel, seeds=None,
     if verbose:
         print(f"-- start fitting spots in channel:{channel}, ", end='')
         _fit_time = time.time()
-    if not isinstance(im, np.ndarray):
+    _resident = isinstance(im, L.DeviceStack)   # e.g. from correct_fov_image(..., return_device=True)
+    if not _resident and not isinstance(im, np.ndarray):
         raise TypeError(f"image given should be a numpy.ndarray, but {type(im)} is given.")
-    _stack = L.DeviceStack.upload(im)
+    _stack = im if _resident else L.DeviceStack.upload(im)
+    _shape = tuple(_stack.shape)
     try:
         if seeds is None:
             _seeds = _get_seeds_dev(_stack, max_num_seeds=max_num_seeds, th_seed=th_seed,
                                     th_seed_per=th_seed_per, use_percentile=use_percentile,
                                     use_dynamic_th=use_dynamic_th, dynamic_niters=dynamic_niters,
                                     min_dynamic_seeds=min_dynamic_seeds, remove_hot_pixel=remove_hot_pixel,
-                                    host_im=im, **seeding_kwargs)
+                                    host_im=None if _resident else im, **seeding_kwargs)
             if verbose:
                 print(f"{len(_seeds)} seeded with th={th_seed}, ", end='')
         else:
-            _seeds = np.array(seeds)[:, :len(np.shape(im))]
+            _seeds = np.array(seeds)[:, :len(_shape)]
             if verbose:
                 print(f"{len(_seeds)} given, ", end='')
         if len(_seeds) == 0:
             return np.array([])
         if seed_mask is not None:                                            # :210-218
-            _idx = np.round(_seeds[:, :im.ndim]).astype(np.int32)
+            _idx = np.round(_seeds[:, :len(_shape)]).astype(np.int32)
             _sel = seed_mask[tuple(_idx.T)] > 0
             _seeds = _seeds[_sel] if _sel.any() else np.array([])
             if verbose:
@@ -132,7 +134,7 @@ def fit_fov_image(im, channel, seeds=None,
         _spots = np.array(_fitter.ps)
         _spots = _spots[np.sum(np.isnan(_spots), axis=1) == 0]               # :232
         if remove_boundary_points:                                           # :234-237
-            _kept = (_spots[:, 1:4] > np.zeros(3)).all(1) * (_spots[:, 1:4] < np.array(np.shape(im))).all(1)
+            _kept = (_spots[:, 1:4] > np.zeros(3)).all(1) * (_spots[:, 1:4] < np.array(_shape)).all(1)
             _spots = _spots[np.where(_kept)[0]]
         # intensity normalisation on the copy that is still resident (background.hip)
         if normalize_background and not normalize_local:                     # :240-245
@@ -148,7 +150,8 @@ def fit_fov_image(im, channel, seeds=None,
                 print("normalize local background for each spot, ", end='')
             _spots[:, 0] = _spots[:, 0] / np.array(_backs)
     finally:
-        _stack.free()
+        if not _resident:
+            _stack.free()
     if verbose:
         print(f"{len(_spots)} fitted in {time.time()-_fit_time:.3f}s.")
     return _spots
@@ -160,6 +163,8 @@ def _get_seeds_dev(stack, host_im=None, max_num_seeds=None, th_seed=150, th_seed
                    remove_hot_pixel=True, hot_pixel_th=3, return_h=False, verbose=False):
     """get_seeds on a stack that is already resident in HBM (no second upload)."""
     if sel_center is not None or use_percentile:
+        if host_im is None:
+            host_im = stack.download()
         return get_seeds(host_im, max_num_seeds=max_num_seeds, th_seed=th_seed, th_seed_per=th_seed_per,
                          use_percentile=use_percentile, sel_center=sel_center, seed_radius=seed_radius,
                          gfilt_size=gfilt_size, background_gfilt_size=background_gfilt_size,

@@ -655,6 +655,11 @@ def test_correct_fov_image_chain_golden_bit_exact(name, tmp_path):
         assert flag == 0 and np.allclose(drift, kw["drift"] if kw["drift"] is not None else 0)
         for ch, st in zip(sel, stacks):
             assert np.array_equal(st.download(), g["%s_%s" % (name, ch)])
+        if name == "full":
+            from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+            a = fit_fov_image(stacks[0], sel[0], th_seed=300, normalize_local=True, verbose=False)
+            b = fit_fov_image(stacks[0].download(), sel[0], th_seed=300, normalize_local=True, verbose=False)
+            assert len(a) > 0 and np.array_equal(a, b)
     finally:
         for st in stacks:
             st.free()
