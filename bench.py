@@ -67,11 +67,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # rehearsal hooks (one-GPU box): IA3_BENCH_DEVICE pins every rank to one device, IA3_BENCH_BACKEND=gloo swaps
+    # the collective backend; the driver's multi-GPU runs set neither
+    if os.environ.get("IA3_BENCH_DEVICE"):
+        local_rank = int(os.environ["IA3_BENCH_DEVICE"])
+    backend = os.environ.get("IA3_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from imageanalysis3_amd import synth, _lib as L
     from imageanalysis3_amd.parallel import gather_spot_tables
     import ctypes as C
@@ -118,7 +125,8 @@ def main():
     prof = L.profile_collect()
     L.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt, float(total_rows)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(total_rows)], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
