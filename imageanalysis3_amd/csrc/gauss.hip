@@ -266,6 +266,16 @@ __global__ __launch_bounds__(256) void highpass_k(const T* __restrict__ im, cons
 // outputs, quantised, second LDS tile) and the axis-2 pass reads that and stores to HBM with lanes along y.  Every
 // intermediate value is the one the three-kernel path produces (same order of operations, same rounding to the
 // stack dtype between axes); traffic drops from 6 to ~2.3 stack transfers.
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2: tiles that share halo
+// lines must land on the same XCD to share them.  Map linear id b to the tile (b % 8) * ceil(n/8) + b / 8, so every
+// XCD walks a contiguous run of tiles (neighbours in y are 8 dispatch slots apart, resident together).  Returns -1
+// for the padding ids of the last run.
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
+  const int per = (n_tiles + 7) >> 3;
+  const int t = (b & 7) * per + (b >> 3);
+  return ((b >> 3) < per && t < n_tiles) ? t : -1;
+}
+
 template <class T, int R>
 __global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T* __restrict__ out, int Z, int X, int Y,
                                                     Taps taps, const int* __restrict__ mz, const int* __restrict__ mx,
@@ -278,7 +288,10 @@ __global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T*
   __shared__ float A[EX][EY + 1];
   __shared__ float B[TX][EY + 1];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.y * TX, y0 = blockIdx.x * TY;
+  const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
+  const int tile_id = xcd_tile(blockIdx.x, nty * ntx);   // grid.x = 8 * ceil(tiles / 8)
+  if (tile_id < 0) return;                               // whole block leaves together
+  const int x0 = (tile_id / nty) * TX, y0 = (tile_id % nty) * TY;
   const int z_begin = blockIdx.z * zseg;
   const int z_end = z_begin + zseg < Z ? z_begin + zseg : Z;
   const size_t plane = (size_t)X * Y;
@@ -368,7 +381,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     // split z when the (x, y) tiling alone cannot fill the chip (each z chunk re-reads 2R halo planes)
     int zseg = Z;
     while ((long long)bx * by * ((Z + zseg - 1) / zseg) < 1024 && zseg / 2 >= 4 * R) zseg = (zseg + 1) / 2;
-    dim3 g(bx, by, (unsigned)((Z + zseg - 1) / zseg));
+    dim3 g(8 * ((bx * by + 7) / 8), 1, (unsigned)((Z + zseg - 1) / zseg));   // tiles, XCD-grouped inside the kernel
     hipLaunchKernelGGL((gauss3_fused<T, R>), g, dim3(256), 0, s, src, dst, Z, X, Y, t, (const int*)qz, (const int*)qx,
                        (const int*)qy, zseg);
     (void)tmp;

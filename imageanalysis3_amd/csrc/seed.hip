@@ -120,6 +120,16 @@ __global__ __launch_bounds__(256) void seed_detect(const T* __restrict__ mx, con
 // (16+2) x (64+2) halo tile of both filtered stacks in LDS with coalesced row loads, every thread takes the 3x3
 // in-plane extrema of its 4 voxels from LDS, and the z direction is a three-deep register pipeline.  Each voxel is
 // fetched from HBM 1.16x (halo) instead of 2.3x.
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2: tiles that share halo
+// lines must land on the same XCD to share them.  Map linear id b to the tile (b % 8) * ceil(n/8) + b / 8, so every
+// XCD walks a contiguous run of tiles (neighbours in y are 8 dispatch slots apart, resident together).  Returns -1
+// for the padding ids of the last run.
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
+  const int per = (n_tiles + 7) >> 3;
+  const int t = (b & 7) * per + (b >> 3);
+  return ((b >> 3) < per && t < n_tiles) ? t : -1;
+}
+
 template <class T, int ZC>
 __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ mx, const T* __restrict__ mn,
                                                           int Z, int X, int Y, int edge, double th_low,
@@ -128,7 +138,10 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
   constexpr int TX = 16, TY = 64, HX = TX + 2, HY = TY + 2, NE = (HX * HY + 255) / 256;
   __shared__ T tmax[2][HX][HY + 2];   // double-buffered: plane q+1 is fetched while plane q is consumed
   __shared__ T tmin[2][HX][HY + 2];
-  const int x0 = blockIdx.y * TX, y0 = blockIdx.x * TY;
+  const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
+  const int tile = xcd_tile(blockIdx.x, nty * ntx);   // grid.x = 8 * ceil(tiles / 8)
+  if (tile < 0) return;                               // whole block leaves together
+  const int x0 = (tile / nty) * TX, y0 = (tile % nty) * TY;
   const int z0 = blockIdx.z * ZC, z1 = z0 + ZC < Z ? z0 + ZC : Z;
   const int ty = threadIdx.x & 63, tg = threadIdx.x >> 6;   // thread owns rows tg*4 .. tg*4+3, column ty
   // per-thread staging slots: element e = threadIdx.x + 256*i of the halo tile -> in-plane offset / LDS slot
@@ -161,22 +174,30 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
   // planes are visited from z0-1 to z1 (clamped); after visiting plane q the pipeline holds q-2, q-1, q
   for (int q = z0 - 1, buf = 0; q <= z1; ++q, buf ^= 1) {
     if (q < z1) fetch(q + 1);   // in flight while plane q is reduced from LDS
+    {
+      // separable 3x3: row extrema of the 6 halo rows this thread's 4 voxels touch (3 LDS reads each), then 3-row
+      // extrema per voxel — half the LDS reads of the direct 9-tap form
+      const int c = ty + 1;
+      T hM[6], hm[6], ce[4], cf[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = tg * 4 + v + 1, c = ty + 1;
-      T a = tmax[buf][r - 1][c - 1], b = tmin[buf][r - 1][c - 1];
+      for (int rr = 0; rr < 6; ++rr) {
+        const int r = tg * 4 + rr;
+        const T a0 = tmax[buf][r][c - 1], a1 = tmax[buf][r][c], a2 = tmax[buf][r][c + 1];
+        const T b0 = tmin[buf][r][c - 1], b1 = tmin[buf][r][c], b2 = tmin[buf][r][c + 1];
+        T a = a0 > a1 ? a0 : a1; a = a2 > a ? a2 : a;
+        T b = b0 < b1 ? b0 : b1; b = b2 < b ? b2 : b;
+        hM[rr] = a; hm[rr] = b;
+        if (rr >= 1 && rr <= 4) { ce[rr - 1] = a1; cf[rr - 1] = b1; }
+      }
 #pragma unroll
-      for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-          T u = tmax[buf][r + dr][c + dc], w = tmin[buf][r + dr][c + dc];
-          a = u > a ? u : a;
-          b = w < b ? w : b;
-        }
-      pM[v][0] = pM[v][1]; pM[v][1] = pM[v][2]; pM[v][2] = a;
-      pm[v][0] = pm[v][1]; pm[v][1] = pm[v][2]; pm[v][2] = b;
-      cM[v][0] = cM[v][1]; cM[v][1] = tmax[buf][r][c];
-      cm[v][0] = cm[v][1]; cm[v][1] = tmin[buf][r][c];
+      for (int v = 0; v < 4; ++v) {
+        T a = hM[v] > hM[v + 1] ? hM[v] : hM[v + 1]; a = hM[v + 2] > a ? hM[v + 2] : a;
+        T b = hm[v] < hm[v + 1] ? hm[v] : hm[v + 1]; b = hm[v + 2] < b ? hm[v + 2] : b;
+        pM[v][0] = pM[v][1]; pM[v][1] = pM[v][2]; pM[v][2] = a;
+        pm[v][0] = pm[v][1]; pm[v][1] = pm[v][2]; pm[v][2] = b;
+        cM[v][0] = cM[v][1]; cM[v][1] = ce[v];
+        cm[v][0] = cm[v][1]; cm[v][1] = cf[v];
+      }
     }
     if (q < z1) stash(buf ^ 1);   // the other buffer was last read one iteration ago, before the previous barrier
     __syncthreads();
@@ -215,7 +236,8 @@ void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, i
                    Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s, int rule = 0) {
   if (W == 3 && rule == 0) {
     constexpr int ZT = 64;   // planes per block; the two halo planes of a chunk are re-read
-    dim3 gt((unsigned)((Y + 63) / 64), (unsigned)((X + 15) / 16), (unsigned)((Z + ZT - 1) / ZT));
+    const unsigned tiles = (unsigned)((Y + 63) / 64) * (unsigned)((X + 15) / 16);
+    dim3 gt(8 * ((tiles + 7) / 8), 1, (unsigned)((Z + ZT - 1) / ZT));
     hipLaunchKernelGGL((seed_detect3_tiled<T, ZT>), gt, dim3(256), 0, s, (const T*)mx, (const T*)mn, Z, X, Y, edge, th_low,
                        out, capacity, ctl);
     return;
