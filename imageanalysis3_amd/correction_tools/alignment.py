@@ -155,7 +155,8 @@ def align_image(
         src_im = _load(src_im, _all_channels0)
     if isinstance(ref_im, str):
         ref_im = _load(ref_im, _ref_all_channels0)
-    if not isinstance(src_im, np.ndarray) or not isinstance(ref_im, np.ndarray):
+    _ok = (np.ndarray, L.DeviceStack)   # a DeviceStack (e.g. from correct_fov_image(return_device=True)) skips the upload
+    if not isinstance(src_im, _ok) or not isinstance(ref_im, _ok):
         raise IOError(f"Wrong input file type, {type(src_im)} / {type(ref_im)} should be .dax file or np.ndarray")
     if np.shape(src_im) != np.shape(ref_im):
         raise IndexError(f"shape of target image:{np.shape(src_im)} and reference image:{np.shape(ref_im)} doesnt match!")
@@ -170,8 +171,14 @@ def align_image(
         raise ValueError(f"bead channel {drift_channel} not exist in all channels given:{_all_channels}")
     if verbose:
         print("-- start aligning given source image to given reference image.")
-    _src = L.DeviceStack.upload(src_im)
-    _ref = L.DeviceStack.upload(ref_im if ref_im.dtype == src_im.dtype else ref_im.astype(src_im.dtype))
+    _own_src, _own_ref = not isinstance(src_im, L.DeviceStack), not isinstance(ref_im, L.DeviceStack)
+    _src = L.DeviceStack.upload(src_im) if _own_src else src_im
+    if _own_ref:
+        _ref = L.DeviceStack.upload(ref_im if ref_im.dtype == _src.dtype else ref_im.astype(_src.dtype))
+    else:
+        _ref = ref_im
+        if _ref.dtype != _src.dtype:
+            raise TypeError("resident source and reference stacks must have the same dtype")
     _result_flag = 0
     _drifts = []
     _updated_mean_dft = None
@@ -184,10 +191,9 @@ def align_image(
                 if use_autocorr:
                     _dft, _error, _phasediff = phase_cross_correlation(_rim, _sim, upsample_factor=precision_fold)
                 else:
-                    _sl = tuple(slice(*_l) for _l in _lims)
-                    _src_spots = fit_fov_image(src_im[_sl], drift_channel, verbose=detailed_verbose, **_fitting_args)
+                    _src_spots = fit_fov_image(_sim, drift_channel, verbose=detailed_verbose, **_fitting_args)
                     _sp_src_cts = select_sparse_centers(_src_spots[:, 1:4], match_distance_th)
-                    _ref_spots = fit_fov_image(ref_im[_sl], drift_channel, verbose=detailed_verbose, **_fitting_args)
+                    _ref_spots = fit_fov_image(_rim, drift_channel, verbose=detailed_verbose, **_fitting_args)
                     _sp_ref_cts = select_sparse_centers(_ref_spots[:, 1:4], match_distance_th, verbose=detailed_verbose)
                     _dft, _paired_src_cts, _paired_ref_cts = align_beads(
                         _sp_src_cts, _sp_ref_cts, _sim, _rim, use_fft=True, match_distance_th=match_distance_th,
@@ -209,8 +215,10 @@ def align_image(
                         print(f"--- drifts for crops:{_kept_drift_inds} pass the thresold, exit cycle.")
                     break
     finally:
-        _src.free()
-        _ref.free()
+        if _own_src:
+            _src.free()
+        if _own_ref:
+            _ref.free()
     if _updated_mean_dft is None:                                                          # :676-693
         if verbose:
             print("-- return a sub-optimal drift")

@@ -11,6 +11,8 @@
 // All FFT-side arithmetic is float64 (complex128), the precision SciPy/skimage use for uint16 input.
 #include "ia3_rt.h"
 #include <hipfft/hipfft.h>
+#include <unistd.h>
+#include <vector>
 #include <math.h>
 
 using namespace ia3rt;
@@ -33,10 +35,35 @@ int next_fast_len(int n) {  // smallest 2^a 3^b 5^c 7^d >= n
     if (_r != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "%s failed: hipfft error %d", #expr, (int)_r); \
   } while (0)
 
-struct Plan {  // RAII
-  hipfftHandle h = 0; bool ok = false;
-  ~Plan() { if (ok) hipfftDestroy(h); }
-};
+// rocFFT plans cost tens of milliseconds to build (kernel selection, twiddle tables, work buffer); drift alignment
+// runs the same few transforms for every crop of every image, so plans are kept: a small per-process cache keyed
+// by (type, dims), least recently used entry evicted.  Work buffers stay attached to the cached plans.
+struct PlanEntry { int type, n0, n1, n2; hipfftHandle h; unsigned long long used; };
+static std::vector<PlanEntry> g_plans;
+static pid_t g_plans_pid = 0;
+static unsigned long long g_plan_clock = 0;
+constexpr size_t MAX_PLANS = 8;
+
+static int get_plan(int type, int n0, int n1, int n2, hipStream_t st, hipfftHandle* out) {
+  if (g_plans_pid != getpid()) { g_plans.clear(); g_plans_pid = getpid(); }   // handles do not survive fork()
+  for (auto& e : g_plans)
+    if (e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) { e.used = ++g_plan_clock; *out = e.h; return IA3_OK; }
+  if (g_plans.size() >= MAX_PLANS) {
+    size_t victim = 0;
+    for (size_t i = 1; i < g_plans.size(); ++i) if (g_plans[i].used < g_plans[victim].used) victim = i;
+    (void)hipStreamSynchronize(st);
+    hipfftDestroy(g_plans[victim].h);
+    g_plans.erase(g_plans.begin() + victim);
+  }
+  hipfftHandle h;
+  hipfftResult r = n2 > 0 ? hipfftPlan3d(&h, n0, n1, n2, (hipfftType)type) : hipfftPlan2d(&h, n0, n1, (hipfftType)type);
+  if (r != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfft plan (%d x %d x %d) failed: error %d", n0, n1, n2, (int)r);
+  r = hipfftSetStream(h, st);
+  if (r != HIPFFT_SUCCESS) { hipfftDestroy(h); return set_error(IA3_EHIP, "hipfftSetStream failed: error %d", (int)r); }
+  g_plans.push_back(PlanEntry{type, n0, n1, n2, h, ++g_plan_clock});
+  *out = h;
+  return IA3_OK;
+}
 
 template <class T> __device__ __forceinline__ double ldv(const T* p, size_t i) { return (double)p[i]; }
 
@@ -142,15 +169,13 @@ int fftalign2d_dev(const double* im1, int s1x, int s1y, const double* im2, int s
   dim3 g((Fy + 255) / 256, Fx);
   hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im1, s1x, s1y, (const double*)stats.as<double>(), 0, a.as<double>(), Fx, Fy);
   hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im2, s2x, s2y, (const double*)(stats.as<double>() + 2), 1, b.as<double>(), Fx, Fy);
-  Plan fwd, inv;
-  IA3_FFT(hipfftPlan2d(&fwd.h, Fx, Fy, HIPFFT_D2Z)); fwd.ok = true;
-  IA3_FFT(hipfftPlan2d(&inv.h, Fx, Fy, HIPFFT_Z2D)); inv.ok = true;
-  IA3_FFT(hipfftSetStream(fwd.h, st));
-  IA3_FFT(hipfftSetStream(inv.h, st));
-  IA3_FFT(hipfftExecD2Z(fwd.h, a.as<double>(), fa.as<cplx>()));
-  IA3_FFT(hipfftExecD2Z(fwd.h, b.as<double>(), fb.as<cplx>()));
+  hipfftHandle fwd, inv;
+  { int prc = get_plan(HIPFFT_D2Z, Fx, Fy, 0, st, &fwd); if (prc) return prc; }
+  { int prc = get_plan(HIPFFT_Z2D, Fx, Fy, 0, st, &inv); if (prc) return prc; }
+  IA3_FFT(hipfftExecD2Z(fwd, a.as<double>(), fa.as<cplx>()));
+  IA3_FFT(hipfftExecD2Z(fwd, b.as<double>(), fb.as<cplx>()));
   hipLaunchKernelGGL(cmul_k, dim3((unsigned)((ncplx + 255) / 256)), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), ncplx);
-  IA3_FFT(hipfftExecZ2D(inv.h, fa.as<cplx>(), a.as<double>()));
+  IA3_FFT(hipfftExecZ2D(inv, fa.as<cplx>(), a.as<double>()));
   // window (alignment_tools.py:301-308)
   const double c0 = center[0] + cx / 2.0, c1 = center[1] + cy / 2.0;
   auto clampi = [](double v, int hi) { v = v < 0 ? 0 : v; v = v > hi ? hi : v; return (int)v; };
@@ -224,12 +249,20 @@ __global__ __launch_bounds__(256) void abs_argmax_part_k(const cplx* __restrict_
   }
   if (threadIdx.x == 0) { pv[blockIdx.x] = sv[0]; pi[blockIdx.x] = si[0]; }
 }
-// sum of |a|^2 (single block)
-__global__ __launch_bounds__(1024) void abs2_sum_k(const cplx* __restrict__ a, size_t n, double* out) {
-  __shared__ double sh[1024];
+// sum of |a|^2: fixed grid of partial sums, then one block adds the partials in index order (deterministic)
+constexpr int ABS2_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void abs2_part_k(const cplx* __restrict__ a, size_t n, double* __restrict__ part) {
+  __shared__ double sh[256];
   double s = 0;
-  for (size_t i = threadIdx.x; i < n; i += 1024) s += a[i].x * a[i].x + a[i].y * a[i].y;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)ABS2_BLOCKS * 256) s += a[i].x * a[i].x + a[i].y * a[i].y;
   sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(1024) void abs2_sum_k(const double* __restrict__ part, double* out) {
+  __shared__ double sh[1024];
+  sh[threadIdx.x] = threadIdx.x < ABS2_BLOCKS ? part[threadIdx.x] : 0.0;
   __syncthreads();
   for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
   if (threadIdx.x == 0) *out = sh[0];
@@ -375,8 +408,8 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
   hipStream_t st = stream();
   const int Z = ref->Z, X = ref->X, Y = ref->Y;
   const size_t n = (size_t)Z * X * Y;
-  Scratch fa(n * sizeof(cplx)), fb(n * sizeof(cplx)), sums(2 * sizeof(double));
-  if (!fa.p || !fb.p || !sums.p) return IA3_ENOMEM;
+  Scratch fa(n * sizeof(cplx)), fb(n * sizeof(cplx)), sums(2 * sizeof(double)), parts(ABS2_BLOCKS * sizeof(double));
+  if (!fa.p || !fb.p || !sums.p || !parts.p) return IA3_ENOMEM;
   const unsigned nb = (unsigned)((n + 255) / 256);
   ProfScope ps("phase_xcorr3d");
   if (ref->dtype == IA3_F32) {
@@ -386,16 +419,17 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)ref->d, fa.as<cplx>(), n);
     hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)mov->d, fb.as<cplx>(), n);
   }
-  Plan plan;
-  IA3_FFT(hipfftPlan3d(&plan.h, Z, X, Y, HIPFFT_Z2Z)); plan.ok = true;
-  IA3_FFT(hipfftSetStream(plan.h, st));
-  IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
-  IA3_FFT(hipfftExecZ2Z(plan.h, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
-  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const cplx*)fa.as<cplx>(), n, sums.as<double>());
-  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const cplx*)fb.as<cplx>(), n, sums.as<double>() + 1);
+  hipfftHandle plan;
+  { int prc = get_plan(HIPFFT_Z2Z, Z, X, Y, st, &plan); if (prc) return prc; }
+  IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
+  IA3_FFT(hipfftExecZ2Z(plan, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
+  hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fa.as<cplx>(), n, parts.as<double>());
+  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
+  hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fb.as<cplx>(), n, parts.as<double>());
+  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>() + 1);
   hipLaunchKernelGGL(cross_power_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), n, normalization);
   // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
-  IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
+  IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
   IA3_KCHECK();
   long long idx; double v2;
   rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;

@@ -337,6 +337,21 @@ def test_align_image_bead_path_golden():
     assert np.allclose(drift, -g["bead_true_d"], atol=0.02)
 
 
+def test_align_image_resident_inputs_equal_host_inputs():
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.correction_tools.alignment import align_image
+    shape = (24, 256, 256)
+    ref, src, c, h = synth.make_bead_pair(shape, 60, 9, (0.4, -2.3, 3.1), margin=(4, 12, 12), min_sep=10.0)
+    a, b = L.DeviceStack.upload(src), L.DeviceStack.upload(ref)
+    try:
+        for auto in (True, False):
+            d0, f0 = align_image(src, ref, use_autocorr=auto, verbose=False, correction_args={'single_im_size': shape})
+            d1, f1 = align_image(a, b, use_autocorr=auto, verbose=False, correction_args={'single_im_size': shape})
+            assert f0 == f1 and np.array_equal(d0, d1)
+    finally:
+        a.free(); b.free()
+
+
 def test_pairing_golden():
     from imageanalysis3_amd.spot_tools.matching import find_paired_centers, check_paired_centers
     g = load_golden("drift.npz")
