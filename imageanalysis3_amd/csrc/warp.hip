@@ -90,57 +90,117 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
   }
 }
 
-// IIR along the contiguous axis: 64 lines per block, marched in 64-element tiles transposed through LDS
-__global__ __launch_bounds__(64) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
-  __shared__ double tile[64][65];
-  const int t = threadIdx.x;
-  const size_t l0 = (size_t)blockIdx.x * 64;
+// Padding and the axis-0 recursion in one pass: a padded z line (<= ZMAX samples) lives in registers, so the padded
+// float64 volume is written once instead of written, read, written, read and written again.  Same operations in the
+// same order as spline_pad_k followed by spline_iir_strided_k with the faithful (full) start sum.
+template <class T, int ZMAX>
+__global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict__ im, int Z, int X, int Y, double* __restrict__ P,
+                                                         IirInit q) {
+  const int Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD, n = Z + 2 * NPAD;
+  const size_t plane = (size_t)Xp * Yp;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= plane) return;
+  const int x = (int)(p / Yp), y = (int)(p - (size_t)x * Yp);
+  const size_t src = (size_t)clampi(x - NPAD, X) * Y + clampi(y - NPAD, Y);
   const double z = q.z, g = q.gain;
-  const int ntile = (n + 63) / 64;
+  const size_t zs = (size_t)X * Y;
+  auto ld = [&](int i) { return (double)im[(size_t)clampi(i - NPAD, Z) * zs + src] * g; };
+  // start value of the causal recursion: the faithful sum over the whole line, streamed from the source
+  const double c0 = ld(0);
+  double s = c0 + q.zn * ld(n - 1), zi = z;
+  for (int i = 1; i < n; ++i) {
+    s += zi * (ld(i) + q.zn * ld(n - 1 - i));
+    zi *= z;
+  }
+  double c[ZMAX];
+#pragma unroll
+  for (int i = 0; i < ZMAX; ++i) c[i] = i < n ? ld(i) : 0.0;
+  s *= q.scale;
+  s += c0;
+  double prev = s;
+  c[0] = prev;
+#pragma unroll
+  for (int i = 1; i < ZMAX; ++i) if (i < n) { const double v = c[i] + z * prev; c[i] = v; prev = v; }
+  prev = prev * (z / (z - 1.0));
+#pragma unroll
+  for (int i = ZMAX - 1; i >= 0; --i) {
+    if (i == n - 1) c[i] = prev;
+    else if (i < n - 1) { const double v = z * (prev - c[i]); c[i] = v; prev = v; }
+  }
+#pragma unroll
+  for (int i = 0; i < ZMAX; ++i) if (i < n) P[(size_t)i * plane + p] = c[i];
+}
+
+// IIR along the contiguous axis: every wave owns 64 lines (lane = line) and marches them in TW-element tiles that
+// are transposed through a wave-private LDS tile (row pieces of TW doubles = one 128-B line for TW = 16); narrow
+// tiles keep the LDS footprint at 8.7 KB per wave, so 16 waves per CU hide the latency of the serial recursion.
+template <int TW>
+__global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
+  constexpr int RPI = 64 / TW;   // rows moved per wave instruction
+  __shared__ double tile[4][64][TW + 1];
+  const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const size_t l0 = ((size_t)blockIdx.x * 4 + wv) * 64;
+  if (l0 >= n_lines) return;                 // whole wave
+  const bool mine = l0 + t < n_lines;
+  const int col = t % TW, rsub = t / TW;
+  const double z = q.z, g = q.gain;
+  const int ntile = (n + TW - 1) / TW;
   double prev = 0.0;
-  for (int k = 0; k < ntile; ++k) {  // causal
-    const int y0 = k * 64, w = n - y0 < 64 ? n - y0 : 64;
-    for (int r = 0; r < 64; ++r)
-      if (l0 + r < n_lines && t < w) tile[r][t] = P[(l0 + r) * n + y0 + t] * g;
-    __syncthreads();
-    if (l0 + t < n_lines) {
-      int i0 = 0;
-      if (k == 0) {
-        const double c0 = tile[t][0];
-        double s = c0, zi = z;
-        if (q.full) {  // n <= 64 here: whole line is in this tile
-          s = c0 + q.zn * tile[t][n - 1];
-          for (int i = 1; i < n; ++i) { s += zi * (tile[t][i] + q.zn * tile[t][n - 1 - i]); zi *= z; }
-        } else {
-          for (int i = 1; i < w; ++i) { s += zi * tile[t][i]; zi *= z; }
-        }
-        s *= q.scale;
-        s += c0;
-        tile[t][0] = s;
-        prev = s;
-        i0 = 1;
-      }
-      for (int i = i0; i < w; ++i) { double v = tile[t][i] + z * prev; tile[t][i] = v; prev = v; }
+  if (mine) {   // start value of the causal recursion (see make_init), read straight from the line
+    const double* line = P + (l0 + t) * (size_t)n;
+    const double c0 = line[0] * g;
+    double s, zi = z;
+    if (q.full) {
+      s = c0 + q.zn * (line[n - 1] * g);
+      for (int i = 1; i < n; ++i) { s += zi * (line[i] * g + q.zn * (line[n - 1 - i] * g)); zi *= z; }
+    } else {
+      s = c0;
+      const int m = n < 64 ? n : 64;
+      for (int i = 1; i < m; ++i) { s += zi * (line[i] * g); zi *= z; }
     }
-    __syncthreads();
-    for (int r = 0; r < 64; ++r)
-      if (l0 + r < n_lines && t < w) P[(l0 + r) * n + y0 + t] = tile[r][t];
-    __syncthreads();
+    s *= q.scale;
+    s += c0;
+    prev = s;
+  }
+  auto load_tile = [&](int y0, int w, double scale) {
+#pragma unroll 4
+    for (int r0 = 0; r0 < 64; r0 += RPI) {
+      const int r = r0 + rsub;
+      if (l0 + r < n_lines && col < w) tile[wv][r][col] = P[(l0 + r) * (size_t)n + y0 + col] * scale;
+    }
+  };
+  auto store_tile = [&](int y0, int w) {
+#pragma unroll 4
+    for (int r0 = 0; r0 < 64; r0 += RPI) {
+      const int r = r0 + rsub;
+      if (l0 + r < n_lines && col < w) P[(l0 + r) * (size_t)n + y0 + col] = tile[wv][r][col];
+    }
+  };
+  for (int k = 0; k < ntile; ++k) {  // causal
+    const int y0 = k * TW, w = n - y0 < TW ? n - y0 : TW;
+    load_tile(y0, w, g);
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+      int i0 = 0;
+      if (k == 0) { tile[wv][t][0] = prev; i0 = 1; }
+      for (int i = i0; i < w; ++i) { const double v = tile[wv][t][i] + z * prev; tile[wv][t][i] = v; prev = v; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    store_tile(y0, w);
+    __builtin_amdgcn_wave_barrier();
   }
   for (int k = ntile - 1; k >= 0; --k) {  // anticausal
-    const int y0 = k * 64, w = n - y0 < 64 ? n - y0 : 64;
-    for (int r = 0; r < 64; ++r)
-      if (l0 + r < n_lines && t < w) tile[r][t] = P[(l0 + r) * n + y0 + t];
-    __syncthreads();
-    if (l0 + t < n_lines) {
+    const int y0 = k * TW, w = n - y0 < TW ? n - y0 : TW;
+    load_tile(y0, w, 1.0);
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
       int i1 = w - 1;
-      if (k == ntile - 1) { prev = tile[t][w - 1] * (z / (z - 1.0)); tile[t][w - 1] = prev; i1 = w - 2; }
-      for (int i = i1; i >= 0; --i) { double v = z * (prev - tile[t][i]); tile[t][i] = v; prev = v; }
+      if (k == ntile - 1) { prev = tile[wv][t][w - 1] * (z / (z - 1.0)); tile[wv][t][w - 1] = prev; i1 = w - 2; }
+      for (int i = i1; i >= 0; --i) { const double v = z * (prev - tile[wv][t][i]); tile[wv][t][i] = v; prev = v; }
     }
-    __syncthreads();
-    for (int r = 0; r < 64; ++r)
-      if (l0 + r < n_lines && t < w) P[(l0 + r) * n + y0 + t] = tile[r][t];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    store_tile(y0, w);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -263,14 +323,19 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   if (!P.p) return IA3_ENOMEM;
   {
     ProfScope ps("spline_prefilter");
-    hipLaunchKernelGGL((spline_pad_k<T>), dim3((unsigned)((Yp + 255) / 256), (unsigned)Xp, (unsigned)Zp), dim3(256), 0, st,
-                       (const T*)im->d, Z, X, Y, P.as<double>());
     const size_t plane = (size_t)Xp * Yp;
     // axis 0: lines = (x,y) columns, stride = plane
     IirInit qz = make_init(Zp);
-    qz.full = 1;  // the strided kernel can always afford the faithful sum along the short z axis
-    hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(),
-                       (int)plane, plane, Zp, (size_t)0, qz);
+    qz.full = 1;  // the faithful start sum is always affordable along the short z axis
+    if (Zp <= 80) {   // padded line fits in registers: pad + axis-0 recursion in one pass
+      hipLaunchKernelGGL((spline_pad_iir0_k<T, 80>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const T*)im->d, Z, X, Y,
+                         P.as<double>(), qz);
+    } else {
+      hipLaunchKernelGGL((spline_pad_k<T>), dim3((unsigned)((Yp + 255) / 256), (unsigned)Xp, (unsigned)Zp), dim3(256), 0, st,
+                         (const T*)im->d, Z, X, Y, P.as<double>());
+      hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(),
+                         (int)plane, plane, Zp, (size_t)0, qz);
+    }
     // axis 1: lines = (z,y), stride = Yp
     IirInit qx = make_init(Xp);
     if (Xp <= 256) qx.full = 1;
@@ -279,7 +344,7 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     // axis 2: contiguous lines (z,x)
     IirInit qy = make_init(Yp);
     const size_t nl = (size_t)Zp * Xp;
-    hipLaunchKernelGGL(spline_iir_contig_k, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, P.as<double>(), nl, Yp, qy);
+    hipLaunchKernelGGL((spline_iir_contig_k<16>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, P.as<double>(), nl, Yp, qy);
   }
   {
     ProfScope ps("warp_cubic");
