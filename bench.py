@@ -58,6 +58,20 @@ def algorithmic_bytes(kernel, shape, esize=4):
     return None
 
 
+def measured_traffic(kernel, shape):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json: separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 read correction applied), or None when there is
+    no measurement for this kernel and stack shape.  Counters cannot be collected from inside the timed run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if list(t.get("_shape", [])) != list(shape) or kernel not in t:
+            return None
+        return int(t[kernel]["read"] + t[kernel]["write"])
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +166,7 @@ def main():
             avg_s = dom_ms / dom_n * 1e-3
             ach = algorithmic_bytes(dom_name, shape) / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom_name, shape),
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": dom_n,
                     "note": "exact scipy.ndimage arithmetic (f64, no FMA) makes the Gaussian passes "
                             "f64-VALU-bound: see valu_frac"}
