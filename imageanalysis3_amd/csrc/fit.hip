@@ -70,21 +70,43 @@ struct FitArgs {
   double iw[3] = {0, 0, 0};   // variant 1: start widths in w_ space
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+// ---- single-value wave reductions without LDS: four DPP rotations inside the 16-lane rows, then the two row /
+// half-wave swaps of gfx950 (v_permlane16_swap / v_permlane32_swap with the value as both operands) -----------------
+__device__ __forceinline__ double lane_mk(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+template <int N>
+__device__ __forceinline__ double lane_ror(double v) {   // value of the lane N places further along the same row
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | N, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | N, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// the partner copies of v across the row pairs (0<->1, 2<->3) and across the half-waves
+__device__ __forceinline__ void lane_swap16(double v, double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  a = lane_mk(lo[0], hi[0]); b = lane_mk(lo[1], hi[1]);   // a = even row of the pair, b = odd row, in every lane of the pair
+}
+__device__ __forceinline__ void lane_swap32(double v, double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  a = lane_mk(lo[0], hi[0]); b = lane_mk(lo[1], hi[1]);   // a = lower half's value, b = upper half's, in both halves
+}
+struct OpSum { __device__ __forceinline__ double operator()(double x, double y) const { return x + y; } };
+struct OpMin { __device__ __forceinline__ double operator()(double x, double y) const { return y < x ? y : x; } };
+struct OpMax { __device__ __forceinline__ double operator()(double x, double y) const { return y > x ? y : x; } };
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+  v = op(v, lane_ror<8>(v));
+  v = op(v, lane_ror<4>(v));
+  v = op(v, lane_ror<2>(v));
+  v = op(v, lane_ror<1>(v));
+  double a, b;
+  lane_swap16(v, a, b); v = op(a, b);
+  lane_swap32(v, a, b); v = op(a, b);
   return v;
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { double o = __shfl_xor(v, m); v = o < v ? o : v; }
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { double o = __shfl_xor(v, m); v = o > v ? o : v; }
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, OpSum()); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, OpMin()); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, OpMax()); }
 
 // Cross-wave hand-off of per-seed results (persistent kernel below): every store of the handed-off words is a
 // relaxed agent-scope atomic (write-through `sc1`), every load of them a relaxed agent-scope atomic (`sc1`, served
@@ -107,6 +129,32 @@ struct Ball {
   float cz[SLOTS], cx[SLOTS], cy[SLOTS];   // voxel coordinates (exact small integers)
   unsigned valid;                          // bit s: slot s holds a voxel
 };
+
+// ---- cross-lane sums of many values at once (gfx950) -----------------------------------------------------------
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows of TWO registers in one VALU instruction,
+// so one add folds two values by one butterfly level ("reduce-scatter"): 2N values -> N registers (xor 32) -> N/2
+// registers (xor 16), each then holding four different values in its four 16-lane rows; the remaining four levels
+// run inside the rows with DPP rotations.  65 values cost ~350 VALU instructions instead of 65 x 6 x (2 ds_bpermute +
+// add) = 1170 with LDS round trips.
+// lanes 0-31: x[l] + x[l+32];  lanes 32-63: y[l-32] + y[l]
+__device__ __forceinline__ double swap32_add(double x, double y) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return lane_mk(lo[0], hi[0]) + lane_mk(lo[1], hi[1]);
+}
+// rows of 16 lanes: row0 = p.row0 + p.row1, row1 = q.row0 + q.row1, row2 = p.row2 + p.row3, row3 = q.row2 + q.row3
+__device__ __forceinline__ double swap16_add(double p, double q) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p), (unsigned)__double2hiint(q), false, false);
+  return lane_mk(lo[0], hi[0]) + lane_mk(lo[1], hi[1]);
+}
+__device__ __forceinline__ double row_sum16(double v) {   // every lane of a row ends with the row's total
+  v = v + lane_ror<8>(v);
+  v = v + lane_ror<4>(v);
+  v = v + lane_ror<2>(v);
+  v = v + lane_ror<1>(v);
+  return v;
+}
 
 // Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
 struct WaveEval {
@@ -140,10 +188,33 @@ struct WaveEval {
       }
       nbad += __popcll(__ballot(r_inf)) + 2 * __popcll(__ballot(r_nan));
     }
+    // sum the 65 partials over the wave: 65 -> 34 -> 17 registers by pairwise lane swaps, then inside the rows
+    {
+      constexpr int NV = NTRI + NP;            // 65
+      constexpr int N1 = (NV + 1) / 2;         // 33 registers after the xor-32 level
+      constexpr int N2 = (N1 + 1) / 2;         // 17 after the xor-16 level, four values each
+      double p1[N1 + 1];
 #pragma unroll
-    for (int k = 0; k < NTRI; ++k) A[k] = wave_sum(a[k]);
+      for (int m = 0; m < N1; ++m) {
+        const double x = 2 * m < NTRI ? a[2 * m] : gg[2 * m - NTRI];
+        const double y = 2 * m + 1 < NTRI ? a[2 * m + 1] : (2 * m + 1 < NV ? gg[2 * m + 1 - NTRI] : 0.0);
+        p1[m] = swap32_add(x, y);
+      }
+      p1[N1] = 0.0;
+      const int lane = threadIdx.x & 63, row = lane >> 4;
+      // row r of register n holds value 4n + {0, 2, 1, 3}[r]
+      const int sel = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
 #pragma unroll
-    for (int k = 0; k < NP; ++k) g[k] = wave_sum(gg[k]);
+      for (int n = 0; n < N2; ++n) {
+        const double tot = row_sum16(swap16_add(p1[2 * n], p1[2 * n + 1]));
+        const int vi = 4 * n + sel;
+        if ((lane & 15) == 0) {
+          if (vi < NTRI) A[vi] = tot;
+          else if (vi < NV) g[vi - NTRI] = tot;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // A, g live in LDS: later reads by every lane follow these writes in order
+    }
     // MINPACK's enorm (scaled sums) returns NaN, not inf, as soon as two components are infinite (inf/inf) or one
     // is NaN; lmder's tests `0.1*fnorm1 < fnorm` and `0.1*fnorm1 >= fnorm` are then both false, which changes
     // the trust-region update.  Reached by the legacy model (no clip on the background exponent) when a trial
