@@ -157,8 +157,11 @@ __device__ __forceinline__ double row_sum16(double v) {   // every lane of a row
 }
 
 // Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
+struct BallLds { float dat[SLOTS][64], cz[SLOTS][64], cx[SLOTS][64], cy[SLOTS][64]; };   // [slot][lane]: 8 KB per wave
+
 struct WaveEval {
-  const Ball* b;
+  const BallLds* b;   // the evaluation is not inlined into the solver: voxel data parked in LDS (not in scratch memory)
+  unsigned valid;     // bit s: slot s of this lane holds a voxel
   FitCfg cfg;
   __device__ double eval(const double* x, double* A, double* g) {
     Geom gm;
@@ -172,10 +175,11 @@ struct WaveEval {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       bool r_inf = false, r_nan = false;
-      if (b->valid & (1u << s)) {
+      if (valid & (1u << s)) {
+        const int ln = threadIdx.x & 63;
         double J[NP];
-        double F = model_jac(gm, (double)b->cz[s], (double)b->cx[s], (double)b->cy[s], J);
-        double r = (gm.ebk_f + F) - (double)b->dat[s];
+        double F = model_jac(gm, (double)b->cz[s][ln], (double)b->cx[s][ln], (double)b->cy[s][ln], J);
+        double r = (gm.ebk_f + F) - (double)b->dat[s][ln];
         r_nan = r != r;
         r_inf = !r_nan && (r - r != 0.0);
         ss += r * r;
@@ -260,8 +264,17 @@ __device__ __forceinline__ void wave_extremes(const double* v, unsigned valid, d
 // vals: float64 data before the float32 cast (used for the start point only, :175-182).
 __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const Ball& ball, const double* vals,
                                              int kind, const double* c0, double delta, int n, float* p_out) {
+  __shared__ BallLds bl;   // one wave per block
+  {
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      bl.dat[sl][ln] = ball.dat[sl]; bl.cz[sl][ln] = ball.cz[sl]; bl.cx[sl][ln] = ball.cx[sl]; bl.cy[sl][ln] = ball.cy[sl];
+    }
+  }
   WaveEval ev;
-  ev.b = &ball;
+  ev.b = &bl;
+  ev.valid = ball.valid;
   ev.cfg.min_ws = fa.min_ws; ev.cfg.max_ws = fa.max_ws; ev.cfg.delta = delta; ev.cfg.init_w = fa.init_w;
   ev.cfg.c0[0] = c0[0]; ev.cfg.c0[1] = c0[1]; ev.cfg.c0[2] = c0[2];
   ev.cfg.variant = fa.variant; ev.cfg.iw[0] = fa.iw[0]; ev.cfg.iw[1] = fa.iw[1]; ev.cfg.iw[2] = fa.iw[2];

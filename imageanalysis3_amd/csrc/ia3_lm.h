@@ -113,28 +113,28 @@ IA3_HD double lm_norm(const double* v) {
 }
 
 // lmpar on the normal equations: find par with | |D x| - delta | <= 0.1 delta, x = (A+par D²)⁻¹ g
-IA3_HD void lm_par(const LMWork& w, double delta, double& par, double* x) {
+IA3_HD void lm_par(const double* A, const double* g, const double* diag, double delta, double& par, double* x) {
   Chol c;
   double t1[NP], t2[NP];
-  lm_factor(w.A, w.diag, 0.0, c);
-  lm_fwd(c, w.g, t1);
+  lm_factor(A, diag, 0.0, c);
+  lm_fwd(c, g, t1);
   lm_bwd(c, t1, x);
   int iter = 0;
   IA3_UNROLL
-  for (int j = 0; j < NP; ++j) t2[j] = w.diag[j] * x[j];
+  for (int j = 0; j < NP; ++j) t2[j] = diag[j] * x[j];
   double dxnorm = lm_norm(t2);
   double fp = dxnorm - delta;
   if (fp <= 0.1 * delta) { par = 0.0; return; }
   double parl = 0.0;
   if (c.skip == 0) {
     IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t1[j] = w.diag[j] * (t2[j] / dxnorm);
+    for (int j = 0; j < NP; ++j) t1[j] = diag[j] * (t2[j] / dxnorm);
     lm_fwd(c, t1, t1);
     double temp = lm_norm(t1);
     parl = ((fp / delta) / temp) / temp;
   }
   IA3_UNROLL
-  for (int j = 0; j < NP; ++j) t1[j] = w.g[j] / w.diag[j];
+  for (int j = 0; j < NP; ++j) t1[j] = g[j] / diag[j];
   double gnorm = lm_norm(t1);
   double paru = gnorm / delta;
   if (paru == 0.0) paru = IA3_DWARF / (delta < 0.1 ? delta : 0.1);
@@ -144,17 +144,17 @@ IA3_HD void lm_par(const LMWork& w, double delta, double& par, double* x) {
   for (;;) {
     ++iter;
     if (par == 0.0) { double t = 0.001 * paru; par = IA3_DWARF > t ? IA3_DWARF : t; }
-    lm_factor(w.A, w.diag, par, c);
-    lm_fwd(c, w.g, t1);
+    lm_factor(A, diag, par, c);
+    lm_fwd(c, g, t1);
     lm_bwd(c, t1, x);
     IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t2[j] = w.diag[j] * x[j];
+    for (int j = 0; j < NP; ++j) t2[j] = diag[j] * x[j];
     dxnorm = lm_norm(t2);
     double temp = fp;
     fp = dxnorm - delta;
     if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
     IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t1[j] = w.diag[j] * (t2[j] / dxnorm);
+    for (int j = 0; j < NP; ++j) t1[j] = diag[j] * (t2[j] / dxnorm);
     lm_fwd(c, t1, t1);
     temp = lm_norm(t1);
     double parc = ((fp / delta) / temp) / temp;
@@ -170,11 +170,15 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
                          double factor) {
   LMResult r;
   r.info = 0; r.nfev = 1; r.iter = 1;
-  double fnorm = ev.eval(w.x, w.A, w.g);
+  // JᵀJ / Jᵀf of the accepted point and of the trial point ping-pong between the two halves of the work area:
+  // accepting a step swaps the pointers instead of copying 65 values through LDS
+  double* Ac = w.A; double* gc = w.g;      // current accepted point
+  double* At = w.A1; double* gt = w.g1;    // trial point
+  double fnorm = ev.eval(w.x, Ac, gc);
   double par = 0.0, delta = 0.0, xnorm = 0.0;
   for (;;) {  // outer loop: A, g hold JᵀJ, Jᵀf at x
     IA3_UNROLL
-    for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(w.A[tri(j, j)]);
+    for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(Ac[tri(j, j)]);
     if (r.iter == 1) {
       double t[NP];
       IA3_UNROLL
@@ -191,7 +195,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
         if (w.cn[j] != 0.0) {
-          double v = fabs((w.g[j] / fnorm) / w.cn[j]);
+          double v = fabs((gc[j] / fnorm) / w.cn[j]);
           gnorm = gnorm > v ? gnorm : v;
         }
       }
@@ -201,7 +205,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
     for (int j = 0; j < NP; ++j) w.diag[j] = w.diag[j] > w.cn[j] ? w.diag[j] : w.cn[j];
     for (;;) {  // inner loop
       double pv[NP], t[NP];
-      lm_par(w, delta, par, pv);
+      lm_par(Ac, gc, w.diag, delta, par, pv);
       IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
         pv[j] = -pv[j];
@@ -218,11 +222,11 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       for (int i = 0; i < NP; ++i) {
         double s = 0.0;
         IA3_UNROLL
-        for (int j = 0; j < NP; ++j) s += (i <= j ? w.A[tri(i, j)] : w.A[tri(j, i)]) * pv[j];
+        for (int j = 0; j < NP; ++j) s += (i <= j ? Ac[tri(i, j)] : Ac[tri(j, i)]) * pv[j];
         jp2 += pv[i] * s;
       }
       if (jp2 < 0.0) jp2 = 0.0;
-      double fnorm1 = ev.eval(w.xt, w.A1, w.g1);
+      double fnorm1 = ev.eval(w.xt, At, gt);
       ++r.nfev;
       double actred = -1.0;
       if (0.1 * fnorm1 < fnorm) { double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
@@ -245,9 +249,8 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       }
       if (ratio >= 1e-4) {  // successful iteration
         IA3_UNROLL
-        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; t[j] = w.diag[j] * w.xt[j]; w.g[j] = w.g1[j]; }
-        IA3_UNROLL
-        for (int k = 0; k < NTRI; ++k) w.A[k] = w.A1[k];
+        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; t[j] = w.diag[j] * w.xt[j]; }
+        { double* sw = Ac; Ac = At; At = sw; sw = gc; gc = gt; gt = sw; }
         xnorm = lm_norm(t);
         fnorm = fnorm1;
         ++r.iter;
