@@ -160,12 +160,14 @@ __device__ __forceinline__ double row_sum16(double v) {   // every lane of a row
 struct BallLds { float dat[SLOTS][64], cz[SLOTS][64], cx[SLOTS][64], cy[SLOTS][64]; };   // [slot][lane]: 8 KB per wave
 
 struct WaveEval {
-  const BallLds* b;   // the evaluation is not inlined into the solver: voxel data parked in LDS (not in scratch memory)
+  // the evaluation is not inlined into the solver, so this object lives in memory: keep it to two LDS pointers and a
+  // mask (voxel data and the fit configuration are parked in LDS, not in scratch memory)
+  const BallLds* b;
+  const FitCfg* cfgp;
   unsigned valid;     // bit s: slot s of this lane holds a voxel
-  FitCfg cfg;
   __device__ double eval(const double* x, double* A, double* g) {
     Geom gm;
-    make_geom(x, cfg, gm);
+    make_geom(x, *cfgp, gm);
     double a[NTRI], gg[NP], ss = 0.0;
 #pragma unroll
     for (int k = 0; k < NTRI; ++k) a[k] = 0.0;
@@ -272,19 +274,23 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const
       bl.dat[sl][ln] = ball.dat[sl]; bl.cz[sl][ln] = ball.cz[sl]; bl.cx[sl][ln] = ball.cx[sl]; bl.cy[sl][ln] = ball.cy[sl];
     }
   }
+  __shared__ FitCfg cfg_sh;   // wave-uniform: every lane writes the same values
+  cfg_sh.min_ws = fa.min_ws; cfg_sh.max_ws = fa.max_ws; cfg_sh.delta = delta; cfg_sh.init_w = fa.init_w;
+  cfg_sh.c0[0] = c0[0]; cfg_sh.c0[1] = c0[1]; cfg_sh.c0[2] = c0[2];
+  cfg_sh.variant = fa.variant; cfg_sh.iw[0] = fa.iw[0]; cfg_sh.iw[1] = fa.iw[1]; cfg_sh.iw[2] = fa.iw[2];
+  __builtin_amdgcn_wave_barrier();
+  const FitCfg& cfg = cfg_sh;
   WaveEval ev;
   ev.b = &bl;
+  ev.cfgp = &cfg_sh;
   ev.valid = ball.valid;
-  ev.cfg.min_ws = fa.min_ws; ev.cfg.max_ws = fa.max_ws; ev.cfg.delta = delta; ev.cfg.init_w = fa.init_w;
-  ev.cfg.c0[0] = c0[0]; ev.cfg.c0[1] = c0[1]; ev.cfg.c0[2] = c0[2];
-  ev.cfg.variant = fa.variant; ev.cfg.iw[0] = fa.iw[0]; ev.cfg.iw[1] = fa.iw[1]; ev.cfg.iw[2] = fa.iw[2];
   double lo10[10], hi10[10];
   wave_extremes(vals, ball.valid, lo10, hi10);
-  init_guess(lo10, hi10, kind, ev.cfg, w.x);
+  init_guess(lo10, hi10, kind, cfg, w.x);
   LMResult r = lm_solve(ev, w, fa.ftol, fa.xtol, fa.gtol, fa.maxfev, fa.factor);
-  to_natural(w.x, ev.cfg, p_out);
+  to_natural(w.x, cfg, p_out);
   Geom gm;
-  make_geom(w.x, ev.cfg, gm);
+  make_geom(w.x, cfg, gm);
   double s = 0.0;
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl)

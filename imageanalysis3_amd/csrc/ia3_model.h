@@ -32,8 +32,8 @@ struct FitCfg {
   // model variant: 0 = External/Fitting_v4.py (production); 1 = External/Fitting_v3.py (legacy
   // `_fit_single_image` path, classes/__init__.py:57-88): per-axis start widths (Fitting_v3.py:71-79) and its
   // to_center (:81-87), whose third coordinate mixes the second and third offsets.
-  int variant = 0;
-  double iw[3] = {0, 0, 0};   // variant 1: start value of the three width parameters (already in w_ space)
+  int variant;     // set it: no default member initialisers, the struct also lives in LDS
+  double iw[3];    // variant 1: start value of the three width parameters (already in w_ space)
 };
 
 // log(DBL_MAX): the reference's overflow guard (np.log(np.finfo(float64).max)); parameters

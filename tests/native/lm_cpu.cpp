@@ -49,7 +49,8 @@ extern "C" int ia3cpu_gaussfit(const double* vals, const int* coords, int n, con
   std::sort(sorted.begin(), sorted.end());
   CpuEval ev; ev.im = im.data(); ev.cz = cz.data(); ev.cx = cx.data(); ev.cy = cy.data(); ev.n = n;
   ev.cfg.min_ws = min_w * min_w; ev.cfg.max_ws = max_w * max_w; ev.cfg.delta = delta; ev.cfg.init_w = init_w;
-  for (int k = 0; k < 3; ++k) ev.cfg.c0[k] = center[k];
+  ev.cfg.variant = 0;
+  for (int k = 0; k < 3; ++k) { ev.cfg.c0[k] = center[k]; ev.cfg.iw[k] = 0.0; }
   LMWork w;
   init_guess(sorted.data(), sorted.data() + n - 10, kind, ev.cfg, w.x);
   LMResult r = lm_solve(ev, w, 1.49012e-8, 1.49012e-8, 0.0, 1000, 100.0);
