@@ -54,6 +54,16 @@ struct Scratch {  // RAII
                               hipGetErrorString(_e), __FILE__, __LINE__);                  \
   } while (0)
 
+// Work queued while an AuxScope is alive goes to a second stream that first waits for everything queued on the main
+// stream so far; aux_join() makes the main stream wait for it.  Used to run independent kernels side by side (a
+// VALU-bound one next to a memory/LDS-bound one).  Scratch blocks released inside the scope are recycled after the join.
+struct AuxScope {
+  bool ok;
+  AuxScope();
+  ~AuxScope();
+};
+int aux_join();
+
 // Optional per-kernel timing with HIP events on the library stream (ia3_profile_*): bench.py
 // derives roofline.achieved from these, rocprofv3 must agree.
 struct ProfScope {

@@ -13,6 +13,9 @@ namespace ia3rt {
 static thread_local char g_err[1024] = "";
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
+static hipStream_t g_aux = nullptr;       // second stream for work that is independent of the main queue
+static hipStream_t g_cur = nullptr;       // what stream() hands out (g_stream unless an AuxScope is open)
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
 static pid_t g_pid = 0;
 static int g_cus = 256;
 static std::mutex g_mu;
@@ -31,7 +34,7 @@ int set_error(int code, const char* fmt, ...) {
 static int do_init(int device) {
   // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
   if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
-  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_device = -1; }
+  if (g_pid != getpid()) { g_stream = nullptr; g_aux = nullptr; g_cur = nullptr; g_fork = g_join = nullptr; g_ws.clear(); g_device = -1; }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -56,7 +59,31 @@ int ensure_init() {
   std::lock_guard<std::mutex> lk(g_mu);
   return do_init(-1);
 }
-hipStream_t stream() { return g_stream; }
+static void ws_flush_deferred();
+hipStream_t stream() { return g_cur ? g_cur : g_stream; }
+
+// Everything launched while an AuxScope is alive goes to the auxiliary stream, which first waits for the work queued
+// on the main stream so far; the destructor makes the main stream wait for the auxiliary work only when join() is
+// called (typically right before the first consumer of its results).
+AuxScope::AuxScope() : ok(false) {
+  if (!g_stream) return;
+  if (!g_aux) {
+    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) { g_aux = nullptr; return; }
+    if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) return;
+  }
+  if (hipEventRecord(g_fork, g_stream) != hipSuccess || hipStreamWaitEvent(g_aux, g_fork, 0) != hipSuccess) return;
+  g_cur = g_aux;
+  ok = true;
+}
+AuxScope::~AuxScope() { g_cur = nullptr; }
+int aux_join() {
+  if (!g_aux) return IA3_OK;
+  if (hipEventRecord(g_join, g_aux) != hipSuccess || hipStreamWaitEvent(g_stream, g_join, 0) != hipSuccess)
+    return set_error(IA3_EHIP, "stream join failed");
+  ws_flush_deferred();
+  return IA3_OK;
+}
 int num_cus() { return g_cus; }
 
 void* ws_get(size_t bytes) {
@@ -77,9 +104,19 @@ void* ws_get(size_t bytes) {
   g_ws.push_back({p, bytes, true});
   return p;
 }
+// Reuse of a returned block is ordered by the main stream.  A block returned while an AuxScope is open may still be
+// in use by the auxiliary stream: it stays busy until aux_join() has put the join into the main queue.
+static std::vector<void*> g_deferred;
 void ws_put(void* p) {
   std::lock_guard<std::mutex> lk(g_mu);
+  if (g_cur) { g_deferred.push_back(p); return; }
   for (auto& e : g_ws) if (e.p == p) { e.busy = false; return; }
+}
+static void ws_flush_deferred() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (void* p : g_deferred)
+    for (auto& e : g_ws) if (e.p == p) { e.busy = false; break; }
+  g_deferred.clear();
 }
 void ws_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -87,7 +124,7 @@ void ws_release_all() {
 }
 
 // ---- profiling ----------------------------------------------------------------------------------
-struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfRec { const char* name; hipEvent_t a, b; hipStream_t st; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 
@@ -96,12 +133,13 @@ ProfScope::ProfScope(const char* name) : slot(-1) {
   ProfRec r;
   r.name = name;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-  (void)hipEventRecord(r.a, g_stream);
+  r.st = stream();
+  (void)hipEventRecord(r.a, r.st);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, g_stream);
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, g_recs[slot].st);
 }
 
 // NumPy's pairwise sum for a contiguous double vector (numpy/_core/src/umath/loops_utils.h.src)

@@ -441,25 +441,33 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     lev.th[i] = p.th_compare_f32 ? (double)(float)t : t;
   }
   // filtered stacks
-  Scratch a(bytes), b(bytes), tmp(bytes);
-  if (!a.p || !b.p || !tmp.p) return IA3_ENOMEM;
+  Scratch a(bytes), b(bytes), tmp(bytes), tmp2(bytes);   // tmp2: ping-pong buffer of the front filter (own stream)
+  if (!a.p || !b.p || !tmp.p || !tmp2.p) return IA3_ENOMEM;
   const void* maxim = im->d;
   const void* minim = im->d;
   std::vector<double> w; int R, rc;
+  // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
+  // background (long, f64-VALU-bound) one; the detector waits for both.
+  bool forked = false;
   if (p.gfilt_size > 0) {
     if (p.w_front) { w.assign(p.w_front, p.w_front + 2 * p.r_front + 1); R = p.r_front; }
     else gaussian_taps(p.gfilt_size, 4.0, w, R);
-    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp.p);
-    if (rc) return rc;
+    {
+      AuxScope aux;
+      forked = aux.ok;
+      rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp2.p);
+    }
+    if (rc) { if (forked) aux_join(); return rc; }
     maxim = a.p;
   }
   if (p.background_gfilt_size > 0) {
     if (p.w_back) { w.assign(p.w_back, p.w_back + 2 * p.r_back + 1); R = p.r_back; }
     else gaussian_taps(p.background_gfilt_size, 4.0, w, R);
     rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, b.p, tmp.p);
-    if (rc) return rc;
+    if (rc) { if (forked) aux_join(); return rc; }
     minim = b.p;
   }
+  if (forked) { rc = aux_join(); if (rc) return rc; }
   const double t1 = now_ms();
   double th_low = lev.th[0];
   for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
