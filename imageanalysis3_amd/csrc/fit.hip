@@ -706,9 +706,11 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   f->d_nvox = base + o; o += b_nvox;
   f->d_nfev = base + o; o += b_nfev;
   f->d_conv = base + o; o += b_conv;
-  f->d_niter = base + o; o += b_niter;
   f->d_counters = base + o; o += b_cnt;
   f->d_done = base + o; o += b_done;
+  // [n_iter | stage control | overflow flag | rows]: contiguous, so the results come back in ONE device-to-host
+  // copy (every separate copy into pageable memory costs a ~25 us round trip)
+  f->d_niter = base + o; o += b_niter;
   f->d_ctl = base + o; o += b_ctl;
   f->d_nbr_overflow = base + o; o += b_ovf;
   f->d_ps = base + o; o += b_ps;
@@ -842,22 +844,27 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
   if (!f) return set_error(IA3_EINVAL, "null fitter");
   hipStream_t st = stream();
   std::vector<SeedState> stv;
-  if (n_iter) { *n_iter = 0; if (f->n) IA3_HIP(hipMemcpyAsync(n_iter, f->d_niter, sizeof(int), hipMemcpyDeviceToHost, st)); }
+  if (n_iter) *n_iter = 0;
+  StageCtl hc = StageCtl{0u, 0, 0, 0};
+  int ovf = 0;
   if (f->n > 0) {
-    if (ps) IA3_HIP(hipMemcpyAsync(ps, f->d_ps, sizeof(float) * 11 * (size_t)f->n, hipMemcpyDeviceToHost, st));
+    // one copy: the three 256-byte control slots and the row table sit back to back in the pool
+    const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_niter);
+    const size_t rows = ps ? sizeof(float) * 11 * (size_t)f->n : 0;
+    std::vector<char>& hb = f->host_stage;
+    hb.resize(head + rows);
+    IA3_HIP(hipMemcpyAsync(hb.data(), f->d_niter, head + rows, hipMemcpyDeviceToHost, st));
     if (nvox) IA3_HIP(hipMemcpyAsync(nvox, f->d_nvox, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     if (success) {
       stv.resize(f->n);
       IA3_HIP(hipMemcpyAsync(stv.data(), f->d_state, sizeof(SeedState) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     }
+    IA3_HIP(hipStreamSynchronize(st));
+    if (n_iter) memcpy(n_iter, hb.data(), sizeof(int));
+    memcpy(&hc, hb.data() + ((char*)f->d_ctl - (char*)f->d_niter), sizeof(StageCtl));
+    memcpy(&ovf, hb.data() + ((char*)f->d_nbr_overflow - (char*)f->d_niter), sizeof(int));
+    if (rows) memcpy(ps, hb.data() + head, rows);
   }
-  StageCtl hc = StageCtl{0u, 0, 0, 0};
-  int ovf = 0;
-  if (f->n > 0) {
-    IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipMemcpyAsync(&ovf, f->d_nbr_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-  }
-  IA3_HIP(hipStreamSynchronize(st));
   if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
   if (ovf) return set_error(IA3_EUNSUPPORTED, "a seed has %d other seeds within 2*radius_fit (limit %d): field too dense", ovf, MAXNB);
   if (success) for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)stv[i].success;

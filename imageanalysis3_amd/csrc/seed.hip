@@ -266,7 +266,7 @@ namespace {
 // and the seed list never leaves HBM between the detector and the fitter.
 constexpr unsigned FIN_CAP = 8192;
 constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
-struct FinCtl { unsigned n_alive; int chosen; unsigned pad[2]; };
+struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; };   // the last two mirror SeedCtl: one read-back
 
 __device__ __forceinline__ unsigned fin_n(const SeedCtl* sctl) { return sctl->n_cand < FIN_CAP ? sctl->n_cand : FIN_CAP; }
 __device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h desc, then z, x, y desc (finish_seeds)
@@ -345,11 +345,12 @@ __global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sc
 }
 
 __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
-                                                     const FinCtl* __restrict__ fc, const unsigned* __restrict__ hotcnt,
+                                                     const FinCtl* fc, const unsigned* __restrict__ hotcnt,
                                                      int hot_th, const unsigned* __restrict__ rank, int max_num,
-                                                     double* __restrict__ zxy, double* __restrict__ hh) {
+                                                     double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw) {
   const unsigned n = fin_n(sctl);
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { fcw->n_cand = sctl->n_cand; fcw->overflow = sctl->overflow; }
   if (i >= n) return;
   const double th = lev.th[fc->chosen];
   const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
@@ -512,14 +513,14 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
           hipLaunchKernelGGL(fin_hot_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc, hot);
         hipLaunchKernelGGL(fin_rank_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, fc, (const unsigned*)hot, hot_th, rank);
         hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_CAP / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc,
-                           (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h));
+                           (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h), fc);
       }
       FinCtl hfc;
       fe = hipGetLastError();
-      if (fe == hipSuccess) fe = hipMemcpyAsync(&hctl, dctl, sizeof(SeedCtl), hipMemcpyDeviceToHost, s);
       if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
       if (fe == hipSuccess) fe = hipStreamSynchronize(s);
       if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe)); }
+      hctl.n_cand = hfc.n_cand; hctl.overflow = hfc.overflow;
       if (hctl.n_cand <= FIN_CAP && !hctl.overflow) {
         int n = (int)hfc.n_alive;
         if (p.max_num_seeds > 0 && p.max_num_seeds <= n) n = p.max_num_seeds;
