@@ -137,6 +137,91 @@ __global__ __launch_bounds__(256) void bleed_k(ChanPtrs ch, int C, int Z, size_t
   }
 }
 
+
+// ---- DaxProcesser variants (classes/preprocess.py:464-680): same stages with a min-max rescale to the full uint16
+// range.  Two passes over the inputs: (1) the corrected value of every voxel is formed and only its min / max are
+// kept (fixed grid of partials + one block; min/max do not depend on the order), (2) it is formed again, rescaled
+// exactly as NumPy evaluates `(im - min) / (max - min) * 65535 + 0`, clipped and truncated to uint16.
+constexpr int MM_BLOCKS = 1024;
+template <class P> __device__ __forceinline__ P illum_val(const uint16_t* im, const P* prof, size_t z, size_t plane, size_t i) {
+  return (P)(float)im[z * plane + i] / prof[i];          // im.astype(np.float32) / pf[None]: float32, or float64 for a float64 profile
+}
+template <class P> __device__ __forceinline__ double bleed_val(const ChanPtrs& ch, int C, int a, const P* prof, size_t z, size_t plane, size_t i) {
+  double acc = 0.0;                                     // np.zeros(image_size): float64 accumulator (:511)
+  for (int j = 0; j < C; ++j) acc = acc + (double)((P)ch.in[j][z * plane + i] * prof[((size_t)a * C + j) * plane + i]);
+  return acc;
+}
+struct MinMax { double mn, mx; };
+template <class V> __device__ __forceinline__ void block_minmax(V mn, V mx, MinMax* part) {
+  __shared__ double smn[256], smx[256];
+  smn[threadIdx.x] = (double)mn; smx[threadIdx.x] = (double)mx;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      smn[threadIdx.x] = smn[threadIdx.x + k] < smn[threadIdx.x] ? smn[threadIdx.x + k] : smn[threadIdx.x];
+      smx[threadIdx.x] = smx[threadIdx.x + k] > smx[threadIdx.x] ? smx[threadIdx.x + k] : smx[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[blockIdx.x].mn = smn[0]; part[blockIdx.x].mx = smx[0]; }
+}
+template <class P>
+__global__ __launch_bounds__(256) void illum_minmax_k(const uint16_t* __restrict__ im, int Z, size_t plane, const P* __restrict__ prof, MinMax* part) {
+  P mn = INFINITY, mx = -INFINITY;
+  const size_t n = plane * Z;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)MM_BLOCKS * 256) {
+    const P q = illum_val<P>(im, prof, v / plane, plane, v % plane);
+    mn = q < mn ? q : mn; mx = q > mx ? q : mx;
+  }
+  block_minmax(mn, mx, part);
+}
+template <class P>
+__global__ __launch_bounds__(256) void bleed_minmax_k(ChanPtrs ch, int C, int a, int Z, size_t plane, const P* __restrict__ prof, MinMax* part) {
+  double mn = INFINITY, mx = -INFINITY;
+  const size_t n = plane * Z;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)MM_BLOCKS * 256) {
+    const double q = bleed_val<P>(ch, C, a, prof, v / plane, plane, v % plane);
+    mn = q < mn ? q : mn; mx = q > mx ? q : mx;
+  }
+  block_minmax(mn, mx, part);
+}
+__global__ __launch_bounds__(1024) void minmax_final_k(const MinMax* __restrict__ part, MinMax* out) {
+  __shared__ double smn[1024], smx[1024];
+  smn[threadIdx.x] = threadIdx.x < MM_BLOCKS ? part[threadIdx.x].mn : INFINITY;
+  smx[threadIdx.x] = threadIdx.x < MM_BLOCKS ? part[threadIdx.x].mx : -INFINITY;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      smn[threadIdx.x] = smn[threadIdx.x + k] < smn[threadIdx.x] ? smn[threadIdx.x + k] : smn[threadIdx.x];
+      smx[threadIdx.x] = smx[threadIdx.x + k] > smx[threadIdx.x] ? smx[threadIdx.x + k] : smx[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out->mn = smn[0]; out->mx = smx[0]; }
+}
+template <class V> __device__ __forceinline__ uint16_t rescale_store(V q, V mn, V mx, int rescale) {
+  if (rescale) { q = q - mn; q = q / (mx - mn); q = q * (V)65535; q = q + (V)0; }
+  q = q < (V)0 ? (V)0 : q;            // np.clip(a_min=0, a_max=65535); NaN passes through as in NumPy
+  q = q > (V)65535 ? (V)65535 : q;
+  return to_u16((double)q);
+}
+template <class P>
+__global__ __launch_bounds__(256) void illum_rescale_k(const uint16_t* __restrict__ im, int Z, size_t plane, const P* __restrict__ prof,
+                                                       const MinMax* __restrict__ mm, int rescale, uint16_t* __restrict__ out) {
+  const P mn = (P)mm->mn, mx = (P)mm->mx;
+  const size_t n = plane * Z;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
+    out[v] = rescale_store<P>(illum_val<P>(im, prof, v / plane, plane, v % plane), mn, mx, rescale);
+}
+template <class P>
+__global__ __launch_bounds__(256) void bleed_rescale_k(ChanPtrs ch, int C, int a, int Z, size_t plane, const P* __restrict__ prof,
+                                                       const MinMax* __restrict__ mm, int rescale) {
+  const double mn = mm->mn, mx = mm->mx;
+  const size_t n = plane * Z;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
+    ch.out[a][v] = rescale_store<double>(bleed_val<P>(ch, C, a, prof, v / plane, plane, v % plane), mn, mx, rescale);
+}
+
 }  // namespace
 
 namespace ia3k {
@@ -333,6 +418,80 @@ int ia3_bleedthrough_correct_dev(ia3_stack* const* ims_u16, int C, const void* p
   if (prof_dtype == 1) hipLaunchKernelGGL((bleed_k<float>), dim3(gx), dim3(256), 0, stream(), ch, C, ims_u16[0]->Z, plane, (const float*)profile_dev);
   else hipLaunchKernelGGL((bleed_k<double>), dim3(gx), dim3(256), 0, stream(), ch, C, ims_u16[0]->Z, plane, (const double*)profile_dev);
   IA3_KCHECK();
+  return IA3_OK;
+}
+
+
+// classes/preprocess.py:605-680 DaxProcesser._corr_illumination: float32 (float64 for a float64 profile) quotient,
+// optional rescale of [min, max] to [0, 65535], clip, truncation.  In place allowed.
+int ia3_illumination_rescale_dev(const ia3_stack* im_u16, const void* profile_dev, int prof_dtype, int rescale, ia3_stack* out_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im_u16 || !profile_dev || !out_u16) return set_error(IA3_EINVAL, "null argument");
+  if (im_u16->dtype != IA3_U16 || out_u16->dtype != IA3_U16) return set_error(IA3_EINVAL, "uint16 stacks expected");
+  if (out_u16->Z != im_u16->Z || out_u16->X != im_u16->X || out_u16->Y != im_u16->Y) return set_error(IA3_EINVAL, "shape mismatch");
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  hipStream_t st = stream();
+  const int Z = im_u16->Z;
+  const size_t plane = (size_t)im_u16->X * im_u16->Y, n = plane * Z;
+  Scratch part((MM_BLOCKS + 1) * sizeof(MinMax));
+  if (!part.p) return IA3_ENOMEM;
+  MinMax* pm = part.as<MinMax>();
+  unsigned blocks = (unsigned)((n + 255) / 256); if (blocks > 256 * 32) blocks = 256 * 32;
+  ProfScope ps("illumination_rescale");
+  if (prof_dtype == 1) {
+    if (rescale) hipLaunchKernelGGL((illum_minmax_k<float>), dim3(MM_BLOCKS), dim3(256), 0, st, (const uint16_t*)im_u16->d, Z, plane, (const float*)profile_dev, pm);
+    if (rescale) hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(1024), 0, st, (const MinMax*)pm, pm + MM_BLOCKS);
+    hipLaunchKernelGGL((illum_rescale_k<float>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)im_u16->d, Z, plane, (const float*)profile_dev, (const MinMax*)(pm + MM_BLOCKS), rescale, (uint16_t*)out_u16->d);
+  } else {
+    if (rescale) hipLaunchKernelGGL((illum_minmax_k<double>), dim3(MM_BLOCKS), dim3(256), 0, st, (const uint16_t*)im_u16->d, Z, plane, (const double*)profile_dev, pm);
+    if (rescale) hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(1024), 0, st, (const MinMax*)pm, pm + MM_BLOCKS);
+    hipLaunchKernelGGL((illum_rescale_k<double>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)im_u16->d, Z, plane, (const double*)profile_dev, (const MinMax*)(pm + MM_BLOCKS), rescale, (uint16_t*)out_u16->d);
+  }
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+// classes/preprocess.py:464-541 DaxProcesser._corr_bleedthrough: float64 accumulation of the float32 (profile dtype)
+// products in channel order, optional rescale, clip, truncation.  Outputs must not alias inputs.
+int ia3_bleedthrough_rescale_dev(ia3_stack* const* ims_u16, int C, const void* profile_dev, int prof_dtype, int rescale,
+                                 ia3_stack* const* outs_u16) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!ims_u16 || !profile_dev || !outs_u16) return set_error(IA3_EINVAL, "null argument");
+  if (C < 1 || C > MAXC) return set_error(IA3_EUNSUPPORTED, "1..%d channels supported, got %d", MAXC, C);
+  if (prof_dtype != 1 && prof_dtype != 2) return set_error(IA3_EINVAL, "profile dtype must be float32 (1) or float64 (2)");
+  ChanPtrs ch;
+  for (int j = 0; j < C; ++j) {
+    if (!ims_u16[j] || !outs_u16[j]) return set_error(IA3_EINVAL, "null channel");
+    if (ims_u16[j]->dtype != IA3_U16 || outs_u16[j]->dtype != IA3_U16) return set_error(IA3_EINVAL, "uint16 stacks expected");
+    if (ims_u16[j]->Z != ims_u16[0]->Z || ims_u16[j]->X != ims_u16[0]->X || ims_u16[j]->Y != ims_u16[0]->Y ||
+        outs_u16[j]->Z != ims_u16[0]->Z || outs_u16[j]->X != ims_u16[0]->X || outs_u16[j]->Y != ims_u16[0]->Y)
+      return set_error(IA3_EINVAL, "shape mismatch");
+    for (int k = 0; k < C; ++k)
+      if (outs_u16[j]->d == ims_u16[k]->d) return set_error(IA3_EINVAL, "outputs must not alias inputs (every output mixes all inputs)");
+    ch.in[j] = (const uint16_t*)ims_u16[j]->d;
+    ch.out[j] = (uint16_t*)outs_u16[j]->d;
+  }
+  hipStream_t st = stream();
+  const int Z = ims_u16[0]->Z;
+  const size_t plane = (size_t)ims_u16[0]->X * ims_u16[0]->Y, n = plane * Z;
+  Scratch part((MM_BLOCKS + 1) * sizeof(MinMax));
+  if (!part.p) return IA3_ENOMEM;
+  MinMax* pm = part.as<MinMax>();
+  unsigned blocks = (unsigned)((n + 255) / 256); if (blocks > 256 * 32) blocks = 256 * 32;
+  ProfScope ps("bleedthrough_rescale");
+  for (int a = 0; a < C; ++a) {
+    if (prof_dtype == 1) {
+      if (rescale) hipLaunchKernelGGL((bleed_minmax_k<float>), dim3(MM_BLOCKS), dim3(256), 0, st, ch, C, a, Z, plane, (const float*)profile_dev, pm);
+      if (rescale) hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(1024), 0, st, (const MinMax*)pm, pm + MM_BLOCKS);
+      hipLaunchKernelGGL((bleed_rescale_k<float>), dim3(blocks), dim3(256), 0, st, ch, C, a, Z, plane, (const float*)profile_dev, (const MinMax*)(pm + MM_BLOCKS), rescale);
+    } else {
+      if (rescale) hipLaunchKernelGGL((bleed_minmax_k<double>), dim3(MM_BLOCKS), dim3(256), 0, st, ch, C, a, Z, plane, (const double*)profile_dev, pm);
+      if (rescale) hipLaunchKernelGGL(minmax_final_k, dim3(1), dim3(1024), 0, st, (const MinMax*)pm, pm + MM_BLOCKS);
+      hipLaunchKernelGGL((bleed_rescale_k<double>), dim3(blocks), dim3(256), 0, st, ch, C, a, Z, plane, (const double*)profile_dev, (const MinMax*)(pm + MM_BLOCKS), rescale);
+    }
+  }
+  IA3_KCHECK();
+  IA3_HIP(hipStreamSynchronize(st));   // `part` goes back to the pool
   return IA3_OK;
 }
 

@@ -218,8 +218,13 @@ __global__ __launch_bounds__(256) void warp_lin_k(const T* __restrict__ im, int 
   const int x = blockIdx.y, zq = blockIdx.z;
   const size_t o = ((size_t)zq * X + x) * Y + y, V = (size_t)Z * X * Y;
   double cc[3] = {(double)zq, (double)x, (double)y};
-  if (field) { cc[0] = cc[0] + field_at(field, fdt, o); cc[1] = cc[1] + field_at(field, fdt, V + o); cc[2] = cc[2] + field_at(field, fdt, 2 * V + o); }
-  cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  if (fdt & 16) {   // (grid - drift) + field: the order of classes/preprocess.py:923-935
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+  } else {          // (grid + field) - drift: translate.py:19-25, io_tools/load.py:443-448
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  }
   const int dims[3] = {Z, X, Y};
   if (mode == IA3_MODE_CONSTANT) {
     bool outside = false;
@@ -261,8 +266,13 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
   const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
   const size_t o = ((size_t)zq * X + x) * Y + y, V = (size_t)Z * X * Y;
   double cc[3] = {(double)zq, (double)x, (double)y};
-  if (field) { cc[0] = cc[0] + field_at(field, fdt, o); cc[1] = cc[1] + field_at(field, fdt, V + o); cc[2] = cc[2] + field_at(field, fdt, 2 * V + o); }
-  cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  if (fdt & 16) {   // (grid - drift) + field: the order of classes/preprocess.py:923-935
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+  } else {          // (grid + field) - drift: translate.py:19-25, io_tools/load.py:443-448
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  }
   const int dims[3] = {Zp, Xp, Yp};
   int idx[3][4]; double w[3][4];
 #pragma unroll
@@ -369,7 +379,7 @@ int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_d
   if (order != 1 && order != 3) return set_error(IA3_EUNSUPPORTED, "warp order %d (1 and 3 are implemented)", order);
   if (order == 1 && mode != IA3_MODE_CONSTANT && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "border mode %d", mode);
   if (order == 3 && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "order 3 is implemented for mode 'nearest'");
-  if (field_dev && field_dtype != 1 && field_dtype != 2) return set_error(IA3_EINVAL, "field dtype must be float32 or float64");
+  if (field_dev && (field_dtype & ~16) != 1 && (field_dtype & ~16) != 2) return set_error(IA3_EINVAL, "field dtype must be float32 (1) or float64 (2), optionally + 16");
   if (im->dtype == IA3_F32) return warp_t<float>(im, drift, field_dev, field_dtype, order, mode, cval, out);
   return warp_t<uint16_t>(im, drift, field_dev, field_dtype, order, mode, cval, out);
 }
@@ -381,7 +391,7 @@ int ia3_warp3d(const void* im, int dtype, int Z, int X, int Y, const double* dri
   rc = ia3_stack_alloc(dtype, Z, X, Y, &b);
   void* dfield = nullptr;
   if (!rc && field) {
-    size_t bytes = (size_t)3 * Z * X * Y * (field_dtype == 1 ? 4 : 8);
+    size_t bytes = (size_t)3 * Z * X * Y * ((field_dtype & 3) == 1 ? 4 : 8);
     if (hipMalloc(&dfield, bytes) != hipSuccess) rc = set_error(IA3_ENOMEM, "hipMalloc(%zu) for the displacement field failed", bytes);
     else if (hipMemcpy(dfield, field, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = set_error(IA3_EHIP, "field upload failed");
   }

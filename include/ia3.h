@@ -135,6 +135,13 @@ int ia3_z_shift_correction_dev(const ia3_stack* im, ia3_stack* out_u16);
 int ia3_illumination_correct_dev(const ia3_stack* im_u16, const void* profile_dev, int prof_dtype, ia3_stack* out_u16);
 int ia3_bleedthrough_correct_dev(ia3_stack* const* ims_u16, int C, const void* profile_dev, int prof_dtype,
                                  ia3_stack* const* outs_u16);
+/* the step-API twins in classes/preprocess.py (DaxProcesser._corr_illumination :605-680, ._corr_bleedthrough :464-541):
+ * same quotient / mix (the mix accumulated in float64), then `(im - min) / (max - min) * 65535 + 0` when rescale != 0,
+ * clip to [0, 65535], truncation */
+int ia3_illumination_rescale_dev(const ia3_stack* im_u16, const void* profile_dev, int prof_dtype, int rescale,
+                                 ia3_stack* out_u16);
+int ia3_bleedthrough_rescale_dev(ia3_stack* const* ims_u16, int C, const void* profile_dev, int prof_dtype, int rescale,
+                                 ia3_stack* const* outs_u16);
 
 /* ---- background level: io_tools/load.py:642-687 find_image_background -----------------------------------
  * counts = np.histogram(im, bins=edges); highest strict local maximum of the counts (scipy.signal.find_peaks,
@@ -242,7 +249,9 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
  * correction_tools/translate.py:5-31 warp_3d_image and its inlined twins (io_tools/load.py:438-453,
  * classes/preprocess.py:918-946): out = map_coordinates(im, grid (+ field) - drift, order, mode, cval).
  * order 1 with mode constant|nearest, order 3 (B-spline prefilter) with mode nearest.
- * field: NULL or a (3,Z,X,Y) displacement field, field_dtype 1 = float32, 2 = float64. */
+ * field: NULL or a (3,Z,X,Y) displacement field, field_dtype 1 = float32, 2 = float64; add 16 to form the
+ * coordinates as (grid - drift) + field, the order of classes/preprocess.py:923-935 (DaxProcesser._warp_image),
+ * instead of (grid + field) - drift. */
 int ia3_warp3d(const void* im, int dtype, int Z, int X, int Y, const double* drift, const void* field,
                int field_dtype, int order, int mode, double cval, void* out);
 int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_dev, int field_dtype,

@@ -211,6 +211,52 @@ def chromfn_golden(meta):
     np.savez_compressed(os.path.join(OUT, "chromfn.npz"), **d)
 
 
+def daxp_golden(meta):
+    """classes/preprocess.py:337-1260 DaxProcesser, step by step, run by the reference on the synthetic movie of the
+    chain case; the images after every step and the fitted spots are the fixtures."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import conftest as T
+    ref_loader.load_corrections()
+    ns = ref_loader.load_reference()
+    pre = sys.modules["IA3.classes.preprocess"]
+    case = T.build_chain_case()
+    chs = case["chs"]
+    size = [case["Z"], case["X"], case["Y"]]
+    d = {}
+
+    def put(key, im):   # CRC of the whole stack + 4096 sampled voxels (enough to localise a mismatch)
+        d[key + "_crc"] = crc(im)
+        d[key + "_smp"] = samples(im)
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "movie.dax")
+        T.write_dax(path, case["raw"])
+        for tag, kw in (("a", dict(rescale=True, illum64=False)), ("b", dict(rescale=False, illum64=True))):
+            p = pre.DaxProcesser(path, Channels=chs, DriftChannel='488', verbose=False)
+            quiet(p._load_image, ImSize=size, NbufferFrame=case["nb"])
+            quiet(p._corr_hot_pixels_3D)
+            for c in chs:
+                put("%s_hot_%s" % (tag, c), getattr(p, "im_" + c))
+            quiet(p._corr_bleedthrough, correction_pf=case["bleed"], rescale=kw["rescale"])
+            for c in chs[:3]:
+                put("%s_bleed_%s" % (tag, c), getattr(p, "im_" + c))
+            illum = {k: (a.astype(np.float64) if kw["illum64"] else a) for k, a in case["illum"].items()}
+            quiet(p._corr_illumination, correction_pf=illum, rescale=kw["rescale"])
+            for c in chs:
+                put("%s_illum_%s" % (tag, c), getattr(p, "im_" + c))
+            quiet(p._warp_image, drift=np.array(case["drift"]), chromatic_pf=case["chrom"])
+            for c in chs:
+                put("%s_warp_%s" % (tag, c), getattr(p, "im_" + c))
+            if tag == "a":
+                quiet(p._gaussian_highpass, correction_channels=['750'])
+                put("a_highpass_750", p.im_750)
+                quiet(p._fit_spots, fit_channels=['647', '561'], th_seed=300)
+                for c in ('647', '561'):
+                    d["a_spots_%s" % c] = np.array(getattr(p, "spots_" + c))
+    np.savez_compressed(os.path.join(OUT, "daxp.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -341,6 +387,7 @@ def main():
     norm_golden(meta)
     chain_golden(meta)
     chromfn_golden(meta)
+    daxp_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

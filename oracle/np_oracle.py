@@ -1157,3 +1157,48 @@ def correct_fov_image(raw_im, sel_channels, single_im_size, all_channels, num_bu
     if gaussian_highpass:                                                                   # :489-498
         ims = [gaussian_high_pass_filter(im, gauss_sigma, gauss_truncate) for im in ims]
     return [ims[load_channels.index(c)].astype(output_dtype).copy() for c in sel_channels]
+
+
+# ----------------------------------------------------------------------------------------------
+# DaxProcesser steps where they differ from correct_fov_image (classes/preprocess.py:464-965)
+# ----------------------------------------------------------------------------------------------
+
+
+def daxp_bleedthrough(ims, correction_pf, image_size, rescale=True):
+    """:505-523 — float64 accumulation of `im * pf[i, j]`, min-max rescale to the dtype range, clip, cast."""
+    outs = []
+    for i in range(len(ims)):
+        dtype = ims[i].dtype
+        mn, mx = np.iinfo(dtype).min, np.iinfo(dtype).max
+        im = np.zeros(image_size)
+        for j in range(len(ims)):
+            im += ims[j] * correction_pf[i, j]
+        if rescale:
+            im = (im - np.min(im)) / (np.max(im) - np.min(im)) * mx + mn
+        outs.append(np.clip(im, a_min=mn, a_max=mx).astype(dtype))
+    return outs
+
+
+def daxp_illumination(im, pf, rescale=True):
+    """:653-662."""
+    dtype = im.dtype
+    mn, mx = np.iinfo(dtype).min, np.iinfo(dtype).max
+    q = im.astype(np.float32) / pf[np.newaxis, :]
+    if rescale:
+        q = (q - np.min(q)) / (np.max(q) - np.min(q)) * mx + mn
+    return np.clip(q, a_min=mn, a_max=mx).astype(dtype)
+
+
+def daxp_warp(im, drift, chromatic=None):
+    """:918-946 — coordinates = (grid - drift) + chromatic, cubic map_coordinates, mode 'nearest'."""
+    from scipy.ndimage import map_coordinates
+    size = im.shape
+    coords = np.meshgrid(np.arange(size[0]), np.arange(size[1]), np.arange(size[2]))
+    coords = np.stack(coords).transpose((0, 2, 1, 3))
+    drift = np.array(drift)
+    if drift.any():
+        coords = coords - drift[:, np.newaxis, np.newaxis, np.newaxis]
+    if chromatic is not None:
+        coords = coords + chromatic
+    out = map_coordinates(im, coords.reshape(coords.shape[0], -1), mode='nearest').astype(im.dtype)
+    return out.reshape(size)

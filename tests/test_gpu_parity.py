@@ -731,3 +731,70 @@ def test_correct_fov_image_translation_functions():
     assert len(funcs) == 2
     assert np.array_equal(funcs[0](spots), gf["spots"])               # 750: chromatic constants + drift
     assert np.array_equal(funcs[1](spots), gf["drift_only"])          # 647 (reference channel): drift only
+
+
+# ---- DaxProcesser step API (classes/preprocess.py:337-1260) -----------------------------------------------------
+@pytest.mark.parametrize("tag,rescale,illum64", [("a", True, False), ("b", False, True)])
+def test_daxprocesser_steps_golden_bit_exact(tag, rescale, illum64, tmp_path):
+    from conftest import build_chain_case, write_dax
+    from imageanalysis3_amd.classes.preprocess import DaxProcesser
+    case = build_chain_case()
+    g = load_golden("daxp.npz")
+    chs = case["chs"]
+    path = str(tmp_path / "movie.dax")
+    write_dax(path, case["raw"])
+
+    def check(step, channels):
+        for c in channels:
+            im = getattr(p, "im_" + c)
+            key = "%s_%s_%s" % (tag, step, c)
+            idx, vals = g[key + "_smp"]
+            assert im.dtype == np.uint16
+            assert np.array_equal(im.reshape(-1)[idx], vals.astype(np.uint16)), (key, "sampled voxels differ")
+            assert crc(im) == g[key + "_crc"], key
+
+    p = DaxProcesser(path, Channels=chs, DriftChannel='488', verbose=False)
+    assert p.drift_channel == '488' and not hasattr(p, "im_750")
+    p._load_image(ImSize=[case["Z"], case["X"], case["Y"]], NbufferFrame=case["nb"])
+    assert p.loaded_channels == chs and tuple(p.image_size) == (case["Z"], case["X"], case["Y"])
+    p._corr_hot_pixels_3D()
+    check("hot", chs)
+    p._corr_bleedthrough(correction_pf=case["bleed"], rescale=rescale)
+    check("bleed", chs[:3])
+    illum = {k: (a.astype(np.float64) if illum64 else a) for k, a in case["illum"].items()}
+    p._corr_illumination(correction_pf=illum, rescale=rescale)
+    check("illum", chs)
+    p._warp_image(drift=np.array(case["drift"]), chromatic_pf=case["chrom"])
+    check("warp", chs)
+    assert all(p.correction_log[c].get('corr_drift') for c in chs) and p.correction_log['750'].get('corr_chromatic')
+    p._corr_illumination(correction_pf=illum)       # logged as done: a second call is a no-op
+    check("warp", chs)
+    if tag == "a":
+        p._gaussian_highpass(correction_channels=['750'])
+        check("highpass", ['750'])
+        p._fit_spots(fit_channels=['647', '561'], th_seed=300)
+        for c in ('647', '561'):
+            ref = g["a_spots_%s" % c]
+            got = getattr(p, "spots_" + c)
+            # seeds sit 3-4 voxels apart here: exact Voronoi ties exist, the reference leaves them to cKDTree's layout.
+            # Strict parity against the oracle with the kernel's tie rule, loose parity against the reference's table.
+            import np_oracle as O
+            orc = O.fit_fov_image(getattr(p, "im_" + c), c, th_seed=300, max_num_seeds=None, voronoi="lowest_index")
+            ia, ib = match_rows(got, orc)
+            rel = np.abs(got[ia][:, :8] - orc[ib][:, :8]) / np.maximum(np.abs(orc[ib][:, :8]), 1e-3)
+            # one fit of this noisy rescaled field runs into maxfev = 1000 without converging (MINPACK warns about it in the
+            # oracle too); where such a fit stops depends on the last bits of every step, and the seeds coupled to it through
+            # the refit sweeps inherit the difference: that group is held to 1e-2, everything else to 1e-5
+            assert (rel.max(1) > 1e-5).sum() <= 3 and rel.max() < 1e-2, rel.max(1)
+            ia, ib = match_rows(got, ref)
+            np.testing.assert_allclose(got[ia][:, :8], ref[ib][:, :8], rtol=1e-2, atol=1e-3)
+            assert np.array_equal(getattr(p, "spots_cell_ids_" + c), np.zeros(len(ref), np.int32))
+        # drift against itself: flag 0, zeros; against a shifted copy of the bead channel through align_image
+        assert p._calculate_drift(path, DriftChannel='488', save_attr=False) == (pytest.approx(np.zeros(3)), 0)
+        with pytest.raises(NotImplementedError):
+            p._fit_spots_by_segmentation('647', None)
+    # assigning an image uploads it; deleting frees it
+    p.im_561 = np.zeros((case["Z"], case["X"], case["Y"]), np.uint16)
+    assert p.im_561.sum() == 0
+    del p.im_561
+    assert not hasattr(p, "im_561")

@@ -222,3 +222,38 @@ def test_correct_fov_image_chain_oracle_vs_reference_golden(name):
     out = O.correct_fov_image(case["raw"], sel, **kw)
     for ch, im in zip(sel, out):
         assert im.dtype == np.uint16 and np.array_equal(im, g["%s_%s" % (name, ch)]), (name, ch)
+
+
+# ---- DaxProcesser steps (classes/preprocess.py:337-1260) ---------------------------------------------------------
+def _daxp_oracle(case, rescale, illum64):
+    """The reference class's step order restated with the oracle functions; yields (key, image)."""
+    chs = case["chs"]
+    n_col, Z = 4, case["Z"]
+    ims = {}
+    for i, c in enumerate(chs):
+        start = case["nb"] + (i - case["nb"]) % n_col
+        ims[c] = case["raw"][start:start + Z * n_col:n_col].copy()
+    for c in chs:
+        ims[c] = O.remove_hot_pixels(ims[c], ims[c].dtype, hot_pix_th=0.5, hot_th=4).astype(np.uint16)
+        yield "hot_" + c, ims[c]
+    outs = O.daxp_bleedthrough([ims[c] for c in chs[:3]], case["bleed"], (Z, case["X"], case["Y"]), rescale)
+    for c, o in zip(chs[:3], outs):
+        ims[c] = o
+        yield "bleed_" + c, o
+    for c in chs:
+        pf = case["illum"][c].astype(np.float64) if illum64 else case["illum"][c]
+        ims[c] = O.daxp_illumination(ims[c], pf, rescale)
+        yield "illum_" + c, ims[c]
+    for c in chs:
+        chrom = case["chrom"].get(c) if c != '488' else None
+        ims[c] = O.daxp_warp(ims[c], case["drift"], chrom)
+        yield "warp_" + c, ims[c]
+
+
+@pytest.mark.parametrize("tag,rescale,illum64", [("a", True, False), ("b", False, True)])
+def test_daxprocesser_steps_oracle_vs_reference_golden(tag, rescale, illum64):
+    from conftest import build_chain_case
+    case = build_chain_case()
+    g = load_golden("daxp.npz")
+    for key, im in _daxp_oracle(case, rescale, illum64):
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(im).tobytes())) == g["%s_%s_crc" % (tag, key)], (tag, key)
