@@ -290,18 +290,66 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
     for (int k = 0; k < 4; ++k) idx[a][k] = clampi(st + k, dims[a]);
   }
   double t = 0.0;
+  if ((size_t)Zp * Xp * Yp * sizeof(double) < 0xffffffffull) {
+    // The padded coefficient volume is < 4 GB: buffer loads with 32-bit byte offsets from a wave-uniform resource
+    // descriptor (one integer add per tap instead of 64-bit address arithmetic for each of the 64 loads, which had
+    // doubled the VALU count).  When no lane of the wave clamps its y taps - always, unless a shift exceeds the 12-voxel
+    // padding - the four taps of a row are 32 contiguous bytes: two 16-byte loads instead of four 8-byte ones.
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, (int)((size_t)Zp * Xp * Yp * sizeof(double)), 0x00020000);
+    const bool contig = idx[2][1] == idx[2][0] + 1 && idx[2][2] == idx[2][0] + 2 && idx[2][3] == idx[2][0] + 3;
+    if (__all(contig)) {
+      const unsigned y0 = (unsigned)idx[2][0] * 8u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double* row = C + ((size_t)idx[0][i] * Xp + idx[1][j]) * Yp;
+        for (int j = 0; j < 4; ++j) {
+          const unsigned off = ((unsigned)idx[0][i] * (unsigned)Xp + (unsigned)idx[1][j]) * (unsigned)Yp * 8u + y0;
+          const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+          const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
+          const double cv[4] = {__hiloint2double((int)lo.y, (int)lo.x), __hiloint2double((int)lo.w, (int)lo.z),
+                                __hiloint2double((int)hi.y, (int)hi.x), __hiloint2double((int)hi.w, (int)hi.z)};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        double c = row[idx[2][k]];
-        c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
-        t = t + c;
-      }
+          for (int k = 0; k < 4; ++k) {
+            double c = cv[k];
+            c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+            t = t + c;
+          }
+        }
+    } else {
+      unsigned yoff[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yoff[k] = (unsigned)idx[2][k] * 8u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned roff = ((unsigned)idx[0][i] * (unsigned)Xp + (unsigned)idx[1][j]) * (unsigned)Yp * 8u;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const v2u q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, roff + yoff[k], 0, 0);
+            double c = __hiloint2double((int)q.y, (int)q.x);
+            c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+            t = t + c;
+          }
+        }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double* row = C + ((size_t)idx[0][i] * Xp + idx[1][j]) * Yp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double c = row[idx[2][k]];
+          c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+          t = t + c;
+        }
+      }
+  }
   out[o] = out_cvt<T>(t);
 }
 
