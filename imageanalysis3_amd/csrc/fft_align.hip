@@ -13,6 +13,7 @@
 #include <hipfft/hipfft.h>
 #include <unistd.h>
 #include <vector>
+#include <mutex>
 #include <math.h>
 
 using namespace ia3rt;
@@ -44,10 +45,19 @@ static pid_t g_plans_pid = 0;
 static unsigned long long g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 8;
 
+static std::mutex g_plan_mu;
+// NOTE: a cached plan is shared by all host threads; the drift entry points are meant to be driven by one thread at a
+// time (the plan is re-bound to the caller's stream on every use, executions of one plan are not concurrent-safe).
 static int get_plan(int type, int n0, int n1, int n2, hipStream_t st, hipfftHandle* out) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
   if (g_plans_pid != getpid()) { g_plans.clear(); g_plans_pid = getpid(); }   // handles do not survive fork()
   for (auto& e : g_plans)
-    if (e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) { e.used = ++g_plan_clock; *out = e.h; return IA3_OK; }
+    if (e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) {
+      e.used = ++g_plan_clock;
+      if (hipfftSetStream(e.h, st) != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfftSetStream failed");
+      *out = e.h;
+      return IA3_OK;
+    }
   if (g_plans.size() >= MAX_PLANS) {
     size_t victim = 0;
     for (size_t i = 1; i < g_plans.size(); ++i) if (g_plans[i].used < g_plans[victim].used) victim = i;

@@ -12,15 +12,26 @@ namespace ia3rt {
 
 static thread_local char g_err[1024] = "";
 static int g_device = -1;
-static hipStream_t g_stream = nullptr;
-static hipStream_t g_aux = nullptr;       // second stream for work that is independent of the main queue
-static hipStream_t g_cur = nullptr;       // what stream() hands out (g_stream unless an AuxScope is open)
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
+static hipStream_t g_stream = nullptr;    // stream of the thread that initialised the library (ia3_stream())
 static pid_t g_pid = 0;
 static int g_cus = 256;
 static std::mutex g_mu;
 
-struct WsEntry { void* p; size_t bytes; bool busy; };
+// Every host thread that calls into the library gets its own streams: the thread that initialised the library uses
+// g_stream, any other thread a stream created on first use.  Independent images can therefore be processed side by
+// side from a thread pool (one FOV per thread): the long tail of one image's fit kernel (a few fits that run to
+// maxfev) overlaps the other images' work.
+struct ThreadCtx {
+  pid_t pid = 0;
+  hipStream_t main = nullptr, aux = nullptr, cur = nullptr;   // cur: what stream() hands out (aux inside an AuxScope)
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<void*> deferred;   // scratch blocks released inside an AuxScope
+};
+static thread_local ThreadCtx t_ctx;
+
+// Scratch cache with stream-ordered reuse: a released block remembers the stream it was last used on and an event
+// recorded there at release time; a different stream that picks it up waits for that event first.
+struct WsEntry { void* p; size_t bytes; bool busy; hipStream_t last; hipEvent_t ev; };
 static std::vector<WsEntry> g_ws;
 
 int set_error(int code, const char* fmt, ...) {
@@ -34,7 +45,7 @@ int set_error(int code, const char* fmt, ...) {
 static int do_init(int device) {
   // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
   if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
-  if (g_pid != getpid()) { g_stream = nullptr; g_aux = nullptr; g_cur = nullptr; g_fork = g_join = nullptr; g_ws.clear(); g_device = -1; }
+  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_device = -1; }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -50,36 +61,55 @@ static int do_init(int device) {
   IA3_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = device;
   g_pid = getpid();
+  t_ctx = ThreadCtx();
+  t_ctx.pid = g_pid;
+  t_ctx.main = g_stream;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_cus = cus;
   return IA3_OK;
 }
 
+// the calling thread's context (its own stream unless it is the initialising thread)
+static int thread_ctx() {
+  if (t_ctx.main && t_ctx.pid == g_pid) return IA3_OK;
+  t_ctx = ThreadCtx();
+  IA3_HIP(hipSetDevice(g_device));   // the current device is per host thread
+  IA3_HIP(hipStreamCreateWithFlags(&t_ctx.main, hipStreamNonBlocking));
+  t_ctx.pid = g_pid;
+  return IA3_OK;
+}
+
 int ensure_init() {
-  std::lock_guard<std::mutex> lk(g_mu);
-  return do_init(-1);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = do_init(-1);
+    if (rc) return rc;
+  }
+  return thread_ctx();
 }
 static void ws_flush_deferred();
-hipStream_t stream() { return g_cur ? g_cur : g_stream; }
+hipStream_t stream() { return t_ctx.cur ? t_ctx.cur : t_ctx.main; }
 
-// Everything launched while an AuxScope is alive goes to the auxiliary stream, which first waits for the work queued
-// on the main stream so far; the destructor makes the main stream wait for the auxiliary work only when join() is
-// called (typically right before the first consumer of its results).
+// Everything launched while an AuxScope is alive goes to the thread's auxiliary stream, which first waits for the work
+// queued on its main stream so far; aux_join() makes the main stream wait for the auxiliary work (typically right
+// before the first consumer of its results).
 AuxScope::AuxScope() : ok(false) {
-  if (!g_stream) return;
-  if (!g_aux) {
-    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) { g_aux = nullptr; return; }
-    if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) return;
+  ThreadCtx& c = t_ctx;
+  if (!c.main) return;
+  if (!c.aux) {
+    if (hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking) != hipSuccess) { c.aux = nullptr; return; }
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return;
   }
-  if (hipEventRecord(g_fork, g_stream) != hipSuccess || hipStreamWaitEvent(g_aux, g_fork, 0) != hipSuccess) return;
-  g_cur = g_aux;
+  if (hipEventRecord(c.fork, c.main) != hipSuccess || hipStreamWaitEvent(c.aux, c.fork, 0) != hipSuccess) return;
+  c.cur = c.aux;
   ok = true;
 }
-AuxScope::~AuxScope() { g_cur = nullptr; }
+AuxScope::~AuxScope() { t_ctx.cur = nullptr; }
 int aux_join() {
-  if (!g_aux) return IA3_OK;
-  if (hipEventRecord(g_join, g_aux) != hipSuccess || hipStreamWaitEvent(g_stream, g_join, 0) != hipSuccess)
+  ThreadCtx& c = t_ctx;
+  if (!c.aux) return IA3_OK;
+  if (hipEventRecord(c.join, c.aux) != hipSuccess || hipStreamWaitEvent(c.main, c.join, 0) != hipSuccess)
     return set_error(IA3_EHIP, "stream join failed");
   ws_flush_deferred();
   return IA3_OK;
@@ -89,38 +119,53 @@ int num_cus() { return g_cus; }
 void* ws_get(size_t bytes) {
   if (bytes == 0) bytes = 256;
   std::lock_guard<std::mutex> lk(g_mu);
+  const hipStream_t me = stream();
   int best = -1;
   for (size_t i = 0; i < g_ws.size(); ++i)
     if (!g_ws[i].busy && g_ws[i].p && g_ws[i].bytes >= bytes &&
         (best < 0 || g_ws[i].bytes < g_ws[best].bytes))
       best = (int)i;
-  if (best >= 0 && g_ws[best].bytes <= 2 * bytes + (1 << 20)) { g_ws[best].busy = true; return g_ws[best].p; }
+  if (best >= 0 && g_ws[best].bytes <= 2 * bytes + (1 << 20)) {
+    WsEntry& e = g_ws[best];
+    // last used on another stream (another host thread, or this thread's other stream): order after that use
+    if (e.last && e.last != me && e.ev) (void)hipStreamWaitEvent(me, e.ev, 0);
+    e.busy = true;
+    return e.p;
+  }
   void* p = nullptr;
   if (hipMalloc(&p, bytes) != hipSuccess) {
     for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
     if (hipMalloc(&p, bytes) != hipSuccess) { set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
   }
-  for (auto& e : g_ws) if (!e.p) { e = {p, bytes, true}; return p; }
-  g_ws.push_back({p, bytes, true});
+  for (auto& e : g_ws) if (!e.p) { e.p = p; e.bytes = bytes; e.busy = true; e.last = nullptr; return p; }
+  g_ws.push_back(WsEntry{p, bytes, true, nullptr, nullptr});
   return p;
 }
-// Reuse of a returned block is ordered by the main stream.  A block returned while an AuxScope is open may still be
-// in use by the auxiliary stream: it stays busy until aux_join() has put the join into the main queue.
-static std::vector<void*> g_deferred;
+static void ws_release_locked(void* p, hipStream_t on) {
+  for (auto& e : g_ws) if (e.p == p) {
+    if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
+    if (e.ev) (void)hipEventRecord(e.ev, on);
+    e.last = on;
+    e.busy = false;
+    return;
+  }
+}
+// A block returned while an AuxScope is open may still be in use by the auxiliary stream: it stays busy until
+// aux_join() has put the join into the main queue.
 void ws_put(void* p) {
+  if (t_ctx.cur) { t_ctx.deferred.push_back(p); return; }
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_cur) { g_deferred.push_back(p); return; }
-  for (auto& e : g_ws) if (e.p == p) { e.busy = false; return; }
+  ws_release_locked(p, t_ctx.main ? t_ctx.main : g_stream);
 }
 static void ws_flush_deferred() {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (void* p : g_deferred)
-    for (auto& e : g_ws) if (e.p == p) { e.busy = false; break; }
-  g_deferred.clear();
+  for (void* p : t_ctx.deferred) ws_release_locked(p, t_ctx.main);
+  t_ctx.deferred.clear();
 }
 void ws_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+  (void)hipDeviceSynchronize();
+  for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; e.last = nullptr; }
 }
 
 // ---- profiling ----------------------------------------------------------------------------------
@@ -128,18 +173,22 @@ struct ProfRec { const char* name; hipEvent_t a, b; hipStream_t st; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 
+static std::mutex g_prof_mu;
 ProfScope::ProfScope(const char* name) : slot(-1) {
-  if (!g_prof || !g_stream) return;
+  if (!g_prof || !stream()) return;
   ProfRec r;
   r.name = name;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.st = stream();
   (void)hipEventRecord(r.a, r.st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, g_recs[slot].st);
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_recs[slot].b, g_recs[slot].st);
 }
 
 // NumPy's pairwise sum for a contiguous double vector (numpy/_core/src/umath/loops_utils.h.src)
@@ -191,10 +240,10 @@ int ia3_device_name(char* buf, int len) {
 int ia3_sync(void) {
   int rc = ensure_init();
   if (rc) return rc;
-  IA3_HIP(hipStreamSynchronize(g_stream));
+  IA3_HIP(hipStreamSynchronize(stream()));
   return IA3_OK;
 }
-void* ia3_stream(void) { return ensure_init() ? nullptr : (void*)g_stream; }
+void* ia3_stream(void) { return ensure_init() ? nullptr : (void*)stream(); }
 int ia3_release_workspace(void) { ws_release_all(); return IA3_OK; }
 
 int ia3_profile_enable(int on) {
@@ -205,7 +254,8 @@ int ia3_profile_enable(int on) {
 // Writes "name,count,total_ms\n" lines for everything recorded since the last call, and clears.
 int ia3_profile_collect(char* buf, int len) {
   int rc = ensure_init(); if (rc) return rc;
-  IA3_HIP(hipStreamSynchronize(g_stream));
+  IA3_HIP(hipDeviceSynchronize());   // events may sit on any thread's stream
+  std::lock_guard<std::mutex> plk(g_prof_mu);
   struct Agg { const char* name; int n; double ms; };
   std::vector<Agg> agg;
   for (auto& r : g_recs) {
@@ -245,8 +295,8 @@ int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out) {
   if (!host) return set_error(IA3_EINVAL, "null host pointer");
   int rc = ia3_stack_alloc(dtype, Z, X, Y, out); if (rc) return rc;
-  hipError_t e = hipMemcpyAsync((*out)->d, host, (*out)->bytes, hipMemcpyHostToDevice, g_stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+  hipError_t e = hipMemcpyAsync((*out)->d, host, (*out)->bytes, hipMemcpyHostToDevice, stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(stream());
   if (e != hipSuccess) {
     ia3_stack_free(*out); *out = nullptr;
     return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
@@ -262,7 +312,7 @@ int ia3_stack_deinterleave(const ia3_stack* raw, int start, int step, int Z, ia3
   rc = ia3_stack_alloc(raw->dtype, Z, raw->X, raw->Y, out); if (rc) return rc;
   const size_t pb = (size_t)raw->X * raw->Y * esize(raw->dtype);
   hipError_t e = hipMemcpy2DAsync((*out)->d, pb, (const char*)raw->d + (size_t)start * pb, pb * step, pb, Z,
-                                  hipMemcpyDeviceToDevice, g_stream);
+                                  hipMemcpyDeviceToDevice, stream());
   if (e != hipSuccess) {
     ia3_stack_free(*out); *out = nullptr;
     return set_error(IA3_EHIP, "frame gather failed: %s", hipGetErrorString(e));
@@ -275,14 +325,14 @@ int ia3_buffer_upload(const void* host, size_t bytes, void** devptr) {
   if (!host || !devptr || bytes == 0) return set_error(IA3_EINVAL, "bad buffer arguments");
   void* d = nullptr;
   if (hipMalloc(&d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
-  hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, g_stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+  hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream());
+  if (e == hipSuccess) e = hipStreamSynchronize(stream());
   if (e != hipSuccess) { (void)hipFree(d); return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); }
   *devptr = d;
   return IA3_OK;
 }
 void ia3_buffer_free(void* devptr) {
-  if (devptr && g_pid == getpid()) { (void)hipStreamSynchronize(g_stream); (void)hipFree(devptr); }
+  if (devptr && g_pid == getpid()) { (void)hipStreamSynchronize(stream()); (void)hipFree(devptr); }
 }
 int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out) {
   int rc = ensure_init(); if (rc) return rc;
@@ -293,8 +343,8 @@ int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out
 }
 int ia3_stack_download(const ia3_stack* s, void* host) {
   if (!s || !host) return set_error(IA3_EINVAL, "null argument");
-  IA3_HIP(hipMemcpyAsync(host, s->d, s->bytes, hipMemcpyDeviceToHost, g_stream));
-  IA3_HIP(hipStreamSynchronize(g_stream));
+  IA3_HIP(hipMemcpyAsync(host, s->d, s->bytes, hipMemcpyDeviceToHost, stream()));
+  IA3_HIP(hipStreamSynchronize(stream()));
   return IA3_OK;
 }
 int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void** devptr) {

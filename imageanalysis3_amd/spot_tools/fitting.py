@@ -157,6 +157,25 @@ def fit_fov_image(im, channel, seeds=None,
     return _spots
 
 
+def fit_fov_images(ims, channels=None, n_workers=2, **kwargs):
+    """``[fit_fov_image(im, ch, **kwargs) for im, ch in zip(ims, channels)]`` with ``n_workers`` images in flight.
+
+    libia3 gives every host thread its own HIP streams, so independent images (the reference hands them to a process
+    pool, classes/field_of_view.py:1129-1138) overlap on the device: while the fit kernel of one image drains its last
+    few long-running fits, the filters and fits of the next images use the rest of the chip.  Results are identical to
+    the sequential calls.  ``ims``: ndarrays or resident ``DeviceStack``s."""
+    from concurrent.futures import ThreadPoolExecutor
+    ims = list(ims)
+    if channels is None:
+        channels = [None] * len(ims)
+    L.lib()   # load once, before the threads start
+    kwargs.setdefault("verbose", False)
+    if n_workers <= 1 or len(ims) <= 1:
+        return [fit_fov_image(_im, _ch, **kwargs) for _im, _ch in zip(ims, channels)]
+    with ThreadPoolExecutor(max_workers=int(n_workers)) as pool:
+        return list(pool.map(lambda a: fit_fov_image(a[0], a[1], **kwargs), zip(ims, channels)))
+
+
 def _get_seeds_dev(stack, host_im=None, max_num_seeds=None, th_seed=150, th_seed_per=95, use_percentile=False,
                    sel_center=None, seed_radius=30, gfilt_size=0.75, background_gfilt_size=7.5, filt_size=3,
                    min_edge_distance=2, use_dynamic_th=True, dynamic_niters=10, min_dynamic_seeds=1,

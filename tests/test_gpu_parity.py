@@ -798,3 +798,15 @@ def test_daxprocesser_steps_golden_bit_exact(tag, rescale, illum64, tmp_path):
     assert p.im_561.sum() == 0
     del p.im_561
     assert not hasattr(p, "im_561")
+
+
+def test_fit_fov_images_concurrent_equals_sequential():
+    """Several host threads, one stream each: same tables as one call after the other."""
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image, fit_fov_images
+    ims = [build_case(n) for n in ("c1_u16", "c1_f32", "m_f32", "hot_u16", "clu_f32", "edge_f32")] * 2
+    seq = [fit_fov_image(im, "647", th_seed=600, verbose=False) for im in ims]
+    for workers in (2, 4):
+        par = fit_fov_images(ims, ["647"] * len(ims), n_workers=workers, th_seed=600)
+        assert len(par) == len(seq)
+        for a, b in zip(par, seq):
+            assert a.shape == b.shape and np.array_equal(a, b)
