@@ -178,11 +178,14 @@ def main():
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom_name, shape),
                     "avg_launch_ms": round(dom_ms / dom_n, 4), "launches": dom_n,
-                    "note": "exact scipy.ndimage arithmetic (f64, no FMA) makes the Gaussian passes "
-                            "f64-VALU-bound: see valu_frac"}
+                    "note": "scipy.ndimage's float64 accumulation (bit-identical results) makes the Gaussian passes "
+                            "f64-VALU-bound: valu_frac = f64 instructions issued / peak issue rate"}
             if dom_name.startswith("gauss_axis") or dom_name.startswith("gauss_fused3"):
                 R = int(dom_name.split("_R")[1])
-                ops = (3 * R + 1) * float(shape[0]) * shape[1] * shape[2]   # add,mul,add per tap pair + 1
+                # per output: one multiply + per tap pair (add, multiply, add); the long passes fuse the last two where
+                # the rounded result is provably the same (gauss.hip), so they issue 2 instructions per pair
+                per_out = (2 * R + 1) if (R >= 16 and dom_name.startswith("gauss_axis")) else (3 * R + 1)
+                ops = per_out * float(shape[0]) * shape[1] * shape[2]
                 if dom_name.startswith("gauss_fused3"):
                     ops *= 3                                                  # three axes in one launch
                 roof["valu_frac"] = round(ops / avg_s / (F64_VALU_PEAK_TFLOPS / 2 * 1e12), 4)

@@ -41,6 +41,31 @@ template <> __device__ __forceinline__ uint16_t cvt<uint16_t>(double v) { return
 
 struct Taps { double w[64]; };
 
+// ---- certified fast path of the long (VALU-bound) passes ------------------------------------------------------
+// The contract fixes the f32 / u16 value of every output, not the f64 bits behind it.  For non-negative inputs the
+// same sum with each (multiply, add) pair fused differs from NI_Correlate1D's by at most (2R+1) f64 ulps (all
+// partial sums are non-negative and bounded by the result), so the quantised value can only differ when the fused
+// sum lies within that distance of a quantisation boundary: a float32 rounding midpoint (low 29 mantissa bits
+// 0x10000000) or, for uint16 truncation, an integer.  Such outputs (a few per 10^7), sums outside the normal float32
+// range and threads that have seen a sign bit are recomputed with the unfused sequence; everything else takes
+// two VALU instructions per tap pair instead of three.  `cert` = the guard distance in f64 ulps (4R+8 by default).
+template <class T> __device__ __forceinline__ bool uncertain(double s, int cert);
+template <> __device__ __forceinline__ bool uncertain<float>(double s, int cert) {
+  const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+  const int d = (int)(lo & 0x1FFFFFFFu) - 0x10000000;
+  const bool near_mid = (d < 0 ? -d : d) <= cert;
+  // exponent outside [2^-100, inf): zero is exact on both paths, anything else (tiny, inf, nan) is recomputed
+  const bool odd_exp = (hi - 0x39B00000u) >= (0x7FF00000u - 0x39B00000u) && (hi | lo) != 0u;
+  return near_mid || odd_exp;
+}
+template <> __device__ __forceinline__ bool uncertain<uint16_t>(double s, int cert) {
+  // |s - nearest integer| <= cert ulps of s (ulp(s) <= s * 2^-52); s == 0 is exact on both paths
+  return s != 0.0 && fabs(s - rint(s)) <= s * ((double)cert * 2.220446049250313e-16);
+}
+template <class T> __device__ __forceinline__ unsigned sign_of(T v);
+template <> __device__ __forceinline__ unsigned sign_of<float>(float v) { return __float_as_uint(v); }
+template <> __device__ __forceinline__ unsigned sign_of<uint16_t>(uint16_t) { return 0u; }
+
 // f(integral_constant<0>), f(<1>), ... while f returns true
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_until(F& f) {
@@ -69,7 +94,8 @@ template <class T, int R, int K, bool TR = false>
 __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T* __restrict__ out,
                                                      int inner, size_t stride, int len,
                                                      size_t outer_stride, Taps taps,
-                                                     const int* __restrict__ bmap, int seg) {
+                                                     const int* __restrict__ bmap, int seg, int cert) {
+  constexpr bool FAST = R >= 16;   // certified fused path only where the pass is VALU-bound
   constexpr int TQ = (K == 6 || K == 12) ? 24 : ((K == 10) ? 30 : 32);   // q extent of the transposing tile (a multiple of K)
   static_assert(!TR || TQ % K == 0, "tile must hold whole chunks");
   __shared__ float tile[TR ? 4 : 1][TR ? 64 : 1][TR ? TQ + 1 : 1];
@@ -86,8 +112,13 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
   constexpr int W = K + 2 * R;
   constexpr int U = (W % K == 0) ? W / K : 1;   // chunks per unrolled body
   double win[W];
+  unsigned sbits = 0;   // OR of the raw inputs this thread has loaded: bit 31 set = a negative (or -0, nan) was seen
 #pragma unroll
-  for (int i = 0; i < W; ++i) win[i] = ld<T>(in, base + (size_t)bmap[q_begin + i] * stride);
+  for (int i = 0; i < W; ++i) {
+    const T v = in[base + (size_t)bmap[q_begin + i] * stride];
+    if constexpr (FAST) sbits |= sign_of<T>(v);
+    win[i] = (double)v;
+  }
   for (int qq = q_begin; qq < q_end; qq += K * U) {
     // the U chunks of one turn of the ring, expanded at compile time (static_for_until: stops at the segment end)
     auto chunk = [&](auto cc) -> bool {
@@ -100,12 +131,41 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
 #pragma unroll
       for (int i = 0; i < K; ++i) nxt[i] = in[base + (size_t)bmap[q0 + K + 2 * R + i] * stride];
       double acc[K];
+      bool redo = true;
+      if constexpr (FAST) {
+        if (cert >= 0 && (int)sbits >= 0) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] = win[(o + k + R) % W] * taps.w[0];
+          for (int k = 0; k < K; ++k) acc[k] = win[(o + k + R) % W] * taps.w[0];
 #pragma unroll
-      for (int j = R; j >= 1; --j) {
+          for (int j = R; j >= 1; --j) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = acc[k] + (win[(o + k + R - j) % W] + win[(o + k + R + j) % W]) * taps.w[j];
+            for (int k = 0; k < K; ++k)
+              acc[k] = __builtin_fma(win[(o + k + R - j) % W] + win[(o + k + R + j) % W], taps.w[j], acc[k]);
+          }
+          redo = false;
+#pragma unroll
+          for (int k = 0; k < K; ++k) redo |= uncertain<T>(acc[k], cert);
+        }
+      }
+      if (redo) {   // the reference sequence: separate multiply and add, same order
+        // `one` is 1.0 the compiler cannot see through: without it the pair sums of this (rare) branch are shared
+        // with the fused branch above and all 30*K of them are kept live across the branch (x * 1.0 is exact)
+        double one = 1.0;
+        if constexpr (FAST) asm volatile("" : "+v"(one));
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = win[(o + k + R) % W] * taps.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const double a = FAST ? win[(o + k + R - j) % W] * one : win[(o + k + R - j) % W];
+            acc[k] = acc[k] + (a + win[(o + k + R + j) % W]) * taps.w[j];
+          }
+        }
+      }
+      if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sbits |= sign_of<T>(nxt[i]);
       }
       if constexpr (TR) {
         const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -361,6 +421,9 @@ __global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T*
 }
 
 // KZ / KS / KC: outputs per chunk of the axis-0 pass, of the other strided passes, of the LDS-transposed pass
+int g_cert = -2;   // -2: default guard (4R+8 ulps), -1: fused path off, >= 0: guard distance in ulps (tests)
+inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
+
 template <class T, int R, int KS, int KC, int KZ = KS>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
@@ -412,7 +475,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     ia3rt::ProfScope ps(nz.c_str());
     const int seg = seg_for_k(Z, (long long)plane, KZ);
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
-    hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg);
+    hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg, cert_for(R));
   }
   if constexpr (R >= 16) {
     // long filters are f64-VALU-bound: give the contiguous axis the register-window kernel too, by transposing
@@ -421,13 +484,13 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
       ia3rt::ProfScope ps(nx.c_str());
       const int seg = seg_for(X, (long long)Y * Z);
       dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
-      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg);
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert_for(R));
     }
     {  // axis 2: tmp[z][y][x] -> dst[z][x][y]: lanes along x, filter along y with stride X, transposed store
       ia3rt::ProfScope ps(ny.c_str());
       const int seg = seg_for(Y, (long long)X * Z);
       dim3 g((unsigned)((X + 255) / 256), (unsigned)Z, (unsigned)((Y + seg - 1) / seg));
-      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)tmp, dst, X, (size_t)X, Y, plane, t, (const int*)my, seg);
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)tmp, dst, X, (size_t)X, Y, plane, t, (const int*)my, seg, cert_for(R));
     }
     return 0;
   }
@@ -437,7 +500,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     ia3rt::ProfScope ps(nx.c_str());
     const int seg = seg_for(X, (long long)Y * Z);
     dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
-    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg);
+    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert_for(R));
   }
   // axis 2: tmp -> dst
   {
@@ -535,6 +598,15 @@ int highpass_combine(const void* im, const void* low, int dtype, size_t n, void*
 using namespace ia3rt;
 
 extern "C" {
+
+int ia3_set_tuning(int key, int value) {
+  if (key == IA3_TUNE_GAUSS_CERT) {
+    if (value < -2) return set_error(IA3_EINVAL, "IA3_TUNE_GAUSS_CERT: value must be >= -2");
+    g_cert = value;
+    return 0;
+  }
+  return set_error(IA3_EINVAL, "unknown tuning key");
+}
 
 static int taps_or_default(double sigma, double truncate, const double* weights, int radius,
                            std::vector<double>& w, int& R) {

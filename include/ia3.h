@@ -49,6 +49,11 @@ int ia3_release_workspace(void);          /* drop cached device scratch buffers 
 /* per-kernel timing with HIP events on the library stream (off by default) */
 int ia3_profile_enable(int on);
 int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines since last collect */
+/* Test / tuning knobs; results never depend on them.  IA3_TUNE_GAUSS_CERT: guard distance (f64 ulps) of the
+ * certified fused-multiply-add path of the long Gaussian passes; -2 default (4R+8), -1 path off (always the
+ * reference operation sequence), large values send every output through the reference sequence after the check. */
+#define IA3_TUNE_GAUSS_CERT 1
+int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out);

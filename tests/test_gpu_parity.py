@@ -810,3 +810,46 @@ def test_fit_fov_images_concurrent_equals_sequential():
         assert len(par) == len(seq)
         for a, b in zip(par, seq):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def _set_gauss_cert(v):
+    import ctypes as C
+    from imageanalysis3_amd import _lib as L
+    L.check(L.lib().ia3_set_tuning(C.c_int(1), C.c_int(v)))
+
+
+def test_gaussian_long_filter_certified_fused_path_bit_exact():
+    """The sigma-7.5 passes use fused multiply-adds where the float32 / uint16 value is provably unaffected and the
+    reference operation sequence elsewhere.  Same bits as SciPy with the default guard, with the fused path off and
+    with every output sent through the reference sequence, on inputs built to sit on quantisation boundaries:
+    piecewise-constant uint16 (every sum is within an ulp of an integer, truncation flips on the last bit),
+    zeros, mixed signs and negative zeros (fused path must step aside)."""
+    from scipy import ndimage as ndi
+    from imageanalysis3_amd.correction_tools.filter import gaussian_filter
+    rng = np.random.RandomState(11)
+    shape = (40, 256, 384)
+    blocks = np.zeros(shape, np.uint16)
+    vals = rng.randint(1, 65535, size=(2, 3))
+    for i in range(2):
+        for j in range(3):
+            blocks[:, i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = vals[i, j]
+    pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
+    pos[:, :64, :64] = 0                      # exact zeros
+    pos[:, 64:128, :64] = 400.0               # constant block
+    mixed = rng.normal(0, 300.0, size=shape).astype(np.float32)
+    negz = pos.copy(); negz[5:9, 100:140, 200:260] = -0.0
+    u16 = np.clip(rng.gamma(2.0, 300.0, size=shape), 0, 65535).astype(np.uint16)
+    cases = {"blocks_u16": blocks, "pos_f32": pos, "mixed_f32": mixed, "negzero_f32": negz, "gamma_u16": u16}
+    try:
+        for name, im in cases.items():
+            ref = ndi.gaussian_filter(im, 7.5, mode="reflect", truncate=4.0)
+            for cert in (-2, -1, 1 << 28):
+                _set_gauss_cert(cert)
+                got = gaussian_filter(im, 7.5, mode="reflect", truncate=4.0)
+                if im.dtype == np.float32:   # compare bit patterns: -0.0 vs +0.0 counts
+                    same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+                else:
+                    same = np.array_equal(got, ref)
+                assert same, (name, cert, int((got != ref).sum()))
+    finally:
+        _set_gauss_cert(-2)
