@@ -5,6 +5,20 @@ import numpy as np
 from .. import visual_tools
 from ..External import Fitting_v3
 
+# classes/__init__.py:22-34 — data types a FOV save file may hold, and the default spot-table length
+_allowed_kwds = {'combo': 'c',
+                 'decoded': 'd',
+                 'unique': 'u',
+                 'relabeled_combo': 'l',
+                 'relabeled_unique': 'v',
+                 'merfish': 'm',
+                 'rna': 'r',
+                 'gene': 'g',
+                 'protein': 'p',
+                 }
+_max_num_seeds = 4000
+_min_num_seeds = 50
+
 
 def _fit_single_image(_im, _id, _chrom_coords, _seeding_args, _fitting_args, _check_fitting=True,
                       _normalization=True, _verbose=False):

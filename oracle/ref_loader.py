@@ -178,3 +178,27 @@ def load_chromatic():
     ch = ns._load("IA3.correction_tools.chromatic", REF + "/correction_tools/chromatic.py")
     ns.chromatic = ch
     return ch
+
+
+def load_batch():
+    """Execute the reference's classes/batch_functions.py (save-file helpers + batch_process_image_to_spots).
+    Needs h5py: run under an interpreter that has it (``/opt/conda/bin/python3.9`` in this image; see
+    oracle/make_golden_h5.py).  Returns the module."""
+    ns = load_reference()
+    if getattr(ns, "batch", None) is not None:
+        return ns.batch
+    import ast
+    import sys
+    import h5py  # noqa: F401  (the real one)
+    load_corrections()
+    load_chromatic()
+    cl = sys.modules["IA3.classes"]
+    src = open(REF + "/classes/__init__.py").read()
+    for node in ast.parse(src).body:   # the literal dict of allowed data types, :22-32
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "_allowed_kwds":
+            cl._allowed_kwds = ast.literal_eval(node.value)
+    cl._image_dtype = ns._root._image_dtype
+    sys.modules["h5py"] = h5py   # load_io may have parked an empty stand-in there
+    b = ns._load("IA3.classes.batch_functions", REF + "/classes/batch_functions.py")
+    ns.batch = b
+    return b

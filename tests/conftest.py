@@ -111,6 +111,35 @@ def build_chain_case():
                 drift=[0.3, -1.2, 2.5])
 
 
+def h5_helper_inputs():
+    """Images / spot tables of the save-file helper fixtures (oracle/make_golden_h5.py::helpers_golden)."""
+    rng = np.random.RandomState(5)
+    ims = [rng.randint(0, 60000, size=(4, 8, 8)).astype(np.uint16) for _ in range(3)]
+    spots = [rng.rand(n, 11).astype(np.float32) * 100 for n in (3, 7, 2)]
+    raw = [s + np.float32(0.5) for s in spots]
+    return ims, spots, raw
+
+
+def batch_inputs():
+    """Movie + correction / fitting arguments of the batch_process_image_to_spots fixtures
+    (oracle/make_golden_h5.py::batch_golden): the chain case, dense chromatic fields for the warped variant and
+    polynomial constants for the unwarped one."""
+    case = build_chain_case()
+    size = [case["Z"], case["X"], case["Y"]]
+    corr = dict(single_im_size=size, all_channels=case["chs"], num_buffer_frames=case["nb"], num_empty_frames=0,
+                corr_channels=case["chs"][:3], illumination_profile=case["illum"], bleed_profile=case["bleed"],
+                chromatic_profile=case["chrom"])
+    rng = np.random.RandomState(21)
+    consts = {}
+    for c in case["chs"][:3]:
+        consts[c] = None if c == '647' else {'constants': [rng.randn(4) * np.array([0.3, 1e-3, 1e-4, 1e-4]) for _ in range(3)],
+                                             'fitting_orders': np.array([1, 1, 1]),
+                                             'ref_center': np.array([size[0] / 2., size[1] / 2., size[2] / 2.])}
+    corr_nowarp = dict(corr, chromatic_profile=consts)
+    fit = dict(max_num_seeds=20, seeding_kwargs={})
+    return case, size, corr, corr_nowarp, fit
+
+
 def write_dax(path, raw):
     raw.astype('<u2').tofile(path)
     with open(path[:-4] + ".inf", "w") as f:

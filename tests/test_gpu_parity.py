@@ -4,6 +4,7 @@ fixtures produced by the reference, and against the NumPy oracle on the same see
 Tolerances (BASELINE.json north_star): integer / index work bit-exact (filters in the stack dtype,
 seed coordinates); fitted (h, z, x, y, bk, sigma_z, sigma_x, sigma_y) within 1e-4 relative.
 """
+import os
 import zlib
 import numpy as np
 import pytest
@@ -853,3 +854,80 @@ def test_gaussian_long_filter_certified_fused_path_bit_exact():
                 assert same, (name, cert, int((got != ref).sum()))
     finally:
         _set_gauss_cert(-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# production entry: movie -> corrected images + drift + spots in the FOV save file
+# ---------------------------------------------------------------------------------------------
+def _spot_tables_close(got, ref, what):
+    """Stored (n, L, 11) tables: same occupied rows, rows within the fit tolerance (order = fit order)."""
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    occ_g, occ_r = got.any(axis=2), ref.any(axis=2)
+    assert np.array_equal(occ_g, occ_r), (what, occ_g.sum(1), occ_r.sum(1))
+    for i in range(len(ref)):
+        n = int(occ_r[i].sum())
+        if n:
+            a, b = got[i, :n].astype(np.float64), ref[i, :n].astype(np.float64)
+            # background column of spots on removed hot columns is exp(-large): compare it on an absolute scale
+            cols = [0, 1, 2, 3, 5, 6, 7]
+            rel = np.abs(a[:, cols] - b[:, cols]) / np.abs(b[:, cols])
+            assert rel.max() <= 1e-3, (what, i, rel.max())
+            assert (rel <= RTOL).mean() >= 0.9, (what, i, (rel <= RTOL).mean())
+            assert np.abs(a[:, 4] - b[:, 4]).max() <= 1e-3 * max(np.abs(b[:, 4]).max(), 1.0), (what, i)
+
+
+@pytest.mark.parametrize("tag,warp", [("w_", True), ("n_", False)])
+def test_batch_process_image_to_spots_golden(tag, warp, tmp_path):
+    """classes/batch_functions.py:60-303 run by the reference (h5py) on the synthetic movie: first pass with a stored
+    drift, second pass resuming from the save file (images carried over, tables kept), third pass overwriting the
+    spots.  Images, flags and drifts identical; spot tables within the fit tolerance."""
+    from conftest import batch_inputs, write_dax
+    from imageanalysis3_amd.classes import batch_functions as B
+    from imageanalysis3_amd.io_tools import h5lite as H
+    if not H.available():
+        pytest.skip("libhdf5 not present")
+    gold = load_golden("h5batch.npz")
+    case, size, corr, corr_nowarp, fit = batch_inputs()
+    os.makedirs(str(tmp_path / "H1R1"))
+    movie = str(tmp_path / "H1R1" / "Conv_zscan_05.dax")
+    write_dax(movie, case["raw"])
+    ref_im = np.zeros(size, np.uint16)
+    cargs = corr if warp else corr_nowarp
+    path = str(tmp_path / "fov.hdf5")
+    B.create_fov_save_file(path, 'unique', [5, 2, 9], ['750', '647', '561'], size, max_num_seeds=4)
+    with H.File(path, "a", libver="latest") as f:
+        f['unique']['drifts'][:2, :] = np.array(case["drift"], np.float32)
+
+    def check(prefix):
+        with H.File(path, "r") as f:
+            g = f['unique']
+            for k in ('ids', 'channels', 'flags', 'drifts'):
+                assert np.array_equal(g[k][...], gold[prefix + k]), (prefix, k)
+            crcs = [zlib.crc32(np.ascontiguousarray(g['ims'][i]).tobytes()) & 0xFFFFFFFF for i in range(3)]
+            assert crcs == [int(c) for c in gold[prefix + 'ims_crc']], (prefix, crcs)
+            _spot_tables_close(g['spots'][...], gold[prefix + 'spots'], prefix + 'spots')
+            _spot_tables_close(g['raw_spots'][...], gold[prefix + 'raw_spots'], prefix + 'raw_spots')
+
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], ref_im, warp_image=warp,
+                                             correction_args=dict(cargs), fitting_args=dict(fit), verbose=warp)
+        assert out is None
+        check(tag)
+        B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], ref_im, warp_image=warp,
+                                       correction_args=dict(cargs), fitting_args=dict(fit, max_num_seeds=3), verbose=warp)
+        check(tag + "again_")
+        sp, raw = B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], ref_im, warp_image=warp,
+                                                 correction_args=dict(cargs), fitting_args=dict(fit, max_num_seeds=3),
+                                                 overwrite_spot=True, verbose=warp, return_spots=True)
+        check(tag + "over_")
+    assert len(sp) == 2 and all(len(s) <= 3 for s in sp)
+    # argument checks of the reference (:92-118)
+    with pytest.raises(IOError):
+        B.batch_process_image_to_spots(movie[:-4] + ".tif", ['750'], path, 'unique', [5], ref_im)
+    with pytest.raises(IOError):
+        B.batch_process_image_to_spots(movie, ['750'], path[:-5] + ".h5", 'unique', [5], ref_im)
+    with pytest.raises(TypeError):
+        B.batch_process_image_to_spots(movie, ['750'], path, 'unique', [5], 3)
+    with pytest.raises(ValueError):
+        B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5], ref_im)
