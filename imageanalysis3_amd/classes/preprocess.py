@@ -632,8 +632,63 @@ class DaxProcesser():
             return
         return _spots_list
 
-    def _fit_spots_by_segmentation(self, *args, **kwargs):
-        raise NotImplementedError("segmentation-driven fitting (:1093-1153) depends on the segmentation tools, out of scope")
+    def _fit_spots_by_segmentation(self, channel, seg_label, th_seed=500, num_spots=None, fitting_kwargs={},
+                                   segment_search_radius=3, save_attrs=True, verbose=False):
+        """:1093-1153 — per label of ``seg_label``: bounding box (shifted by the drift), ``fit_fov_image`` on that crop
+        of the resident stack, keep the spots whose neighbourhood votes for the label.  ``seg_label`` is a host array
+        (segmentation itself is out of scope); the crops are cut on the device."""
+        from ..segmentation_tools.cell import segmentation_mask_2_bounding_box
+        from ..spot_tools.fitting import fit_fov_image
+        from .partition_spots import Spots_Partition
+        _drift = getattr(self, 'drift', np.zeros(len(self.image_size)))
+        if self.verbose:
+            print(f"- Start fitting spots in each segmentation")
+        _cell_ids = np.unique(seg_label)
+        _cell_ids = _cell_ids[_cell_ids > 0]
+        _stack = self._dev[str(channel)]
+        _all_spots, _all_cell_ids = [], []
+        for _cell_id in _cell_ids:
+            _cell_mask = (seg_label == _cell_id)
+            _crop = segmentation_mask_2_bounding_box(_cell_mask, 3)   # sic (:1117): 3 lands in cell_id, margin stays 1
+            _drift_crop = _crop.translate_drift(drift=_drift)
+            _local = _stack.crop(_drift_crop.array)
+            try:
+                _spots = fit_fov_image(_local, str(channel), th_seed=th_seed, max_num_seeds=num_spots,
+                                       verbose=verbose, **fitting_kwargs)
+            finally:
+                _local.free()
+            if len(_spots) > 0:
+                _spots = Spots3D(_spots)
+                _spots[:, _spots.coordinate_indices] = _spots[:, _spots.coordinate_indices] + _drift_crop.array[:, 0]
+                _kept_flg = Spots_Partition.spots_to_labels(_cell_mask, _spots, search_radius=segment_search_radius,
+                                                            verbose=False)
+                _spots = _spots[_kept_flg > 0]
+                if len(_spots) > 0:
+                    _all_spots.append(_spots)
+                    _all_cell_ids.append(np.ones(len(_spots), dtype=np.int32) * _cell_id)
+        if len(_all_spots) > 0:
+            _all_spots = np.concatenate(_all_spots)
+            _all_cell_ids = np.concatenate(_all_cell_ids)
+        else:
+            _all_spots = np.array([])
+            _all_cell_ids = np.array([])
+            print(f"No spots detected.")
+        if save_attrs:
+            setattr(self, f"spots_{channel}", _all_spots)
+            setattr(self, f"spots_cell_ids_{channel}", _all_cell_ids)
+            return
+        return _all_spots, _all_cell_ids
+
+    # saving / loading: empty in the reference as well (:1155-1164)
+    def _save_to_hdf5(self):
+        pass
+
+    def _save_to_npy(self, save_channels, save_folder=None, save_basenames=None):
+        if save_folder is None:
+            pass
+
+    def _load_from_hdf5(self):
+        pass
 
     # -- file helpers -------------------------------------------------------------------------------------------------
     @staticmethod
@@ -649,6 +704,38 @@ class DaxProcesser():
             return [_ch for _ch in _names if len(re.findall(r'^[0-9]+$', _ch))]
         except Exception:
             return None
+
+    @staticmethod
+    def _FindGlobalPosition(dax_filename, verbose=True):
+        """:1184-1195 — stage position (micron) from the .xml next to the movie."""
+        import xml.etree.ElementTree as ET
+        try:
+            _hal_info = ET.parse(dax_filename.replace('.dax', '.xml')).getroot()
+            return np.array(_hal_info.findall('acquisition/stage_position')[0].text.split(','), dtype=np.float64)
+        except Exception:
+            raise ValueError(f"Positions not properly parsed")
+
+    @staticmethod
+    def _LoadSegmentation(segmentation_filename, fov_id=None, verbose=True):
+        """:1234-1255 — label image from .npy / .pkl / .hdf5 (``<fov_id>/dna_mask``)."""
+        import os
+        import pickle
+        if not isinstance(segmentation_filename, str) or not os.path.isfile(segmentation_filename):
+            raise ValueError(f"invalid segmentation_filename: {segmentation_filename}")
+        if verbose:
+            print(f"-- load segmentation from: {segmentation_filename}")
+        _ext = segmentation_filename.split(os.extsep)[-1]
+        if _ext == 'npy':
+            _seg_label = np.load(segmentation_filename)
+        elif _ext == 'pkl':
+            _seg_label = pickle.load(open(segmentation_filename, 'rb'))
+        elif _ext == 'hdf5' or _ext == 'h5':
+            from ..io_tools import h5lite as h5py
+            with h5py.File(segmentation_filename, 'r') as _f:
+                if fov_id is None:
+                    fov_id = list(_f.keys())[0]
+                _seg_label = _f[str(fov_id)]['dna_mask'][:]
+        return _seg_label
 
     @staticmethod
     def _LoadInfFile(inf_filename):

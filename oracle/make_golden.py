@@ -257,6 +257,37 @@ def daxp_golden(meta):
     np.savez_compressed(os.path.join(OUT, "daxp.npz"), **d)
 
 
+def seg_golden(meta):
+    """classes/preprocess.py:1093-1153 DaxProcesser._fit_spots_by_segmentation run by the reference on the movie of
+    the chain case with the label image of tests/conftest.py::seg_labels."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import conftest as T
+    ref_loader.load_corrections()
+    ref_loader.load_partition()
+    pre = sys.modules["IA3.classes.preprocess"]
+    case = T.build_chain_case()
+    size = [case["Z"], case["X"], case["Y"]]
+    lab = T.seg_labels(size)
+    d = {"lab_crc": crc(lab)}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "movie.dax")
+        T.write_dax(path, case["raw"])
+        p = pre.DaxProcesser(path, Channels=case["chs"], DriftChannel='488', verbose=False)
+        quiet(p._load_image, ImSize=size, NbufferFrame=case["nb"])
+        quiet(p._corr_hot_pixels_3D)
+        with open(os.devnull, "w") as nul, contextlib.redirect_stderr(nul):   # tqdm bar
+            quiet(p._fit_spots_by_segmentation, '647', lab, th_seed=300, segment_search_radius=3)
+            d["spots_647"], d["ids_647"] = np.array(p.spots_647), np.array(p.spots_cell_ids_647)
+            p.drift = np.array(case["drift"])
+            out = quiet(p._fit_spots_by_segmentation, '750', lab, th_seed=300, num_spots=2, save_attrs=False)
+            d["spots_750"], d["ids_750"] = np.array(out[0]), np.array(out[1])
+            out = quiet(p._fit_spots_by_segmentation, '561', (lab == 4) * 4, th_seed=300, save_attrs=False)
+            d["spots_561"], d["ids_561"] = np.array(out[0]), np.array(out[1])
+    np.savez_compressed(os.path.join(OUT, "seg.npz"), **d)
+    print("seg", {k: np.shape(v) for k, v in d.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -388,6 +419,7 @@ def main():
     chain_golden(meta)
     chromfn_golden(meta)
     daxp_golden(meta)
+    seg_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
@@ -395,4 +427,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:   # regenerate single fixtures: python oracle/make_golden.py seg_golden ...
+        for _name in sys.argv[1:]:
+            globals()[_name]({})
+    else:
+        main()

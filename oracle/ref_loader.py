@@ -202,3 +202,39 @@ def load_batch():
     b = ns._load("IA3.classes.batch_functions", REF + "/classes/batch_functions.py")
     ns.batch = b
     return b
+
+
+def load_partition():
+    """Execute what DaxProcesser._fit_spots_by_segmentation imports (classes/preprocess.py:1102-1104): the reference's
+    segmentation_tools/cell.py (for segmentation_mask_2_bounding_box) and classes/partition_spots.py (for
+    Spots_Partition.spots_to_labels).  Plotting modules are stubbed.  Returns (cell module, partition module)."""
+    ns = load_reference()
+    if getattr(ns, "partition", None) is not None:
+        return ns.seg_cell, ns.partition
+    import sys
+    load_corrections()
+    cl = sys.modules["IA3.classes"]
+    cl.default_pixel_sizes = [250, 108, 108]
+    ft = types.ModuleType("IA3.figure_tools")
+    ft.__path__ = []
+    sys.modules["IA3.figure_tools"] = ft
+    for name, attr in (("plot_segmentation", "plot_segmentation"), ("plot_partition", "plot_cell_spot_counts")):
+        m = types.ModuleType("IA3.figure_tools." + name)
+        setattr(m, attr, None)
+        sys.modules["IA3.figure_tools." + name] = m
+    io = sys.modules["IA3.io_tools"]
+    io.parameters = ns._load("IA3.io_tools.parameters", REF + "/io_tools/parameters.py")
+    io.spots = ns._load("IA3.io_tools.spots", REF + "/io_tools/spots.py")
+    import numpy as np
+    import numpy.lib.npyio as _npyio
+    if not hasattr(_npyio, "save"):   # cell.py:3 imports it from its pre-2.0 location (unused)
+        _npyio.save = np.save
+    st = types.ModuleType("IA3.segmentation_tools")
+    st.__path__ = []
+    sys.modules["IA3.segmentation_tools"] = st
+    cell = ns._load("IA3.segmentation_tools.cell", REF + "/segmentation_tools/cell.py")
+    st.cell = cell
+    part = ns._load("IA3.classes.partition_spots", REF + "/classes/partition_spots.py")
+    cl.partition_spots = part
+    ns.seg_cell, ns.partition = cell, part
+    return cell, part

@@ -140,6 +140,20 @@ def batch_inputs():
     return case, size, corr, corr_nowarp, fit
 
 
+def seg_labels(shape):
+    """Label image for the segmentation-driven fit fixtures: a quadrant box (1), a central ellipsoid (2), a thin
+    slab along one edge (3) and a 3-voxel speck (4)."""
+    Z, X, Y = shape
+    lab = np.zeros(shape, np.int32)
+    lab[1:Z - 1, 2:X // 2 - 2, 3:Y // 2 - 1] = 1
+    z, x, y = np.meshgrid(np.arange(Z), np.arange(X), np.arange(Y), indexing='ij')
+    ell = ((z - Z / 2.) / (Z / 2.2)) ** 2 + ((x - 0.66 * X) / (X / 4.)) ** 2 + ((y - 0.6 * Y) / (Y / 3.5)) ** 2 <= 1
+    lab[ell & (lab == 0)] = 2
+    lab[:, X - 4:X, 0:Y // 2] = 3
+    lab[Z // 2, 5, Y - 6:Y - 3] = 4
+    return lab
+
+
 def write_dax(path, raw):
     raw.astype('<u2').tofile(path)
     with open(path[:-4] + ".inf", "w") as f:

@@ -792,8 +792,7 @@ def test_daxprocesser_steps_golden_bit_exact(tag, rescale, illum64, tmp_path):
             assert np.array_equal(getattr(p, "spots_cell_ids_" + c), np.zeros(len(ref), np.int32))
         # drift against itself: flag 0, zeros; against a shifted copy of the bead channel through align_image
         assert p._calculate_drift(path, DriftChannel='488', save_attr=False) == (pytest.approx(np.zeros(3)), 0)
-        with pytest.raises(NotImplementedError):
-            p._fit_spots_by_segmentation('647', None)
+        assert p._save_to_hdf5() is None and p._load_from_hdf5() is None   # empty in the reference too (:1155-1164)
     # assigning an image uploads it; deleting frees it
     p.im_561 = np.zeros((case["Z"], case["X"], case["Y"]), np.uint16)
     assert p.im_561.sum() == 0
@@ -931,3 +930,36 @@ def test_batch_process_image_to_spots_golden(tag, warp, tmp_path):
         B.batch_process_image_to_spots(movie, ['750'], path, 'unique', [5], 3)
     with pytest.raises(ValueError):
         B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5], ref_im)
+
+
+def test_daxprocesser_fit_spots_by_segmentation_golden(tmp_path):
+    """classes/preprocess.py:1093-1153 against the reference's own run: per-label crops (with and without a drift),
+    kept spots and their labels; a label whose box holds no seed contributes nothing."""
+    import contextlib, io
+    from conftest import seg_labels, build_chain_case, write_dax
+    from imageanalysis3_amd.classes.preprocess import DaxProcesser
+    from imageanalysis3_amd.segmentation_tools.cell import segmentation_mask_2_bounding_box
+    g = load_golden("seg.npz")
+    case = build_chain_case()
+    size = [case["Z"], case["X"], case["Y"]]
+    lab = seg_labels(size)
+    assert (zlib.crc32(np.ascontiguousarray(lab).tobytes()) & 0xFFFFFFFF) == int(g["lab_crc"])
+    box = segmentation_mask_2_bounding_box(lab == 2, 3)        # 3 is taken as cell_id (absent): margin stays 1
+    zz, xx, yy = np.where(lab == 2)
+    assert box.array.tolist() == [[max(zz.min() - 1, 0), min(zz.max() + 2, size[0])], [xx.min() - 1, xx.max() + 2],
+                                  [yy.min() - 1, yy.max() + 2]]
+    path = str(tmp_path / "movie.dax")
+    write_dax(path, case["raw"])
+    p = DaxProcesser(path, Channels=case["chs"], DriftChannel='488', verbose=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p._load_image(ImSize=size, NbufferFrame=case["nb"])
+        p._corr_hot_pixels_3D()
+        assert p._fit_spots_by_segmentation('647', lab, th_seed=300, segment_search_radius=3) is None
+        p.drift = np.array(case["drift"])
+        s750, i750 = p._fit_spots_by_segmentation('750', lab, th_seed=300, num_spots=2, save_attrs=False)
+        s561, i561 = p._fit_spots_by_segmentation('561', (lab == 4) * 4, th_seed=300, save_attrs=False)
+    assert np.array_equal(p.spots_cell_ids_647, g["ids_647"]) and p.spots_cell_ids_647.dtype == np.int32
+    assert_rows_close(np.asarray(p.spots_647), g["spots_647"])
+    assert np.array_equal(i750, g["ids_750"])
+    assert_rows_close(np.asarray(s750), g["spots_750"])
+    assert len(s561) == 0 and len(i561) == 0 and g["spots_561"].shape == (0,)
