@@ -351,8 +351,14 @@ class DaxProcesser():
             if self.verbose:
                 print("- Correct bleedthrough already finished, skip. ")
             return
-        if correction_pf is None:
-            raise NotImplementedError("pass correction_pf (loading the correction folder is out of scope)")
+        if correction_folder is None:
+            correction_folder = self.correction_folder
+        if correction_pf is None:                                            # :494-502
+            from ..io_tools.load import load_correction_profile
+            correction_pf = load_correction_profile('bleedthrough', _correction_channels,
+                                                    correction_folder=correction_folder,
+                                                    ref_channel=_correction_channels[0], all_channels=self.channels,
+                                                    im_size=self.image_size, verbose=self.verbose)
         if any(_ch not in self._dev for _ch in _correction_channels):
             raise NotImplementedError("bleedthrough correction needs every correction channel loaded")
         _n = len(_correction_channels)
@@ -412,8 +418,14 @@ class DaxProcesser():
                 print("- Correct illumination already finished, skip. ")
             return
         _correction_channels = [_ch for _ch, _log in zip(_correction_channels, _logs) if not _log]
-        if correction_pf is None:
-            raise NotImplementedError("pass correction_pf (loading the correction folder is out of scope)")
+        if correction_folder is None:
+            correction_folder = self.correction_folder
+        if correction_pf is None:                                            # :635-643
+            from ..io_tools.load import load_correction_profile
+            correction_pf = load_correction_profile('illumination', _correction_channels,
+                                                    correction_folder=correction_folder,
+                                                    ref_channel=_correction_channels[0], all_channels=self.channels,
+                                                    im_size=self.image_size, verbose=self.verbose)
         _stacks = []
         for _ch in _correction_channels:
             if _ch not in self._dev:
@@ -439,8 +451,14 @@ class DaxProcesser():
         if np.array(_logs).all():
             return
         _correction_channels = [_ch for _ch, _log in zip(_correction_channels, _logs) if not _log]
-        if correction_pf is None:
-            raise NotImplementedError("pass correction_pf (loading the correction folder is out of scope)")
+        if correction_folder is None:
+            correction_folder = self.correction_folder
+        if correction_pf is None:                                            # :716-724
+            from ..io_tools.load import load_correction_profile
+            correction_pf = load_correction_profile('chromatic_constants', _correction_channels,
+                                                    correction_folder=correction_folder, all_channels=self.channels,
+                                                    ref_channel=ref_channel, im_size=self.image_size,
+                                                    verbose=self.verbose)
         _drift = getattr(self, 'drift', np.zeros(len(self.image_size)))
         _funcs = []
         for _ch in _correction_channels:
@@ -547,8 +565,14 @@ class DaxProcesser():
             if self.verbose:
                 print("- Warp drift and chromatic already finished, skip. ")
             return
-        if corr_chromatic and chromatic_pf is None:
-            raise NotImplementedError("pass chromatic_pf (loading the correction folder is out of scope)")
+        if correction_folder is None:
+            correction_folder = self.correction_folder
+        if corr_chromatic and chromatic_pf is None:                          # :889-897
+            from ..io_tools.load import load_correction_profile
+            chromatic_pf = load_correction_profile('chromatic', _chromatic_channels,
+                                                   correction_folder=correction_folder, all_channels=self.channels,
+                                                   ref_channel=ref_channel, im_size=self.image_size,
+                                                   verbose=self.verbose)
         _done_chs, _stacks = [], []
         for _ch in _correction_channels:
             _finish_warp = _ch_2_finish_warp.get(_ch)
@@ -761,3 +785,17 @@ class DaxProcesser():
             return np.array([int(_dz), _dx, _dy], dtype=np.int32)
         except Exception:
             return np.array(default_im_size)
+
+
+def batch_process_image_quick(dax_filename, correction_folder, sel_channels, drift_channel='488', dapi_channel='405',
+                              corr_hot_pixels=True, corr_illumination=True, verbose=True):
+    """classes/preprocess.py:1257-1278 — load the selected channels of one movie, remove hot pixels, divide by the
+    illumination profiles found in ``correction_folder``; returns the images."""
+    _cls = DaxProcesser(dax_filename, correction_folder, Channels=None, DriftChannel=drift_channel,
+                        DapiChannel=dapi_channel, verbose=verbose)
+    _cls._load_image(sel_channels=sel_channels)
+    if corr_hot_pixels:
+        _cls._corr_hot_pixels_3D(correction_channels=sel_channels)
+    if corr_illumination:
+        _cls._corr_illumination(correction_channels=sel_channels)
+    return [getattr(_cls, f"im_{_ch}") for _ch in sel_channels]

@@ -61,6 +61,76 @@ def _stack3(im):
     return L.as_stack_array(a)
 
 
+def load_correction_profile(corr_type, corr_channels=None,
+                            correction_folder=None, all_channels=None,
+                            ref_channel='647', im_size=None, verbose=False):
+    """io_tools/load.py:553-640 — read a correction profile from the correction folder:
+    ``bleedthrough_correction_<chs high→low>_<X>_<Y>.npy`` -> (C,C,X,Y) array;
+    ``chromatic_correction_<ch>_<ref>_<Z>_<X>_<Y>.npy`` -> dict of dense fields (None for the reference channel);
+    ``chromatic_correction_<ch>_<ref>_<Z>_<X>_<Y>_const.pkl`` -> dict of polynomial constants;
+    ``illumination_correction_<ch>_<X>x<Y>.npy`` -> dict of (X,Y) maps."""
+    import os
+    import pickle
+    from .. import _corr_channels, _correction_folder, _allowed_colors, _image_size
+    corr_channels = _corr_channels if corr_channels is None else corr_channels
+    correction_folder = _correction_folder if correction_folder is None else correction_folder
+    all_channels = _allowed_colors if all_channels is None else all_channels
+    im_size = _image_size if im_size is None else im_size
+    _allowed_types = ['chromatic', 'illumination', 'bleedthrough', 'chromatic_constants']
+    _type = str(corr_type).lower()
+    if _type not in _allowed_types:
+        raise ValueError(f"Wrong input corr_type, should be one of {_allowed_types}")
+    _all_channels = [str(_ch) for _ch in all_channels]
+    _corr_channels_ = [str(_ch) for _ch in corr_channels]
+    for _channel in _corr_channels_:
+        if _channel not in _all_channels:
+            raise ValueError(f"Wrong input channel:{_channel}, should be one of {_all_channels}")
+    _ref_channel = str(ref_channel).lower()
+    if _ref_channel not in _all_channels:
+        raise ValueError(f"Wrong input ref_channel:{_ref_channel}, should be one of {_all_channels}")
+    if verbose:
+        print(f"-- loading {_type} correction profile from file", end=':')
+    if _type == 'bleedthrough':
+        _basename = _type + '_correction' \
+            + '_' + '_'.join(sorted(_corr_channels_, key=lambda v: -int(v))) \
+            + '_' + str(im_size[-2]) + '_' + str(im_size[-1]) + '.npy'
+        if verbose:
+            print(_basename)
+        _pf = np.load(os.path.join(correction_folder, _basename), allow_pickle=True)
+        _pf = _pf.reshape(len(_corr_channels_), len(_corr_channels_), im_size[-2], im_size[-1])
+    elif _type == 'chromatic' or _type == 'chromatic_constants':
+        if verbose:
+            print('')
+        _pf = {}
+        for _channel in _corr_channels_:
+            if _channel != _ref_channel:
+                _basename = 'chromatic_correction' + '_' + str(_channel) + '_' + str(_ref_channel)
+                for _d in im_size:
+                    _basename += f'_{int(_d)}'
+                _basename += '.npy' if _type == 'chromatic' else '_const.pkl'
+                if verbose:
+                    print('\t', _channel, _basename)
+                if _type == 'chromatic':
+                    _pf[_channel] = np.load(os.path.join(correction_folder, _basename), allow_pickle=True)
+                else:
+                    _pf[_channel] = pickle.load(open(os.path.join(correction_folder, _basename), 'rb'))
+            else:
+                if verbose:
+                    print('\t', _channel, None)
+                _pf[_channel] = None
+    elif _type == 'illumination':
+        if verbose:
+            print('')
+        _pf = {}
+        for _channel in _corr_channels_:
+            _basename = _type + '_correction' + '_' + str(_channel) \
+                + '_' + str(im_size[-2]) + 'x' + str(im_size[-1]) + '.npy'
+            if verbose:
+                print('\t', _channel, _basename)
+            _pf[_channel] = np.load(os.path.join(correction_folder, _basename), allow_pickle=True)
+    return _pf
+
+
 def find_image_background(im, dtype=_image_dtype, bin_size=10, make_plot=False, max_iter=10):
     """Histogram-peak background level (io_tools/load.py:642-687), computed by ``ia3_find_background(_dev)``
     (background.hip).  ``im``: uint16/float32 ndarray or a resident ``DeviceStack``.  ``make_plot`` is accepted
@@ -239,9 +309,9 @@ def correct_fov_image(dax_filename, sel_channels,
     The raw movie is uploaded ONCE as uint16 and every stage runs on resident stacks (hotpix.hip, corrections.hip,
     warp.hip, gauss.hip); only the selected channels come back (or stay resident with ``return_device=True`` — feed
     them to ``ia3_fit_fov_dev`` / ``fit_fov_image``).  ``dax_filename`` may also be the raw (frames, X, Y) uint16
-    movie itself.  Profiles must be passed in (ndarray or ``DeviceBuffer``; upload them once per run with
-    ``DeviceBuffer``): reading the reference's pickled profile folder is outside the accelerated path, as is
-    ``normalization=True``.  With ``warp_image=False`` the images are left unwarped and one spot-translation
+    movie itself.  Profiles: ndarray or ``DeviceBuffer`` (upload them once per run with ``DeviceBuffer``), or None to read them from
+    ``correction_folder`` as the reference does (``load_correction_profile``); ``normalization=True`` is outside the
+    accelerated path.  With ``warp_image=False`` the images are left unwarped and one spot-translation
     function per selected channel is returned (``chromatic_profile[ch]`` is then the constants dict)."""
     import os
     import time
@@ -290,8 +360,11 @@ def correct_fov_image(dax_filename, sel_channels,
         raise NotImplementedError("output_dtype other than uint16 is outside the accelerated path")
     # profiles
     if illumination_corr:
-        if illumination_profile is None:
-            raise NotImplementedError("pass illumination_profile (loading the correction folder is out of scope)")
+        if illumination_profile is None:                                     # :239-246
+            illumination_profile = load_correction_profile('illumination', corr_channels=_load_channels,
+                                                           correction_folder=correction_folder, all_channels=all_channels,
+                                                           ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                           verbose=verbose)
         if not isinstance(illumination_profile, dict):
             raise TypeError("Wrong input type of illumination_profile, should be dict!")
         for _ch in _load_channels:
@@ -299,8 +372,11 @@ def correct_fov_image(dax_filename, sel_channels,
                 raise KeyError(f"channel:{_ch} not given in illumination_profile")
     _do_bleed = bleed_corr and len(_overlap_channels) > 0
     if _do_bleed:
-        if bleed_profile is None:
-            raise NotImplementedError("pass bleed_profile (loading the correction folder is out of scope)")
+        if bleed_profile is None:                                            # :255-259
+            bleed_profile = load_correction_profile('bleedthrough', corr_channels=corr_channels,
+                                                    correction_folder=correction_folder, all_channels=all_channels,
+                                                    ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                    verbose=verbose)
         if not isinstance(bleed_profile, DeviceBuffer):
             bleed_profile = np.array(bleed_profile, dtype=np.float32)
             _nc = len(corr_channels)
@@ -308,8 +384,12 @@ def correct_fov_image(dax_filename, sel_channels,
                 raise IndexError(f"Wrong input shape for bleed_profile: {bleed_profile.shape}, should be "
                                  f"{(_nc, _nc, single_im_size[-2], single_im_size[-1])}")
     if chromatic_corr and len(_overlap_channels) > 0:
-        if chromatic_profile is None:
-            raise NotImplementedError("pass chromatic_profile (loading the correction folder is out of scope)")
+        if chromatic_profile is None:                                        # :266-281
+            chromatic_profile = load_correction_profile('chromatic' if warp_image else 'chromatic_constants',
+                                                        corr_channels=corr_channels,
+                                                        correction_folder=correction_folder, all_channels=all_channels,
+                                                        ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                        verbose=verbose)
         if not isinstance(chromatic_profile, dict):
             raise TypeError("Wrong input type of chromatic_profile, should be dict!")
         for _ch in _load_channels:

@@ -257,6 +257,40 @@ def daxp_golden(meta):
     np.savez_compressed(os.path.join(OUT, "daxp.npz"), **d)
 
 
+def profiles_golden(meta):
+    """io_tools/load.py:553-640 load_correction_profile: the file names the reference opens (np.load / pickle.load are
+    replaced by recorders) and the shapes / keys it returns."""
+    import pickle
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from conftest import profile_name_cases
+    load, _ = ref_loader.load_io()
+    opened = []
+
+    def fake_np_load(path, allow_pickle=False):
+        opened.append(os.path.basename(path))
+        return np.zeros(3 * 3 * 64 * 96, np.float32)
+
+    real_np_load, real_open, real_pk = np.load, load.open if hasattr(load, "open") else None, pickle.load
+    d = {}
+    try:
+        load.np.load = fake_np_load
+        load.pickle.load = lambda f: {"constants": "const"}
+        load.open = lambda path, mode="rb": opened.append(os.path.basename(path)) or None
+        for i, (typ, kw) in enumerate(profile_name_cases()):
+            del opened[:]
+            pf = load.load_correction_profile(typ, correction_folder="/corr", **kw)
+            d["names_%d" % i] = np.array(opened)
+            d["keys_%d" % i] = np.array(sorted(pf.keys())) if isinstance(pf, dict) else np.array(pf.shape)
+            d["none_%d" % i] = np.array([k for k in sorted(pf.keys()) if pf[k] is None]) if isinstance(pf, dict) else np.array([])
+    finally:
+        load.np.load = real_np_load
+        load.pickle.load = real_pk
+        if real_open is None:
+            del load.open
+    np.savez_compressed(os.path.join(OUT, "profile_names.npz"), **d)
+    print({k: v.tolist() for k, v in d.items()})
+
+
 def seg_golden(meta):
     """classes/preprocess.py:1093-1153 DaxProcesser._fit_spots_by_segmentation run by the reference on the movie of
     the chain case with the label image of tests/conftest.py::seg_labels."""
@@ -420,6 +454,7 @@ def main():
     chromfn_golden(meta)
     daxp_golden(meta)
     seg_golden(meta)
+    profiles_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

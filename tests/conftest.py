@@ -140,6 +140,16 @@ def batch_inputs():
     return case, size, corr, corr_nowarp, fit
 
 
+def profile_name_cases():
+    """(corr_type, kwargs) calls of the load_correction_profile fixtures (oracle/make_golden.py::profiles_golden)."""
+    chs = ['750', '647', '561', '488', '405']
+    return [("illumination", dict(corr_channels=['750', '561', '488'], all_channels=chs, im_size=[12, 64, 96])),
+            ("bleedthrough", dict(corr_channels=['561', '750', '647'], all_channels=chs, im_size=[12, 64, 96])),
+            ("chromatic", dict(corr_channels=['750', '647', '561'], all_channels=chs, ref_channel='647', im_size=[12, 64, 96])),
+            ("chromatic_constants", dict(corr_channels=['750', '647'], all_channels=chs, ref_channel='647', im_size=[30, 2048, 2048])),
+            ("Illumination", dict(corr_channels=['405'], all_channels=chs, im_size=[50, 2048, 2048]))]
+
+
 def seg_labels(shape):
     """Label image for the segmentation-driven fit fixtures: a quadrant box (1), a central ellipsoid (2), a thin
     slab along one edge (3) and a 3-voxel speck (4)."""

@@ -963,3 +963,70 @@ def test_daxprocesser_fit_spots_by_segmentation_golden(tmp_path):
     assert np.array_equal(i750, g["ids_750"])
     assert_rows_close(np.asarray(s750), g["spots_750"])
     assert len(s561) == 0 and len(i561) == 0 and g["spots_561"].shape == (0,)
+
+
+def test_profiles_read_from_correction_folder(tmp_path):
+    """Profiles left as None are read from the correction folder under the reference's file names
+    (io_tools/load.py:239-281, :553-640): same images as with the profiles handed over; DaxProcesser steps and
+    batch_process_image_quick (classes/preprocess.py:1257-1278) take the same route."""
+    import contextlib, io, pickle
+    from conftest import build_chain_case, chain_kwargs, write_dax
+    from imageanalysis3_amd.io_tools.load import correct_fov_image
+    from imageanalysis3_amd.classes.preprocess import DaxProcesser, batch_process_image_quick
+    case = build_chain_case()
+    g = load_golden("chain.npz")
+    Z, X, Y = case["Z"], case["X"], case["Y"]
+    folder = str(tmp_path / "corr")
+    os.makedirs(folder)
+    for c in case["chs"]:
+        np.save(os.path.join(folder, "illumination_correction_%s_%dx%d.npy" % (c, X, Y)), case["illum"][c])
+    np.save(os.path.join(folder, "bleedthrough_correction_750_647_561_%d_%d.npy" % (X, Y)), case["bleed"].reshape(-1))
+    for c in ('750', '561'):
+        np.save(os.path.join(folder, "chromatic_correction_%s_647_%d_%d_%d.npy" % (c, Z, X, Y)), case["chrom"][c])
+    path = str(tmp_path / "movie.dax")
+    write_dax(path, case["raw"])
+    sel, kw = chain_kwargs(case, "full")
+    for k in ("illumination_profile", "bleed_profile", "chromatic_profile"):
+        kw.pop(k)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = correct_fov_image(path, sel, correction_folder=folder, **kw)
+    for ch, im in zip(sel, out[0]):
+        assert np.array_equal(im, g["full_%s" % ch]), ch
+    with pytest.raises(FileNotFoundError):
+        correct_fov_image(path, sel, correction_folder=str(tmp_path), **kw)
+    # DaxProcesser: profiles from its CorrectionFolder
+    d = load_golden("daxp.npz")
+    p = DaxProcesser(path, CorrectionFolder=folder, Channels=case["chs"], DriftChannel='488', verbose=False)
+    p._load_image(ImSize=[Z, X, Y], NbufferFrame=case["nb"])
+    p._corr_hot_pixels_3D()
+    p._corr_bleedthrough(rescale=True)
+    p._corr_illumination(rescale=True)
+    p._warp_image(drift=np.array(case["drift"]))
+    for c in case["chs"]:
+        assert (zlib.crc32(np.ascontiguousarray(getattr(p, "im_" + c)).tobytes()) & 0xFFFFFFFF) == int(d["a_warp_%s_crc" % c]), c
+    # the quick wrapper: load + hot pixels + illumination on a movie whose .xml / .inf describe it (no buffer frames)
+    from imageanalysis3_amd import synth
+    z2, x2 = 6, 32
+    ims2 = [synth.make_fov((z2, x2, x2), 3, 70 + i, dtype=np.uint16, margin=(1, 5, 5))[0] for i in range(4)]
+    raw2 = np.zeros((4 * z2, x2, x2), np.uint16)
+    for i in range(4):
+        raw2[i::4] = ims2[i]
+    path2 = str(tmp_path / "quick.dax")
+    write_dax(path2, raw2)
+    with open(path2[:-4] + ".inf", "w") as f:   # `key = value` lines only: _LoadInfFile (:1197-1205) splits every line
+        f.write("frame dimensions = %d x %d\nnumber of frames = %d\nframe size = %d\n" % (x2, x2, 4 * z2, x2 * x2))
+    with open(path2[:-4] + ".xml", "w") as f:
+        f.write("<settings><illumination><shutters>shutters/shutter_750_647_561_488_s%d.xml</shutters></illumination></settings>" % z2)
+    rng = np.random.RandomState(3)
+    for c in case["chs"]:
+        np.save(os.path.join(folder, "illumination_correction_%s_%dx%d.npy" % (c, x2, x2)), (0.5 + 0.5 * rng.rand(x2, x2)).astype(np.float32))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ims = batch_process_image_quick(path2, folder, ['750', '561'], verbose=False)
+        q = DaxProcesser(path2, folder, Channels=None, DriftChannel='488', DapiChannel='405', verbose=False)
+        assert list(q.channels) == case["chs"]
+        q._load_image(sel_channels=['750', '561'])
+        assert np.array_equal(q.im_750, ims2[0]) and np.array_equal(q.im_561, ims2[2])
+        q._corr_hot_pixels_3D(correction_channels=['750', '561'])
+        q._corr_illumination(correction_channels=['750', '561'])
+    assert len(ims) == 2 and ims[0].dtype == np.uint16
+    assert np.array_equal(ims[0], q.im_750) and np.array_equal(ims[1], q.im_561) and not np.array_equal(ims[0], ims2[0])

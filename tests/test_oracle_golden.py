@@ -1,5 +1,6 @@
 """CPU: the NumPy oracle against fixtures produced by the reference's own Python
 (oracle/make_golden.py).  This is what "parity pinned" rests on."""
+import os
 import zlib
 import numpy as np
 import pytest
@@ -257,3 +258,34 @@ def test_daxprocesser_steps_oracle_vs_reference_golden(tag, rescale, illum64):
     g = load_golden("daxp.npz")
     for key, im in _daxp_oracle(case, rescale, illum64):
         assert np.uint32(zlib.crc32(np.ascontiguousarray(im).tobytes())) == g["%s_%s_crc" % (tag, key)], (tag, key)
+
+
+def test_load_correction_profile_names(monkeypatch):
+    """io_tools/load.py:553-640: the files opened in the correction folder and the shape / keys returned, against
+    what the reference opens for the same calls (recorded with np.load / pickle.load replaced)."""
+    import pickle
+    import builtins
+    from conftest import profile_name_cases, GOLDEN
+    from imageanalysis3_amd.io_tools import load as LD
+    g = np.load(os.path.join(GOLDEN, "profile_names.npz"))
+    opened = []
+    monkeypatch.setattr(np, "load", lambda path, allow_pickle=False: opened.append(os.path.basename(path)) or np.zeros(3 * 3 * 64 * 96, np.float32))
+    monkeypatch.setattr(pickle, "load", lambda f: {"constants": "const"})
+    real_open = builtins.open
+    monkeypatch.setattr(builtins, "open", lambda path, mode="r", *a, **k: (opened.append(os.path.basename(path)) or None)
+                        if str(path).startswith("/corr") else real_open(path, mode, *a, **k))
+    for i, (typ, kw) in enumerate(profile_name_cases()):
+        del opened[:]
+        pf = LD.load_correction_profile(typ, correction_folder="/corr", **kw)
+        assert opened == list(g["names_%d" % i]), (typ, opened)
+        if isinstance(pf, dict):
+            assert sorted(pf.keys()) == list(g["keys_%d" % i])
+            assert [k for k in sorted(pf.keys()) if pf[k] is None] == list(g["none_%d" % i])
+        else:
+            assert list(pf.shape) == list(g["keys_%d" % i])
+    with pytest.raises(ValueError):
+        LD.load_correction_profile("flatfield", correction_folder="/corr")
+    with pytest.raises(ValueError):
+        LD.load_correction_profile("illumination", corr_channels=['999'], correction_folder="/corr")
+    with pytest.raises(ValueError):
+        LD.load_correction_profile("chromatic", ref_channel='999', correction_folder="/corr")
