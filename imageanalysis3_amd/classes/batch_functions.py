@@ -470,3 +470,42 @@ def batch_process_image_to_spots(dax_filename,
     if return_spots:
         return _spot_list, _raw_spot_list
     return
+
+
+def batch_process_images_to_spots(args_list, num_threads=4, shared_kwargs=None):
+    """The fan-out of ``Field_of_View._process_image_to_spots`` (classes/field_of_view.py:1015-1142) for one GPU.
+
+    The reference starts ``mp.Pool(num_threads).starmap(batch_process_image_to_spots, args)`` with manager locks for
+    the save file; every task pickles its arguments (reference image and profiles included).  Here the tasks are
+    threads of the one process that owns the GPU: libia3 gives each thread its own HIP streams, so the corrections,
+    warps and fits of different movies overlap on the device, profiles / the reference bead image are shared by
+    reference (hand them over as ``DeviceBuffer`` / ndarray once), and plain ``threading.Lock`` objects serialise the
+    save file.  ``args_list``: one dict of ``batch_process_image_to_spots`` keyword arguments per movie (or a tuple of
+    its positional arguments); ``shared_kwargs`` are added to each.  Returns the per-movie return values, in order.
+    Across GPUs: one such process per device over ``parallel.shard_fovs``."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    shared_kwargs = dict(shared_kwargs or {})
+    _file_lock = threading.RLock()   # images and spot tables live in the same file: one lock for both
+    _spot_lock = _file_lock
+    L.lib()   # load the library before the threads start
+
+    def _run(_args):
+        if isinstance(_args, dict):
+            _kw = dict(shared_kwargs)
+            _kw.update(_args)
+            _pos = ()
+        else:
+            _pos, _kw = tuple(_args), dict(shared_kwargs)
+        _kw.setdefault('fov_savefile_lock', _file_lock)
+        _kw.setdefault('spot_file_lock', _spot_lock)
+        # the argument dicts are written to inside the call (th_seed, seed_mask): give every task its own copy
+        for _k in ('fitting_args', 'correction_args', 'drift_args'):
+            if _k in _kw:
+                _kw[_k] = dict(_kw[_k])
+        return batch_process_image_to_spots(*_pos, **_kw)
+
+    if num_threads <= 1 or len(args_list) <= 1:
+        return [_run(_a) for _a in args_list]
+    with ThreadPoolExecutor(max_workers=int(num_threads)) as _pool:
+        return list(_pool.map(_run, args_list))

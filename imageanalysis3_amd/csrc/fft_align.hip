@@ -14,6 +14,7 @@
 #include <unistd.h>
 #include <vector>
 #include <mutex>
+#include <sys/syscall.h>
 #include <math.h>
 
 using namespace ia3rt;
@@ -37,40 +38,53 @@ int next_fast_len(int n) {  // smallest 2^a 3^b 5^c 7^d >= n
   } while (0)
 
 // rocFFT plans cost tens of milliseconds to build (kernel selection, twiddle tables, work buffer); drift alignment
-// runs the same few transforms for every crop of every image, so plans are kept: a small per-process cache keyed
-// by (type, dims), least recently used entry evicted.  Work buffers stay attached to the cached plans.
+// runs the same few transforms for every crop of every image, so plans are kept: a small cache per host thread keyed
+// by (type, dims), least recently used entry evicted.  Work buffers stay attached to the cached plans, and a plan
+// with its work buffer must not run on two streams at once — hence one cache per thread (= per library stream), not
+// one per process: several threads aligning different images use different plans.
 struct PlanEntry { int type, n0, n1, n2; hipfftHandle h; unsigned long long used; };
-static std::vector<PlanEntry> g_plans;
-static pid_t g_plans_pid = 0;
-static unsigned long long g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 8;
+struct PlanCache {
+  std::vector<PlanEntry> plans;
+  pid_t pid = 0;
+  unsigned long long clock = 0;
+  ~PlanCache() {
+    // worker threads release their plans when they end; the main thread's cache is left to process teardown
+    // (the HIP runtime may already be gone when its thread-locals are destroyed)
+    if (pid == getpid() && (pid_t)syscall(SYS_gettid) != getpid())
+      for (auto& e : plans) hipfftDestroy(e.h);
+  }
+};
+static thread_local PlanCache t_cache;
+static std::mutex g_plan_mu;   // plan construction is serialised
 
-static std::mutex g_plan_mu;
-// NOTE: a cached plan is shared by all host threads; the drift entry points are meant to be driven by one thread at a
-// time (the plan is re-bound to the caller's stream on every use, executions of one plan are not concurrent-safe).
 static int get_plan(int type, int n0, int n1, int n2, hipStream_t st, hipfftHandle* out) {
-  std::lock_guard<std::mutex> lk(g_plan_mu);
-  if (g_plans_pid != getpid()) { g_plans.clear(); g_plans_pid = getpid(); }   // handles do not survive fork()
-  for (auto& e : g_plans)
+  PlanCache& c = t_cache;
+  if (c.pid != getpid()) { c.plans.clear(); c.pid = getpid(); }   // handles do not survive fork()
+  for (auto& e : c.plans)
     if (e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) {
-      e.used = ++g_plan_clock;
+      e.used = ++c.clock;
       if (hipfftSetStream(e.h, st) != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfftSetStream failed");
       *out = e.h;
       return IA3_OK;
     }
-  if (g_plans.size() >= MAX_PLANS) {
+  if (c.plans.size() >= MAX_PLANS) {
     size_t victim = 0;
-    for (size_t i = 1; i < g_plans.size(); ++i) if (g_plans[i].used < g_plans[victim].used) victim = i;
+    for (size_t i = 1; i < c.plans.size(); ++i) if (c.plans[i].used < c.plans[victim].used) victim = i;
     (void)hipStreamSynchronize(st);
-    hipfftDestroy(g_plans[victim].h);
-    g_plans.erase(g_plans.begin() + victim);
+    hipfftDestroy(c.plans[victim].h);
+    c.plans.erase(c.plans.begin() + victim);
   }
   hipfftHandle h;
-  hipfftResult r = n2 > 0 ? hipfftPlan3d(&h, n0, n1, n2, (hipfftType)type) : hipfftPlan2d(&h, n0, n1, (hipfftType)type);
+  hipfftResult r;
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    r = n2 > 0 ? hipfftPlan3d(&h, n0, n1, n2, (hipfftType)type) : hipfftPlan2d(&h, n0, n1, (hipfftType)type);
+  }
   if (r != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfft plan (%d x %d x %d) failed: error %d", n0, n1, n2, (int)r);
   r = hipfftSetStream(h, st);
   if (r != HIPFFT_SUCCESS) { hipfftDestroy(h); return set_error(IA3_EHIP, "hipfftSetStream failed: error %d", (int)r); }
-  g_plans.push_back(PlanEntry{type, n0, n1, n2, h, ++g_plan_clock});
+  c.plans.push_back(PlanEntry{type, n0, n1, n2, h, ++c.clock});
   *out = h;
   return IA3_OK;
 }
