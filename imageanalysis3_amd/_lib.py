@@ -17,7 +17,7 @@ MODE_REFLECT, MODE_NEAREST, MODE_CONSTANT = 0, 1, 2
 EXPORTS = [
     "ia3_init", "ia3_last_error", "ia3_version", "ia3_device_name", "ia3_sync", "ia3_stream",
     "ia3_release_workspace", "ia3_profile_enable", "ia3_profile_collect", "ia3_set_tuning",
-    "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
+    "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_load_file", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
     "ia3_remove_hot_pixels", "ia3_z_shift_correction", "ia3_illumination_correct", "ia3_bleedthrough_correct",
@@ -162,6 +162,15 @@ class DeviceStack(object):
         code = IA3_F32 if dt == np.float32 else IA3_U16
         check(lib().ia3_stack_wrap(C.c_void_p(t.data_ptr()), code, t.shape[0], t.shape[1], t.shape[2], C.byref(h)))
         return cls(h, tuple(t.shape), dt, keepalive=t)
+
+    @classmethod
+    def from_file(cls, path, frames, X, Y, offset_bytes=0, big_endian=False):
+        """Resident uint16 (frames, X, Y) stack read straight from a raw movie file (pipelined read + upload)."""
+        import os
+        h = C.c_void_p()
+        check(lib().ia3_stack_load_file(os.fsencode(path), C.c_longlong(int(offset_bytes)), int(frames), int(X), int(Y),
+                                        1 if big_endian else 0, C.byref(h)))
+        return cls(h, (int(frames), int(X), int(Y)), np.dtype(np.uint16))
 
     def crop(self, lims):
         """New resident stack = self[z0:z1, x0:x1, y0:y1]; ``lims`` is a (3,2) [start, stop) array."""

@@ -279,7 +279,7 @@ class DaxProcesser():
         """:400-462 — read the movie, gather the selected channels on the device."""
         import time
         from .. import _lib as L
-        from ..io_tools.load import read_dax, split_im_by_channels
+        from ..io_tools.load import load_dax_resident, split_im_by_channels
         _load_start = time.time()
         if not hasattr(self, 'loaded_channels'):
             setattr(self, 'loaded_channels', [])
@@ -298,7 +298,7 @@ class DaxProcesser():
                                                           verbose=self.verbose)
         else:
             self.image_size = np.array(ImSize, dtype=np.int32)
-        _raw = L.DeviceStack.upload(read_dax(self.filename))
+        _raw = load_dax_resident(self.filename)
         try:
             _ims = split_im_by_channels(_raw, _loading_channels, all_channels=self.channels, single_im_size=self.image_size,
                                         num_buffer_frames=NbufferFrame, num_empty_frames=NemptyFrame)

@@ -6,6 +6,8 @@
 #include <string.h>
 #include <math.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <mutex>
 
 namespace ia3rt {
@@ -300,6 +302,83 @@ int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack
   if (e != hipSuccess) {
     ia3_stack_free(*out); *out = nullptr;
     return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+  }
+  return IA3_OK;
+}
+// Raw movie file -> resident uint16 stack (what DaxReader.loadAll + an upload do, visual_tools.py:974-1083): the file
+// is read in 32 MiB pieces into two pinned staging buffers per host thread and every piece is sent with an async copy
+// while the next one is being read, so a movie costs max(file read, PCIe) instead of read + pageable copy.
+namespace {
+constexpr size_t STAGE_BYTES = 32u << 20;
+struct Staging {
+  void* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  pid_t pid = 0;
+};
+thread_local Staging t_stage;
+int staging_ready() {
+  Staging& s = t_stage;
+  if (s.pid == getpid()) return IA3_OK;
+  for (int i = 0; i < 2; ++i) {
+    if (hipHostMalloc(&s.buf[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess)
+      return set_error(IA3_ENOMEM, "cannot allocate pinned staging buffers");
+  }
+  s.pid = getpid();
+  return IA3_OK;
+}
+__global__ void bswap16_k(uint16_t* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { uint16_t v = p[i]; p[i] = (uint16_t)((v >> 8) | (v << 8)); }
+}
+}  // namespace
+
+int ia3_stack_load_file(const char* path, long long offset_bytes, int frames, int X, int Y, int big_endian,
+                        ia3_stack** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!path || !out || frames < 1 || X < 1 || Y < 1 || offset_bytes < 0) return set_error(IA3_EINVAL, "bad load arguments");
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return set_error(IA3_EINVAL, "cannot open %s", path);
+  struct stat stt;
+  const size_t total = (size_t)frames * X * Y * 2;
+  if (fstat(fd, &stt) != 0 || (size_t)stt.st_size < (size_t)offset_bytes + total) {
+    close(fd);
+    return set_error(IA3_EINVAL, "%s holds fewer than %d frames of %d x %d uint16", path, frames, X, Y);
+  }
+  rc = staging_ready();
+  if (!rc) rc = ia3_stack_alloc(IA3_U16, frames, X, Y, out);
+  if (rc) { close(fd); return rc; }
+  Staging& sg = t_stage;
+  hipStream_t st = stream();
+  hipError_t e = hipSuccess;
+  size_t done = 0;
+  bool used[2] = {false, false};
+  for (int k = 0; done < total && e == hipSuccess; ++k) {
+    const int b = k & 1;
+    if (used[b]) e = hipEventSynchronize(sg.ev[b]);   // the copy that last read this buffer has finished
+    if (e != hipSuccess) break;
+    const size_t want = total - done < STAGE_BYTES ? total - done : STAGE_BYTES;
+    size_t got = 0;
+    while (got < want) {
+      ssize_t r = pread(fd, (char*)sg.buf[b] + got, want - got, (off_t)(offset_bytes + done + got));
+      if (r <= 0) { close(fd); ia3_stack_free(*out); *out = nullptr; return set_error(IA3_EINVAL, "short read from %s", path); }
+      got += (size_t)r;
+    }
+    e = hipMemcpyAsync((char*)(*out)->d + done, sg.buf[b], want, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(sg.ev[b], st);
+    used[b] = true;
+    done += want;
+  }
+  close(fd);
+  if (e == hipSuccess && big_endian) {
+    const size_t n = total / 2;
+    hipLaunchKernelGGL(bswap16_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint16_t*)(*out)->d, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    ia3_stack_free(*out); *out = nullptr;
+    return set_error(IA3_EHIP, "movie upload failed: %s", hipGetErrorString(e));
   }
   return IA3_OK;
 }

@@ -166,9 +166,8 @@ def find_local_backgrounds(stack, centers_zxy, crop_size, dtype=_image_dtype, bi
 # correct_fov_image (io_tools/load.py:166-522): the whole per-image chain on stacks that stay in HBM
 # ---------------------------------------------------------------------------------------------------------------
 
-def read_dax(dax_filename):
-    """The raw movie of a .dax/.inf pair as a (frames, width, height) uint16 array — what the reference's
-    ``DaxReader(dax_filename).loadAll()`` returns (visual_tools.py:974-1083; host file I/O only)."""
+def _dax_info(dax_filename):
+    """(frames, X, Y, big_endian) from the .inf next to a .dax movie (visual_tools.py:990-1030)."""
     import os
     import re
     inf = os.path.splitext(dax_filename)[0] + ".inf"
@@ -187,10 +186,24 @@ def read_dax(dax_filename):
                 big = m.group(1) == "big"
     if not h:
         h = w = 256
-    data = np.fromfile(dax_filename, dtype='>u2' if big else '<u2')
     if n is None:
-        n = data.size // (h * w)
-    return np.ascontiguousarray(data[:n * h * w].reshape(n, w, h).astype(np.uint16, copy=False))
+        n = os.path.getsize(dax_filename) // (2 * h * w)
+    return n, w, h, big
+
+
+def read_dax(dax_filename):
+    """The raw movie of a .dax/.inf pair as a (frames, width, height) uint16 array — what the reference's
+    ``DaxReader(dax_filename).loadAll()`` returns (visual_tools.py:974-1083; host file I/O only)."""
+    n, w, h, big = _dax_info(dax_filename)
+    data = np.fromfile(dax_filename, dtype='>u2' if big else '<u2', count=n * h * w)
+    return np.ascontiguousarray(data.reshape(n, w, h).astype(np.uint16, copy=False))
+
+
+def load_dax_resident(dax_filename):
+    """The same movie as a resident ``DeviceStack`` without a host copy: the file is streamed through pinned staging
+    buffers (``ia3_stack_load_file``), file read and PCIe transfer overlapped."""
+    n, w, h, big = _dax_info(dax_filename)
+    return L.DeviceStack.from_file(dax_filename, n, w, h, big_endian=big)
 
 
 def get_num_frame(dax_filename, frame_per_color=None, buffer_frame=10, empty_frame=0, verbose=False):
@@ -400,18 +413,20 @@ def correct_fov_image(dax_filename, sel_channels,
         if load_file_lock is not None:
             load_file_lock.acquire()
         try:
-            _raw_im = read_dax(dax_filename)
+            _raw = load_dax_resident(dax_filename)     # file -> pinned staging -> HBM, no host copy of the movie
         finally:
             if load_file_lock is not None:
                 load_file_lock.release()
-    if _raw_im.dtype != np.uint16 or _raw_im.ndim != 3:
-        raise TypeError("the raw movie should be a (frames, X, Y) uint16 array")
-    _num_color = (_raw_im.shape[0] - 2 * num_buffer_frames - num_empty_frames) / single_im_size[0]
+    else:
+        if _raw_im.dtype != np.uint16 or _raw_im.ndim != 3:
+            raise TypeError("the raw movie should be a (frames, X, Y) uint16 array")
+        _raw = L.DeviceStack.upload(np.ascontiguousarray(_raw_im))
+    _num_color = (_raw.shape[0] - 2 * num_buffer_frames - num_empty_frames) / single_im_size[0]
     if _num_color != int(_num_color):
+        _raw.free()
         raise ValueError("Wrong num_color, should be integer!")
     _num_color = int(_num_color)
     lib = L.lib()
-    _raw = L.DeviceStack.upload(np.ascontiguousarray(_raw_im))
     _owned = []      # resident stacks to release
     try:
         _ims = split_im_by_channels(_raw, _load_channels, all_channels[:_num_color], single_im_size=single_im_size,

@@ -58,6 +58,11 @@ int ia3_set_tuning(int key, int value);
 /* ---- device-resident stacks ----------------------------------------------------------------- */
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out);
 int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out);
+/* Raw uint16 movie file -> resident (frames, X, Y) stack: what DaxReader(dax).loadAll() followed by an upload does
+ * (visual_tools.py:974-1083), read in pieces through pinned staging buffers so file read and PCIe copy overlap.
+ * offset_bytes: start of the first frame; big_endian != 0 swaps bytes on the device. */
+int ia3_stack_load_file(const char* path, long long offset_bytes, int frames, int X, int Y, int big_endian,
+                        ia3_stack** out);
 int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out); /* borrow device memory */
 /* io_tools/load.py:524-550 split_im_by_channels on a resident raw movie (frames, X, Y): frames start, start+step, .. */
 int ia3_stack_deinterleave(const ia3_stack* raw, int start, int step, int Z, ia3_stack** out);

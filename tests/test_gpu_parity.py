@@ -1085,3 +1085,36 @@ def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path):
     for r in range(4):   # every round holds the frames of the single-movie fixture
         assert (zlib.crc32(np.ascontiguousarray(par['ims'][2 * r]).tobytes()) & 0xFFFFFFFF) == int(gold['w_ims_crc'][0])
         _spot_tables_close(par['spots'][2 * r:2 * r + 2], gold['w_spots'][:2], "round %d" % r)
+
+
+def test_movie_file_streams_into_a_resident_stack(tmp_path):
+    """ia3_stack_load_file: pieces larger and smaller than the staging buffers, an offset, big-endian files; equal to
+    read_dax + upload."""
+    from conftest import write_dax
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.io_tools.load import read_dax, load_dax_resident
+    rng = np.random.RandomState(8)
+    for frames, X, Y in ((7, 33, 65), (40, 1024, 512)):      # 30 KB and 40 MiB (more than one 32 MiB piece)
+        raw = rng.randint(0, 65535, size=(frames, X, Y)).astype(np.uint16)
+        path = str(tmp_path / ("m%d.dax" % frames))
+        write_dax(path, raw)
+        st = load_dax_resident(path)
+        try:
+            assert st.shape == (frames, X, Y) and st.dtype == np.uint16
+            assert np.array_equal(st.download(), raw) and np.array_equal(read_dax(path), raw)
+        finally:
+            st.free()
+        part = L.DeviceStack.from_file(path, 3, X, Y, offset_bytes=2 * X * Y * 2)
+        assert np.array_equal(part.download(), raw[2:5])
+        part.free()
+    big = str(tmp_path / "big.dax")
+    raw.astype('>u2').tofile(big)
+    with open(big[:-4] + ".inf", "w") as f:
+        f.write("frame dimensions = %d x %d\nnumber of frames = %d\n big endian\n" % (Y, X, frames))
+    st = load_dax_resident(big)
+    assert np.array_equal(st.download(), raw) and np.array_equal(read_dax(big), raw)
+    st.free()
+    with pytest.raises(ValueError):
+        L.DeviceStack.from_file(path, frames + 1, X, Y)
+    with pytest.raises(ValueError):
+        L.DeviceStack.from_file(str(tmp_path / "absent.dax"), 1, 8, 8)
