@@ -885,6 +885,13 @@ int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev) {
   return IA3_OK;
 }
 
+int ia3_fit_nfev(ia3_fitter* f, int* nfev) {
+  if (!f || !nfev) return set_error(IA3_EINVAL, "null argument");
+  IA3_HIP(hipStreamSynchronize(stream()));
+  IA3_HIP(hipMemcpy(nfev, f->d_nfev, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost));
+  return IA3_OK;
+}
+
 int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* centers_zxy, int n,
                   const ia3_fit_params* p, float* out_ps, uint8_t* success, int* n_iter) {
   ia3_stack* s = nullptr;

@@ -217,6 +217,8 @@ int ia3_fit_run(ia3_fitter* f);                   /* .firstfit(); .repeatfit() i
 int ia3_fit_results(ia3_fitter* f, float* ps, uint8_t* success, int* nvox);
 /* same, plus n_iter of the last repeatfit, with a single stream synchronisation */
 int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, int* n_iter);
+/* nfev: n ints, model evaluations spent on each seed so far (first fit + sweeps); MINPACK stops a fit at maxfev */
+int ia3_fit_nfev(ia3_fitter* f, int* nfev);
 int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev);
 void ia3_fit_destroy(ia3_fitter* f);
 
