@@ -67,6 +67,9 @@ def lib():
             raise ImportError(
                 "imageanalysis3_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C imageanalysis3_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # streams of concurrent host threads onto separate hardware queues (see runtime.cpp do_init); must be in the
+        # environment before the HIP runtime starts, hence also here, before anything is loaded
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(LIB_PATH)
         L.ia3_last_error.restype = C.c_char_p
         L.ia3_version.restype = C.c_char_p

@@ -48,6 +48,10 @@ static int do_init(int device) {
   // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
   if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
   if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_device = -1; }
+  // Every host thread drives two streams (ThreadCtx); the runtime multiplexes streams onto 4 hardware queues by
+  // default, where a long-running fit kernel holds back unrelated work queued behind it.  Ask for more queues unless
+  // the user chose a number (only effective when this is the first HIP call of the process).
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)

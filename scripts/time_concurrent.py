@@ -19,7 +19,7 @@ def one(st):
     return nr.value
 
 jobs = stacks * 4   # 16 FOV passes
-for w in (1, 2, 4, 8, 1):
+for w in (1, 2, 4, 8, 16):
     t0 = time.perf_counter()
     if w == 1:
         res = [one(s) for s in jobs]
