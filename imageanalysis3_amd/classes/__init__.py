@@ -22,29 +22,27 @@ _min_num_seeds = 50
 
 def _fit_single_image(_im, _id, _chrom_coords, _seeding_args, _fitting_args, _check_fitting=True,
                       _normalization=True, _verbose=False):
-    """classes/__init__.py:57-88 — for every chromosome coordinate: seeds within a radius
-    (``visual_tools.get_seed_in_distance(_im, coord, *_seeding_args)``), Fitting_v3 first fit (+ refit sweeps when
-    ``_check_fitting``), heights divided by ``nanmedian(_im)`` when ``_normalization``.
-    Returns a list with one (N,11) array (or an empty array) per coordinate."""
+    """classes/__init__.py:57-88 — legacy per-cell fit.  For every chromosome coordinate: seeds within a radius
+    (``visual_tools.get_seed_in_distance(_im, coord, *_seeding_args)``), ``Fitting_v3`` first fit (+ refit sweeps when
+    ``_check_fitting``), heights divided by ``nanmedian(_im)`` when ``_normalization``.  One (N,11) array (or an
+    empty array) per coordinate."""
     if _verbose:
         print(f"+++ fitting for region:{_id}")
-    _spots_for_chrom = []
-    if _normalization:
-        _norm_cst = np.nanmedian(_im)
-    for _chrom_coord in _chrom_coords:
-        if _im is None:
-            _spots_for_chrom.append(np.array([]))
-        else:
-            _seeds = visual_tools.get_seed_in_distance(_im, _chrom_coord, *_seeding_args)
-            if len(_seeds) == 0:
-                _spots_for_chrom.append(np.array([]))
-                continue
-            _fitter = Fitting_v3.iter_fit_seed_points(_im, _seeds.T, *_fitting_args)
-            _fitter.firstfit()
-            if _check_fitting:
-                _fitter.repeatfit()
-            _spots = np.array(_fitter.ps)
-            if _normalization:
-                _spots[:, 0] = _spots[:, 0] / _norm_cst
-            _spots_for_chrom.append(_spots)
-    return _spots_for_chrom
+    if _im is None:
+        return [np.array([]) for _ in _chrom_coords]
+    scale = np.nanmedian(_im) if _normalization else None
+    tables = []
+    for coord in _chrom_coords:
+        seeds = visual_tools.get_seed_in_distance(_im, coord, *_seeding_args)
+        if len(seeds) == 0:
+            tables.append(np.array([]))
+            continue
+        fitter = Fitting_v3.iter_fit_seed_points(_im, seeds.T, *_fitting_args)
+        fitter.firstfit()
+        if _check_fitting:
+            fitter.repeatfit()
+        rows = np.array(fitter.ps)
+        if scale is not None:
+            rows[:, 0] /= scale
+        tables.append(rows)
+    return tables
