@@ -222,56 +222,51 @@ def get_centers(im, seeds=None, th_seed=150,
                 fit_radius=5,
                 remove_close_pts=True, close_threshold=0.1,
                 verbose=False):
-    """spot_tools/fitting.py:268-334 — fitted bead centres (K,3) float32."""
-    from ..External.Fitting_v4 import iter_fit_seed_points
+    """spot_tools/fitting.py:268-334 — fitted bead centres (K,3) float32: seeds (found here unless given), first fit and
+    refit sweeps on the device, then (``remove_close_pts``) NaN rows, points with another point within
+    ``close_threshold`` (squared distance) and points outside the image are dropped."""
     if seeds is None:
-        seeds = get_seeds(im, max_num_seeds=max_num_seeds,
-                          th_seed=th_seed, th_seed_per=th_seed_per,
-                          use_percentile=use_percentile,
-                          sel_center=sel_center, seed_radius=seed_radius,
-                          use_dynamic_th=use_dynamic_th,
-                          min_dynamic_seeds=min_num_seeds,
-                          remove_hot_pixel=remove_hot_pixel,
-                          hot_pixel_th=hot_pixel_th,
-                          return_h=False, verbose=verbose,
-                          **seed_kwargs)
-    fitter = iter_fit_seed_points(im, seeds.T, radius_fit=fit_radius)
+        seeding = dict(max_num_seeds=max_num_seeds, th_seed=th_seed, th_seed_per=th_seed_per,
+                       use_percentile=use_percentile, sel_center=sel_center, seed_radius=seed_radius,
+                       use_dynamic_th=use_dynamic_th, min_dynamic_seeds=min_num_seeds,
+                       remove_hot_pixel=remove_hot_pixel, hot_pixel_th=hot_pixel_th, return_h=False, verbose=verbose)
+        _twice = sorted(set(seeding) & set(seed_kwargs))
+        if _twice:   # the reference passes both sets of keywords in one call
+            raise TypeError(f"get_seeds() got multiple values for keyword argument '{_twice[0]}'")
+        seeding.update(seed_kwargs)
+        seeds = get_seeds(im, **seeding)
+    fitter = Fitting_v4.iter_fit_seed_points(im, seeds.T, radius_fit=fit_radius)
     fitter.firstfit()
     fitter.repeatfit()
-    pfits = fitter.ps
-    if len(pfits) > 0:
-        centers = np.array(pfits)[:, 1:4]
-        if verbose:
-            print(f"-- fitting {len(pfits)} points.")
-        if remove_close_pts:                                                 # :319-326
-            _nan = np.isnan(centers).any(1)
-            _d2 = np.sum((centers[:, None, :] - centers[None, :, :]) ** 2, axis=-1)
-            _close = np.sum(_d2 < close_threshold, axis=1) > 1
-            _out = (centers < 0).any(1) | (centers > np.array(im.shape)).any(1)
-            remove = _nan | _close | _out
-            centers = centers[remove == False]  # noqa: E712
-            if verbose:
-                print(f"-- {np.sum(remove)} points removed, given miminum distance {close_threshold}.")
-    else:
-        centers = np.array([])
+    rows = fitter.ps
+    if len(rows) == 0:
         if verbose:
             print("-- no points fitted, return empty array.")
+        return np.array([])
+    centers = np.array(rows)[:, 1:4]
+    if verbose:
+        print(f"-- fitting {len(rows)} points.")
+    if remove_close_pts:                                                     # :319-326
+        sq = ((centers[:, None, :] - centers[None, :, :]) ** 2).sum(axis=-1)
+        crowded = (sq < close_threshold).sum(axis=1) > 1                     # itself + at least one more
+        outside = (centers < 0).any(axis=1) | (centers > np.array(im.shape)).any(axis=1)
+        drop = np.isnan(centers).any(axis=1) | crowded | outside
+        centers = centers[~drop]
+        if verbose:
+            print(f"-- {int(drop.sum())} points removed, given miminum distance {close_threshold}.")
     return centers
 
 
 def select_sparse_centers(centers, distance_th=9,
                           distance_norm=np.inf,
                           verbose=False):
-    """spot_tools/fitting.py:338-363 — greedy sparse selection (host logic on a few hundred rows)."""
-    _sel_centers = []
-    for ct in centers:
-        if len(_sel_centers) == 0:
-            _sel_centers.append(ct)
-        else:
-            _dists = np.linalg.norm(np.array(_sel_centers) - ct[np.newaxis, :], axis=1, ord=distance_norm)
-            if (_dists <= distance_th).any():
-                continue
-            _sel_centers.append(ct)
+    """spot_tools/fitting.py:338-363 — greedy thinning in input order: a centre is kept when no centre kept before it
+    lies within ``distance_th`` (norm ``distance_norm``).  Host logic on a few hundred rows."""
+    kept = []
+    for c in centers:
+        if kept and (np.linalg.norm(np.array(kept) - c, axis=1, ord=distance_norm) <= distance_th).any():
+            continue
+        kept.append(c)
     if verbose:
-        print(f"-- {len(_sel_centers)} among {len(centers)} centers are selected by th={distance_th}")
-    return np.array(_sel_centers)
+        print(f"-- {len(kept)} among {len(centers)} centers are selected by th={distance_th}")
+    return np.array(kept)
