@@ -336,17 +336,32 @@ __device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
   return ((b >> 3) < per && t < n_tiles) ? t : -1;
 }
 
+template <int R> constexpr int fused_threads() { return R <= 3 ? 512 : 256; }
+
 template <class T, int R>
-__global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T* __restrict__ out, int Z, int X, int Y,
+__global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __restrict__ in, T* __restrict__ out, int Z, int X, int Y,
                                                     Taps taps, const int* __restrict__ mz, const int* __restrict__ mx,
                                                     const int* __restrict__ my, int zseg) {
-  constexpr int TX = 32, TY = 64, W = 2 * R + 1;
+  constexpr int TX = 32, TY = 64, W = 2 * R + 1, NT = fused_threads<R>();
   constexpr int EX = TX + 2 * R, EY = TY + 2 * R;          // halo tile
-  constexpr int NPOS = EX * EY, SL = (NPOS + 255) / 256;   // positions per thread
-  constexpr int NX1 = TX * EY, S1 = (NX1 + 255) / 256;     // axis-1 outputs per thread
-  constexpr int S2 = TX * TY / 256;                        // axis-2 outputs per thread
-  __shared__ float A[EX][EY + 1];
-  __shared__ float B[TX][EY + 1];
+  constexpr int NPOS = EX * EY, SL = (NPOS + NT - 1) / NT;   // positions per thread
+  constexpr int NX1 = TX * EY, S1 = (NX1 + NT - 1) / NT;     // axis-1 outputs per thread
+  constexpr int S2 = TX * TY / NT;                        // axis-2 outputs per thread
+  // SQ counters put the first version of this kernel at 78 VALU instructions per voxel for 30 of arithmetic: seven
+  // f32->f64 conversions per tap set on each of the three axes, six register moves per position to slide the z
+  // window, index arithmetic.  For R <= 3 the window therefore holds float64 values (one conversion per loaded voxel)
+  // in a ring addressed with compile-time offsets (the z loop is expanded W times, no moves), with 512 threads per
+  // block so that the 2 x W x SL window registers fit.  Alone the kernel is not faster (0.91 vs 0.81 ms, fewer blocks
+  // in flight), but it runs side by side with the VALU-bound first long pass (seed.hip), and there the VALU
+  // instructions it no longer issues are what counts: DoG stage 3.26 -> 3.06 ms.  Float64 LDS planes (no conversion
+  // on the 2 x W reads per output) and 1024-thread blocks were measured as well: 3.12 and 3.23-3.33 ms.  Larger radii
+  // keep the narrow window: W x SL float64 values would not fit the register file.
+  constexpr bool WIDE = R <= 3;
+  using WT = std::conditional_t<WIDE, double, T>;          // window element
+  using LT = float;                                        // LDS element (the quantised intermediate is exact in a float)
+  constexpr int U = WIDE ? W : 1;                          // z steps per expanded loop body
+  __shared__ LT A[EX][EY + 1];
+  __shared__ LT B[TX][EY + 1];
   const int tid = threadIdx.x;
   const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
   const int tile_id = xcd_tile(blockIdx.x, nty * ntx);   // grid.x = 8 * ceil(tiles / 8)
@@ -359,64 +374,74 @@ __global__ __launch_bounds__(256) void gauss3_fused(const T* __restrict__ in, T*
   int off[SL];
 #pragma unroll
   for (int k = 0; k < SL; ++k) {
-    const int pos = tid + 256 * k;
+    const int pos = tid + NT * k;
     const int xx = pos / EY, yy = pos - xx * EY;
     off[k] = pos < NPOS ? mx[x0 + xx] * Y + my[y0 + yy] : 0;
   }
-  T win[SL][W];   // raw planes z-R .. z+R of every owned position
+  WT win[SL][W];   // planes z-R .. z+R of every owned position; logical slot j lives at (phase + j) % W when WIDE
 #pragma unroll
   for (int j = 0; j < W - 1; ++j) {
     const size_t pz = (size_t)mz[z_begin + j] * plane;
 #pragma unroll
-    for (int k = 0; k < SL; ++k) win[k][j] = in[pz + off[k]];
+    for (int k = 0; k < SL; ++k) win[k][j] = (WT)in[pz + off[k]];
   }
-  for (int z = z_begin; z < z_end; ++z) {
-    {
-      const size_t pz = (size_t)mz[z + W - 1] * plane;
+  for (int zz = z_begin; zz < z_end; zz += U) {
+    auto step = [&](auto pc) -> bool {
+      constexpr int ph = decltype(pc)::value;          // ring phase: logical slot j -> physical (ph + j) % W
+      const int z = zz + ph;
+      if (z >= z_end) return false;                    // block-uniform
+      {
+        const size_t pz = (size_t)mz[z + W - 1] * plane;
 #pragma unroll
-      for (int k = 0; k < SL; ++k) win[k][W - 1] = in[pz + off[k]];
-    }
-    // axis 0 on the halo tile
-#pragma unroll
-    for (int k = 0; k < SL; ++k) {
-      const int pos = tid + 256 * k;
-      if (pos < NPOS) {
-        double acc = (double)win[k][R] * taps.w[0];
-#pragma unroll
-        for (int j = R; j >= 1; --j) acc = acc + ((double)win[k][R - j] + (double)win[k][R + j]) * taps.w[j];
-        const int xx = pos / EY, yy = pos - xx * EY;
-        A[xx][yy] = (float)cvt<T>(acc);
+        for (int k = 0; k < SL; ++k) win[k][(ph + W - 1) % W] = (WT)in[pz + off[k]];
       }
+      // axis 0 on the halo tile
 #pragma unroll
-      for (int j = 0; j < W - 1; ++j) win[k][j] = win[k][j + 1];
-    }
-    __syncthreads();
-    // axis 1: outputs (x, yy) for x in [0,TX), yy in [0,EY)
+      for (int k = 0; k < SL; ++k) {
+        const int pos = tid + NT * k;
+        if (pos < NPOS) {
+          double acc = (double)win[k][(ph + R) % W] * taps.w[0];
 #pragma unroll
-    for (int k = 0; k < S1; ++k) {
-      const int o = tid + 256 * k;
-      if (o < NX1) {
-        const int x = o / EY, yy = o - x * EY;
-        double acc = (double)A[x + R][yy] * taps.w[0];
+          for (int j = R; j >= 1; --j)
+            acc = acc + ((double)win[k][(ph + R - j) % W] + (double)win[k][(ph + R + j) % W]) * taps.w[j];
+          const int xx = pos / EY, yy = pos - xx * EY;
+          A[xx][yy] = (LT)cvt<T>(acc);
+        }
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int j = R; j >= 1; --j) acc = acc + ((double)A[x + R - j][yy] + (double)A[x + R + j][yy]) * taps.w[j];
-        B[x][yy] = (float)cvt<T>(acc);
+          for (int j = 0; j < W - 1; ++j) win[k][j] = win[k][j + 1];
+        }
       }
-    }
-    __syncthreads();
-    // axis 2: outputs (x, y), lanes along y
-    T* po = out + (size_t)z * plane;
+      __syncthreads();
+      // axis 1: outputs (x, yy) for x in [0,TX), yy in [0,EY)
 #pragma unroll
-    for (int k = 0; k < S2; ++k) {
-      const int o = tid + 256 * k;
-      const int x = o / TY, y = o - x * TY;
-      double acc = (double)B[x][y + R] * taps.w[0];
+      for (int k = 0; k < S1; ++k) {
+        const int o = tid + NT * k;
+        if (o < NX1) {
+          const int x = o / EY, yy = o - x * EY;
+          double acc = (double)A[x + R][yy] * taps.w[0];
 #pragma unroll
-      for (int j = R; j >= 1; --j) acc = acc + ((double)B[x][y + R - j] + (double)B[x][y + R + j]) * taps.w[j];
-      if (x0 + x < X && y0 + y < Y) po[(size_t)(x0 + x) * Y + (y0 + y)] = cvt<T>(acc);
-    }
-    // the next plane's A is written only after every thread has passed the barrier above (A is dead after axis 1),
-    // B only after the next plane's first barrier: no third barrier needed
+          for (int j = R; j >= 1; --j) acc = acc + ((double)A[x + R - j][yy] + (double)A[x + R + j][yy]) * taps.w[j];
+          B[x][yy] = (LT)cvt<T>(acc);
+        }
+      }
+      __syncthreads();
+      // axis 2: outputs (x, y), lanes along y
+      T* po = out + (size_t)z * plane;
+#pragma unroll
+      for (int k = 0; k < S2; ++k) {
+        const int o = tid + NT * k;
+        const int x = o / TY, y = o - x * TY;
+        double acc = (double)B[x][y + R] * taps.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) acc = acc + ((double)B[x][y + R - j] + (double)B[x][y + R + j]) * taps.w[j];
+        if (x0 + x < X && y0 + y < Y) po[(size_t)(x0 + x) * Y + (y0 + y)] = cvt<T>(acc);
+      }
+      // the next plane's A is written only after every thread has passed the barrier above (A is dead after axis 1),
+      // B only after the next plane's first barrier: no third barrier needed
+      return true;
+    };
+    static_for_until<0, U>(step);
   }
 }
 
@@ -427,7 +452,7 @@ inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
 template <class T, int R, int KS, int KC, int KZ = KS>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
   const size_t plane = (size_t)X * Y;
-  if constexpr (R <= 6) {
+  if constexpr (R <= 3) {   // R = 6 was measured too: fused 2.26 ms, three passes 1.17 ms (2048x2048x50 f32)
     // maps must cover the halo of the last (partial) tile: positions up to ceil(len/tile)*tile + 2R
     static const std::string nf = "gauss_fused3_R" + std::to_string(R);
     ia3rt::ProfScope ps(nf.c_str());
@@ -445,8 +470,8 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     int zseg = Z;
     while ((long long)bx * by * ((Z + zseg - 1) / zseg) < 1024 && zseg / 2 >= 4 * R) zseg = (zseg + 1) / 2;
     dim3 g(8 * ((bx * by + 7) / 8), 1, (unsigned)((Z + zseg - 1) / zseg));   // tiles, XCD-grouped inside the kernel
-    hipLaunchKernelGGL((gauss3_fused<T, R>), g, dim3(256), 0, s, src, dst, Z, X, Y, t, (const int*)qz, (const int*)qx,
-                       (const int*)qy, zseg);
+    hipLaunchKernelGGL((gauss3_fused<T, R>), g, dim3(fused_threads<R>()), 0, s, src, dst, Z, X, Y, t, (const int*)qz,
+                       (const int*)qx, (const int*)qy, zseg);
     (void)tmp;
     return 0;
   }
