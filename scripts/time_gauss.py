@@ -27,3 +27,8 @@ for var in (0,):
   for rep in range(10):
       L.check(lib.ia3_dog_seed_dev(a._h, C.byref(sp), L.dptr(out), len(out), C.byref(nn), C.byref(th)))
   print("var", var, "dog_seed %.3f ms" % ((time.perf_counter() - t0) * 100), nn.value)
+  L.profile_enable(True)
+  for rep in range(5):
+      L.check(lib.ia3_dog_seed_dev(a._h, C.byref(sp), L.dptr(out), len(out), C.byref(nn), C.byref(th)))
+  prof = L.profile_collect(); L.profile_enable(False)
+  print("   ", {k: round(v[1] / v[0], 3) for k, v in prof.items()})
