@@ -39,6 +39,18 @@ IA3_HD constexpr int tri(int i, int j) {  // packed upper-triangle index, i <= j
 #define IA3_UNROLL _Pragma("GCC unroll 16")
 #endif
 
+// Element-wise sections (ten independent square roots or divisions, each a 20-30 instruction sequence on the GPU) run
+// on lanes 0..9 of the wave, one element per lane, instead of ten times on every lane: operands and results go through
+// the LDS-resident work area, the surrounding control flow stays wave-uniform.  Same operations on the same operands,
+// so results are bit-identical to the serial form the host build uses.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IA3_LM_PAR 1
+#define IA3_LM_SYNC() __builtin_amdgcn_wave_barrier()
+__device__ __forceinline__ int lm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#else
+#define IA3_LM_PAR 0
+#endif
+
 struct LMWork {      // persistent across evaluations (LDS on the device)
   double A[NTRI];    // JᵀJ at the current accepted point
   double g[NP];      // Jᵀf at the current accepted point
@@ -49,6 +61,7 @@ struct LMWork {      // persistent across evaluations (LDS on the device)
   double x[NP];
   double xt[NP];     // trial point
   double p[NP];      // step
+  double sc[2 * NP]; // scratch of the lane-parallel sections
 };
 
 struct LMResult {
@@ -112,8 +125,30 @@ IA3_HD double lm_norm(const double* v) {
   return sqrt(s);
 }
 
+// t1[j] = diag[j] * ((diag[j] * x[j]) / dxnorm);  t2[j] = diag[j] * x[j] is passed in for the serial form
+IA3_HD void lm_scaled(const double* diag, const double* x, const double* t2, double dxnorm, double* t1, double* sc) {
+#if IA3_LM_PAR
+  IA3_UNROLL
+  for (int j = 0; j < NP; ++j) sc[NP + j] = x[j];          // wave-uniform values: every lane stores the same
+  IA3_LM_SYNC();
+  const int ln = lm_lane();
+  if (ln < NP) { const double d = diag[ln]; sc[ln] = d * ((d * sc[NP + ln]) / dxnorm); }
+  IA3_LM_SYNC();
+  IA3_UNROLL
+  for (int j = 0; j < NP; ++j) t1[j] = sc[j];
+  IA3_LM_SYNC();
+  (void)t2;
+#else
+  IA3_UNROLL
+  for (int j = 0; j < NP; ++j) t1[j] = diag[j] * (t2[j] / dxnorm);
+  (void)x; (void)sc;
+#endif
+}
+
 // lmpar on the normal equations: find par with | |D x| - delta | <= 0.1 delta, x = (A+par D²)⁻¹ g
-IA3_HD void lm_par(const double* A, const double* g, const double* diag, double delta, double& par, double* x) {
+// sc: 2*NP doubles of scratch (LDS on the device)
+IA3_HD void lm_par(const double* A, const double* g, const double* diag, double delta, double& par, double* x,
+                   double* sc) {
   Chol c;
   double t1[NP], t2[NP];
   lm_factor(A, diag, 0.0, c);
@@ -127,14 +162,24 @@ IA3_HD void lm_par(const double* A, const double* g, const double* diag, double 
   if (fp <= 0.1 * delta) { par = 0.0; return; }
   double parl = 0.0;
   if (c.skip == 0) {
-    IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t1[j] = diag[j] * (t2[j] / dxnorm);
+    lm_scaled(diag, x, t2, dxnorm, t1, sc);
     lm_fwd(c, t1, t1);
     double temp = lm_norm(t1);
     parl = ((fp / delta) / temp) / temp;
   }
+#if IA3_LM_PAR
+  {
+    const int ln = lm_lane();
+    if (ln < NP) sc[ln] = g[ln] / diag[ln];
+    IA3_LM_SYNC();
+    IA3_UNROLL
+    for (int j = 0; j < NP; ++j) t1[j] = sc[j];
+    IA3_LM_SYNC();
+  }
+#else
   IA3_UNROLL
   for (int j = 0; j < NP; ++j) t1[j] = g[j] / diag[j];
+#endif
   double gnorm = lm_norm(t1);
   double paru = gnorm / delta;
   if (paru == 0.0) paru = IA3_DWARF / (delta < 0.1 ? delta : 0.1);
@@ -153,8 +198,7 @@ IA3_HD void lm_par(const double* A, const double* g, const double* diag, double 
     double temp = fp;
     fp = dxnorm - delta;
     if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-    IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t1[j] = diag[j] * (t2[j] / dxnorm);
+    lm_scaled(diag, x, t2, dxnorm, t1, sc);
     lm_fwd(c, t1, t1);
     temp = lm_norm(t1);
     double parc = ((fp / delta) / temp) / temp;
@@ -177,8 +221,16 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
   double fnorm = ev.eval(w.x, Ac, gc);
   double par = 0.0, delta = 0.0, xnorm = 0.0;
   for (;;) {  // outer loop: A, g hold JᵀJ, Jᵀf at x
+#if IA3_LM_PAR
+    {
+      const int ln = lm_lane();
+      if (ln < NP) w.cn[ln] = sqrt(Ac[tri(ln, ln)]);
+      IA3_LM_SYNC();
+    }
+#else
     IA3_UNROLL
     for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(Ac[tri(j, j)]);
+#endif
     if (r.iter == 1) {
       double t[NP];
       IA3_UNROLL
@@ -192,20 +244,42 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
     }
     double gnorm = 0.0;
     if (fnorm != 0.0) {
+#if IA3_LM_PAR
+      {
+        const int ln = lm_lane();
+        if (ln < NP) { const double cnl = w.cn[ln]; if (cnl != 0.0) w.sc[ln] = fabs((gc[ln] / fnorm) / cnl); }
+        IA3_LM_SYNC();
+      }
+#endif
       IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
         if (w.cn[j] != 0.0) {
+#if IA3_LM_PAR
+          double v = w.sc[j];
+#else
           double v = fabs((gc[j] / fnorm) / w.cn[j]);
+#endif
           gnorm = gnorm > v ? gnorm : v;
         }
       }
+#if IA3_LM_PAR
+      IA3_LM_SYNC();
+#endif
     }
     if (gnorm <= gtol) { r.info = 4; break; }
+#if IA3_LM_PAR
+    {
+      const int ln = lm_lane();
+      if (ln < NP) { const double dl = w.diag[ln], cl = w.cn[ln]; w.diag[ln] = dl > cl ? dl : cl; }
+      IA3_LM_SYNC();
+    }
+#else
     IA3_UNROLL
     for (int j = 0; j < NP; ++j) w.diag[j] = w.diag[j] > w.cn[j] ? w.diag[j] : w.cn[j];
+#endif
     for (;;) {  // inner loop
       double pv[NP], t[NP];
-      lm_par(Ac, gc, w.diag, delta, par, pv);
+      lm_par(Ac, gc, w.diag, delta, par, pv, w.sc);
       IA3_UNROLL
       for (int j = 0; j < NP; ++j) {
         pv[j] = -pv[j];
@@ -218,6 +292,21 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       // |J p|² = pᵀ A p   (A of the current accepted point; must precede the trial evaluation only
       // in the sense that A is still untouched: eval writes A1/g1)
       double jp2 = 0.0;
+#if IA3_LM_PAR
+      {
+        const int ln = lm_lane();
+        if (ln < NP) {   // row ln of A times p, columns in ascending order as in the serial form
+          double s = 0.0;
+          IA3_UNROLL
+          for (int j = 0; j < NP; ++j) s += (ln <= j ? Ac[tri(ln, j)] : Ac[tri(j, ln)]) * pv[j];
+          w.sc[ln] = s;
+        }
+        IA3_LM_SYNC();
+        IA3_UNROLL
+        for (int i = 0; i < NP; ++i) jp2 += pv[i] * w.sc[i];
+        IA3_LM_SYNC();
+      }
+#else
       IA3_UNROLL
       for (int i = 0; i < NP; ++i) {
         double s = 0.0;
@@ -225,6 +314,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
         for (int j = 0; j < NP; ++j) s += (i <= j ? Ac[tri(i, j)] : Ac[tri(j, i)]) * pv[j];
         jp2 += pv[i] * s;
       }
+#endif
       if (jp2 < 0.0) jp2 = 0.0;
       double fnorm1 = ev.eval(w.xt, At, gt);
       ++r.nfev;
