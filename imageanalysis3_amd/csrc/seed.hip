@@ -130,6 +130,19 @@ __device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
   return ((b >> 3) < per && t < n_tiles) ? t : -1;
 }
 
+// three-input extrema: one v_max3 / v_min3 instruction each (the `a > b ? a : b` spelling compiles to a compare, a
+// select and a hazard nop per pair: the SQ counters showed 50 VALU instructions per voxel, most of them these)
+__device__ __forceinline__ float max3v(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float min3v(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ uint16_t max3v(uint16_t a, uint16_t b, uint16_t c) {
+  const unsigned m = max(max((unsigned)a, (unsigned)b), (unsigned)c);
+  return (uint16_t)m;
+}
+__device__ __forceinline__ uint16_t min3v(uint16_t a, uint16_t b, uint16_t c) {
+  const unsigned m = min(min((unsigned)a, (unsigned)b), (unsigned)c);
+  return (uint16_t)m;
+}
+
 template <class T, int ZC>
 __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ mx, const T* __restrict__ mn,
                                                           int Z, int X, int Y, int edge, double th_low,
@@ -184,15 +197,13 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
         const int r = tg * 4 + rr;
         const T a0 = tmax[buf][r][c - 1], a1 = tmax[buf][r][c], a2 = tmax[buf][r][c + 1];
         const T b0 = tmin[buf][r][c - 1], b1 = tmin[buf][r][c], b2 = tmin[buf][r][c + 1];
-        T a = a0 > a1 ? a0 : a1; a = a2 > a ? a2 : a;
-        T b = b0 < b1 ? b0 : b1; b = b2 < b ? b2 : b;
+        const T a = max3v(a0, a1, a2), b = min3v(b0, b1, b2);
         hM[rr] = a; hm[rr] = b;
         if (rr >= 1 && rr <= 4) { ce[rr - 1] = a1; cf[rr - 1] = b1; }
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        T a = hM[v] > hM[v + 1] ? hM[v] : hM[v + 1]; a = hM[v + 2] > a ? hM[v + 2] : a;
-        T b = hm[v] < hm[v + 1] ? hm[v] : hm[v + 1]; b = hm[v + 2] < b ? hm[v + 2] : b;
+        const T a = max3v(hM[v], hM[v + 1], hM[v + 2]), b = min3v(hm[v], hm[v + 1], hm[v + 2]);
         pM[v][0] = pM[v][1]; pM[v][1] = pM[v][2]; pM[v][2] = a;
         pm[v][0] = pm[v][1]; pm[v][1] = pm[v][2]; pm[v][2] = b;
         cM[v][0] = cM[v][1]; cM[v][1] = ce[v];
@@ -206,10 +217,7 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int x = x0 + tg * 4 + v, y = y0 + ty;
-      T vmax = pM[v][0] > pM[v][1] ? pM[v][0] : pM[v][1];
-      vmax = pM[v][2] > vmax ? pM[v][2] : vmax;
-      T vmin = pm[v][0] < pm[v][1] ? pm[v][0] : pm[v][1];
-      vmin = pm[v][2] < vmin ? pm[v][2] : vmin;
+      const T vmax = max3v(pM[v][0], pM[v][1], pM[v][2]), vmin = min3v(pm[v][0], pm[v][1], pm[v][2]);
       const T cmax = cM[v][0], cmin = cm[v][0];
       const float diff = (float)cmax - (float)cmin;
       bool hit = x < X && y < Y && (vmax == cmax) && (vmin != cmin) && ((double)diff >= th_low);
