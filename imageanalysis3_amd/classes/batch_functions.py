@@ -365,16 +365,26 @@ def batch_process_image_to_spots(dax_filename,
         print(f"+ batch process image: {dax_filename} for channels:{channels}")
 
     # ---- what does the save file already hold? (:121-166) ----------------------------------------------------------
-    with _held(fov_savefile_lock):
-        stored_ims, stored_flags, stored_drifts = load_image_from_fov_file(
-            save_filename, data_type, region_ids, load_drift=True, verbose=verbose)
+    # The reference loads every image slot and then decides; a slot is reusable only when it holds data AND its flag
+    # says it was stored the way this call wants it (warped or not), so slots whose flag does not match — every slot
+    # of a fresh file — are not read at all (3 x 419 MB per movie for a full-size FOV).
+    _require_type(data_type)
     redo_everything = overwrite_image or overwrite_drift
-    todo = []            # per channel: True = correct it from the movie, False = reuse the stored image
-    for im, flag in zip(stored_ims, stored_flags):
-        usable = (im != empty_value).any() and int(flag) - 1 == int(warp_image)
-        todo.append(redo_everything or not usable)
-    reused = {c: im.copy() for c, im, t in zip(channels, stored_ims, todo) if not t}
-    del stored_ims
+    todo, reused, stored_drifts = [], {}, []   # per channel: True = correct it from the movie, False = reuse the stored image
+    t_load = time.time()
+    with _held(fov_savefile_lock), SaveFile(save_filename, data_type) as sf:
+        for c, rid in zip(channels, region_ids):
+            slot = sf.row(rid)
+            stored_drifts.append(sf['drifts'][slot, :])
+            usable = False
+            if not redo_everything and int(sf['flags'][slot]) - 1 == int(warp_image):
+                im = sf['ims'][slot]
+                usable = bool(im.any() if empty_value == 0 else (im != empty_value).any())
+                if usable:
+                    reused[c] = im
+            todo.append(not usable)
+    if verbose:
+        print(f"- loading {data_type} info from file:{os.path.basename(save_filename)} in {time.time()-t_load:.3f}s.")
     start_drift, measure_drift = _stored_drift(stored_drifts, overwrite_drift)
 
     resident = []        # DeviceStacks owned by this call

@@ -293,8 +293,12 @@ int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
   int rc = ensure_init(); if (rc) return rc;
   rc = check_shape(dtype, Z, X, Y); if (rc) return rc;
   size_t bytes = (size_t)Z * X * Y * esize(dtype);
-  void* d = nullptr;
-  if (hipMalloc(&d, bytes) != hipSuccess) return set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  // stacks come from the same stream-ordered cache as the scratch buffers: a chain of operators allocates and frees
+  // dozens of 0.4 GB stacks per movie, and hipMalloc / hipFree (which synchronises the device) cost 1-2 ms each.
+  // A freed block is handed out again only after the work queued on the freeing thread's stream (ws_get waits for
+  // that event when another stream takes it over): free a stack from the thread that used it last.
+  void* d = ws_get(bytes);
+  if (!d) return IA3_ENOMEM;
   *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes};
   return IA3_OK;
 }
@@ -441,7 +445,7 @@ int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void*
 }
 void ia3_stack_free(ia3_stack* s) {
   if (!s) return;
-  if (s->owned && s->d) (void)hipFree(s->d);
+  if (s->owned && s->d) ws_put(s->d);
   delete s;
 }
 
