@@ -13,6 +13,7 @@ struct ia3_stack {
   int dtype, Z, X, Y;
   bool owned;
   size_t bytes;
+  void* home = nullptr;   // hipStream_t of the thread that allocated it (owned stacks): see ia3_stack_free
 };
 
 namespace ia3rt {

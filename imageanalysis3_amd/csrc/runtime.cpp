@@ -299,7 +299,7 @@ int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
   // that event when another stream takes it over): free a stack from the thread that used it last.
   void* d = ws_get(bytes);
   if (!d) return IA3_ENOMEM;
-  *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes};
+  *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes, (void*)t_ctx.main};
   return IA3_OK;
 }
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out) {
@@ -445,7 +445,17 @@ int ia3_stack_info(const ia3_stack* s, int* dtype, int* Z, int* X, int* Y, void*
 }
 void ia3_stack_free(ia3_stack* s) {
   if (!s) return;
-  if (s->owned && s->d) ws_put(s->d);
+  if (s->owned && s->d) {
+    // freed by another thread than the one that allocated it (a finaliser, a hand-over between workers): the block
+    // must not be reused before the allocating thread's queued work either, so this thread's stream waits for it
+    hipStream_t home = (hipStream_t)s->home, me = t_ctx.main ? t_ctx.main : g_stream;
+    if (home && me && home != me && g_pid == getpid()) {
+      static thread_local hipEvent_t ev = nullptr;
+      if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      if (ev && hipEventRecord(ev, home) == hipSuccess) (void)hipStreamWaitEvent(me, ev, 0);
+    }
+    ws_put(s->d);
+  }
   delete s;
 }
 
