@@ -355,9 +355,12 @@ def batch_process_image_to_spots(dax_filename,
                                  spot_file_lock=None,
                                  overwrite_spot=False,
                                  verbose=False,
-                                 return_spots=False):
+                                 return_spots=False,
+                                 fit_workers=None):
     """reference :60-303 — one movie: corrected images + drift into the FOV save file, then the spots of every selected
-    channel.  Returns None like the reference; ``return_spots=True`` (an extension) returns ``(spots, raw_spots)``."""
+    channel.  Returns None like the reference; ``return_spots=True`` (an extension) returns ``(spots, raw_spots)``;
+    ``fit_workers`` (an extension): host threads fitting the channels of this movie side by side (default: one per
+    channel, at most 4; 1 = one after the other)."""
     _check_batch_arguments(dax_filename, save_filename, ref_filename, sel_channels, region_ids)
     channels = [str(c) for c in sel_channels]
     region_ids = [int(r) for r in region_ids]
@@ -437,12 +440,22 @@ def batch_process_image_to_spots(dax_filename,
                     fitting_args['seed_mask'] = ndimage.shift(fitting_args['seed_mask'], -drift, mode='constant', cval=0)
                 if verbose:   # (the reference reads the timer here on both branches: NameError with warp_image)
                     print(f"-- in {time.time()-_translate_start:.2f}s.")
-            spot_list = []
-            for k, (im, c) in enumerate(zip(images, channels)):
-                fitting_args['th_seed'] = Channel_2_SeedTh[str(c)]
-                raw = fit_fov_image(im, c, verbose=verbose, **fitting_args)
-                spot_list.append(raw.copy() if translate is None else translate[k](raw))
-                raw_spot_list.append(raw)
+            def fit_channel(k):
+                # the reference sets fitting_args['th_seed'] per channel inside its loop; every task gets its own copy
+                kw = dict(fitting_args, th_seed=Channel_2_SeedTh[str(channels[k])])
+                return fit_fov_image(images[k], channels[k], verbose=verbose, **kw)
+
+            workers = min(len(images), 4 if fit_workers is None else int(fit_workers))
+            if workers > 1:   # the channels of one movie are independent: their fits share the device (own streams)
+                from concurrent.futures import ThreadPoolExecutor
+                L.check(L.lib().ia3_sync())   # the corrected stacks were produced on THIS thread's stream: finish them
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    raw_spot_list = list(pool.map(fit_channel, range(len(images))))
+            else:
+                raw_spot_list = [fit_channel(k) for k in range(len(images))]
+            if channels:
+                fitting_args['th_seed'] = Channel_2_SeedTh[str(channels[-1])]   # what the reference's loop leaves behind
+            spot_list = [raw.copy() if translate is None else translate[k](raw) for k, raw in enumerate(raw_spot_list)]
             if save_spots:
                 with _held(spot_file_lock):
                     save_spots_to_fov_file(save_filename, spot_list, data_type, region_ids,

@@ -73,7 +73,7 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("C5_TMP", "/tmp")) as td:
                           "rows": rows, "max_abs_drift": float(np.abs(drifts).max())}), flush=True)
         os.remove(path)
 
-    run("warmup", 1, False, 1)
+    run("warmup", 1, False, 1)   # every variant must report the same number of rows per movie
     run("seq_nosave", 1, False, N_MOVIES)
     run("thr4_nosave", 4, False, N_MOVIES)
     run("thr4_save", 4, True, N_MOVIES)
