@@ -169,6 +169,8 @@ def fit_fov_images(ims, channels=None, n_workers=2, **kwargs):
     if channels is None:
         channels = [None] * len(ims)
     L.lib()   # load once, before the threads start
+    if any(isinstance(_im, L.DeviceStack) for _im in ims):
+        L.check(L.lib().ia3_sync())   # resident inputs may still be in production on this thread's stream
     kwargs.setdefault("verbose", False)
     if n_workers <= 1 or len(ims) <= 1:
         return [fit_fov_image(_im, _ch, **kwargs) for _im, _ch in zip(ims, channels)]
