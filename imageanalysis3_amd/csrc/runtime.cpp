@@ -147,12 +147,36 @@ void* ws_get(size_t bytes) {
   g_ws.push_back(WsEntry{p, bytes, true, nullptr, nullptr});
   return p;
 }
+// idle blocks above this total go back to the driver (largest first): stacks of many different sizes would otherwise
+// pile up in a long-running process.  IA3_CACHE_GB overrides the default of 64 GB (the device has 288).
+static size_t ws_idle_limit() {
+  static const size_t lim = [] {
+    const char* e = getenv("IA3_CACHE_GB");
+    const double gb = e ? atof(e) : 64.0;
+    return (size_t)((gb > 0 ? gb : 0) * 1073741824.0);
+  }();
+  return lim;
+}
+static void ws_trim_locked() {
+  size_t idle = 0;
+  for (auto& e : g_ws) if (!e.busy && e.p) idle += e.bytes;
+  while (idle > ws_idle_limit()) {
+    int big = -1;
+    for (size_t i = 0; i < g_ws.size(); ++i)
+      if (!g_ws[i].busy && g_ws[i].p && (big < 0 || g_ws[i].bytes > g_ws[big].bytes)) big = (int)i;
+    if (big < 0) break;
+    (void)hipFree(g_ws[big].p);   // synchronises the device: rare by construction
+    idle -= g_ws[big].bytes;
+    g_ws[big].p = nullptr; g_ws[big].bytes = 0; g_ws[big].last = nullptr;
+  }
+}
 static void ws_release_locked(void* p, hipStream_t on) {
   for (auto& e : g_ws) if (e.p == p) {
     if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
     if (e.ev) (void)hipEventRecord(e.ev, on);
     e.last = on;
     e.busy = false;
+    ws_trim_locked();
     return;
   }
 }

@@ -1118,3 +1118,24 @@ def test_movie_file_streams_into_a_resident_stack(tmp_path):
         L.DeviceStack.from_file(path, frames + 1, X, Y)
     with pytest.raises(ValueError):
         L.DeviceStack.from_file(str(tmp_path / "absent.dax"), 1, 8, 8)
+
+
+def test_stack_cache_reuse_and_release():
+    """Stacks come from the stream-ordered cache: a freed block is handed out again, contents of live stacks are never
+    touched, ia3_release_workspace gives idle blocks back."""
+    from imageanalysis3_amd import _lib as L
+    rng = np.random.RandomState(1)
+    a = rng.randint(0, 60000, size=(5, 64, 96)).astype(np.uint16)
+    s1 = L.DeviceStack.upload(a)
+    s2 = L.DeviceStack.upload(a + 1)
+    s1.free()
+    s3 = L.DeviceStack.upload(a + 2)          # may reuse s1's block; s2 must be intact
+    assert np.array_equal(s2.download(), a + 1) and np.array_equal(s3.download(), a + 2)
+    c = s3.crop([[1, 4], [10, 50], [20, 90]])
+    assert np.array_equal(c.download(), (a + 2)[1:4, 10:50, 20:90])
+    for s in (s2, s3, c):
+        s.free()
+    L.check(L.lib().ia3_release_workspace())
+    s4 = L.DeviceStack.upload(a)
+    assert np.array_equal(s4.download(), a)
+    s4.free()
