@@ -12,9 +12,11 @@ import numpy as np
 from .. import _lib as L
 from .. import _allowed_colors, _image_size, _num_buffer_frames, _num_empty_frames, _correction_folder
 
-# "phase" is scikit-image's default since 0.19; the reference pins no version, set to
-# None to get the un-normalised correlation of scikit-image 0.17/0.18.
-DEFAULT_NORMALIZATION = "phase"
+# The reference calls skimage.registration.phase_cross_correlation without pinning a version.  None = the
+# un-normalised correlation of scikit-image 0.17 / 0.18 — the release found next to the reference's other dependencies
+# in this image (0.18.3), against which this path is pinned bit for bit (tests/golden/phase.npz); "phase" = the
+# default of scikit-image >= 0.19, checked against the oracle's restatement of the published algorithm only.
+DEFAULT_NORMALIZATION = None
 
 
 def _find_boundary(_ct, _radius, _im_size):

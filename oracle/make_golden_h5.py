@@ -121,7 +121,39 @@ def batch_golden(B, d, td):
     d['raw_crc'] = crc(case["raw"])
 
 
+def phase_golden():
+    """skimage.registration.phase_cross_correlation (the real one: 0.18.3 in /opt/conda, the un-normalised
+    correlation of the 0.17/0.18 releases) and the reference's align_image on its default phase-correlation path
+    (correction_tools/alignment.py:527-695), on the bead pairs of imageanalysis3_amd.synth.make_bead_pair."""
+    import skimage
+    from skimage.registration import phase_cross_correlation
+    from imageanalysis3_amd import synth
+    R = ref_loader.load_reference()
+    d = {"skimage_version": np.array(skimage.__version__)}
+    dd = np.array([0.7, -3.25, 5.5])
+    ref, src, _, _ = synth.make_bead_pair((20, 96, 96), 20, 3, dd, margin=(5, 12, 12), min_sep=12.0)
+    for tag, a, b in (("f32", ref, src), ("u16", ref.astype(np.uint16), src.astype(np.uint16))):
+        for up in (1, 10, 100):
+            sh, err, ph = phase_cross_correlation(a, b, upsample_factor=up)
+            d["pcc_%s_%d" % (tag, up)] = np.concatenate([np.asarray(sh, np.float64), [err, ph]])
+    d2 = np.array([1.3, -4.6, 7.25])
+    ref2, src2, _, _ = synth.make_bead_pair((30, 256, 256), 120, 21, d2)
+    crops = R.alignment.generate_drift_crops(single_im_size=[30, 256, 256])
+    d["align_crops"] = np.asarray(crops)
+    out = quiet(R.alignment.align_image, src2, ref2, crop_list=crops, use_autocorr=True, verbose=False)
+    d["align_drift"], d["align_flag"] = np.asarray(out[0], np.float64), np.array(out[1])
+    out = quiet(R.alignment.align_image, src2.astype(np.uint16), ref2.astype(np.uint16), crop_list=crops, use_autocorr=True,
+                verbose=False)
+    d["align_u16_drift"], d["align_u16_flag"] = np.asarray(out[0], np.float64), np.array(out[1])
+    np.savez_compressed(os.path.join(OUT, "phase.npz"), **d)
+    for k in sorted(d):
+        print(k, d[k])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "phase":
+        phase_golden()
+        sys.exit(0)
     B = ref_loader.load_batch()
     d = {}
     with tempfile.TemporaryDirectory() as td:

@@ -8,9 +8,11 @@ Parity status: PINNED.  Every function below is checked in ``tests/test_oracle_g
 against fixtures produced by running the reference's own Python in the development
 container (``oracle/make_golden.py`` → ``tests/golden/*.npz``), and — where the reference tree
 is present — directly against the reference (``tests/test_oracle_vs_reference.py``).
-Exception: ``phase_cross_correlation`` (scikit-image, not vendored by the reference, version
-unpinned, not installed) — that function is "parity unpinned" and is validated by known-answer
-tests only.
+``phase_cross_correlation`` (scikit-image, not vendored by the reference, version unpinned, absent from the
+system interpreter) is pinned against the real scikit-image 0.18.3 of the image's Anaconda interpreter
+(``oracle/make_golden_h5.py phase`` → ``tests/golden/phase.npz``) for ``normalization=None``; the
+``normalization="phase"`` flavour of scikit-image >= 0.19 is a restatement of the published algorithm validated by
+known-answer tests only.
 
 Third-party arithmetic the reference delegates to and this oracle keeps delegating to:
 ``scipy.optimize.leastsq`` (MINPACK lmder), ``scipy.spatial.cKDTree`` / ``Delaunay``,

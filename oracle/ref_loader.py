@@ -61,13 +61,17 @@ def load_reference():
     pfn = stub("pyfftw.interfaces.numpy_fft", rfftn=np.fft.rfftn, irfftn=np.fft.irfftn)
     stub("pyfftw", interfaces=stub("pyfftw.interfaces", numpy_fft=pfn))
     stub("cv2")
-    stub("skimage", morphology=None, restoration=None, measure=None)
-    stub("skimage.segmentation", random_walker=None)
+    try:   # the real scikit-image where an interpreter has it (/opt/conda's python3.9: 0.18.3)
+        import skimage.registration  # noqa: F401
+        import skimage.segmentation  # noqa: F401
+    except Exception:
+        stub("skimage", morphology=None, restoration=None, measure=None)
+        stub("skimage.segmentation", random_walker=None)
 
-    def _no_pcc(*a, **k):
-        raise RuntimeError("scikit-image not installed")
+        def _no_pcc(*a, **k):
+            raise RuntimeError("scikit-image not installed")
 
-    stub("skimage.registration", phase_cross_correlation=_no_pcc)
+        stub("skimage.registration", phase_cross_correlation=_no_pcc)
     G = dict(_correction_folder="", _temp_folder="", _distance_zxy=[200, 108, 108],
              _sigma_zxy=[1.35, 1.9, 1.9],
              _allowed_colors=["750", "647", "561", "488", "405"],

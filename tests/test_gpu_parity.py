@@ -366,8 +366,9 @@ def test_pairing_golden():
 
 @pytest.mark.parametrize("norm", ["phase", None])
 def test_phase_cross_correlation_vs_oracle_and_truth(norm):
-    """PARITY UNPINNED against scikit-image (absent): checked against the oracle's restatement of the
-    published algorithm and against the analytically injected shift."""
+    """Both normalisations against the oracle's restatement of the published algorithm and the analytically injected
+    shift (normalization=None is additionally pinned against scikit-image 0.18.3 itself, see
+    test_phase_correlation_and_align_image_vs_scikit_image_golden)."""
     import np_oracle as O
     from imageanalysis3_amd import synth
     from imageanalysis3_amd.correction_tools.alignment import phase_cross_correlation
@@ -1139,3 +1140,29 @@ def test_stack_cache_reuse_and_release():
     s4 = L.DeviceStack.upload(a)
     assert np.array_equal(s4.download(), a)
     s4.free()
+
+
+def test_phase_correlation_and_align_image_vs_scikit_image_golden(monkeypatch):
+    """Pinned against the real thing: skimage.registration.phase_cross_correlation 0.18.3 (un-normalised correlation)
+    and the reference's align_image on its default phase-correlation path, both run under /opt/conda's interpreter
+    (oracle/make_golden_h5.py phase)."""
+    from imageanalysis3_amd import synth
+    from imageanalysis3_amd.correction_tools import alignment
+    g = load_golden("phase.npz")
+    dd = np.array([0.7, -3.25, 5.5])
+    ref, src, _, _ = synth.make_bead_pair((20, 96, 96), 20, 3, dd, margin=(5, 12, 12), min_sep=12.0)
+    for tag, a, b in (("f32", ref, src), ("u16", ref.astype(np.uint16), src.astype(np.uint16))):
+        for up in (1, 10, 100):
+            s, e, p = alignment.phase_cross_correlation(a, b, upsample_factor=up, normalization=None)
+            exp = g["pcc_%s_%d" % (tag, up)]
+            assert np.allclose(s, exp[:3], atol=1e-9), (tag, up, s, exp[:3])
+            assert abs(e - exp[3]) <= 1e-5 and abs(p - exp[4]) <= 1e-5, (tag, up, e, p, exp[3:])
+    d2 = np.array([1.3, -4.6, 7.25])
+    ref2, src2, _, _ = synth.make_bead_pair((30, 256, 256), 120, 21, d2)
+    crops = alignment.generate_drift_crops(single_im_size=[30, 256, 256])
+    assert np.array_equal(np.asarray(crops), g["align_crops"])
+    monkeypatch.setattr(alignment, "DEFAULT_NORMALIZATION", None)   # what scikit-image 0.17 / 0.18 compute
+    for a, b, key in ((src2, ref2, "align"), (src2.astype(np.uint16), ref2.astype(np.uint16), "align_u16")):
+        drift, flag = alignment.align_image(a, b, crop_list=crops, use_autocorr=True, verbose=False)
+        assert flag == int(g[key + "_flag"])
+        assert np.allclose(drift, g[key + "_drift"], atol=1e-9), (key, drift, g[key + "_drift"])

@@ -289,3 +289,19 @@ def test_load_correction_profile_names(monkeypatch):
         LD.load_correction_profile("illumination", corr_channels=['999'], correction_folder="/corr")
     with pytest.raises(ValueError):
         LD.load_correction_profile("chromatic", ref_channel='999', correction_folder="/corr")
+
+
+def test_phase_cross_correlation_oracle_vs_scikit_image():
+    """The oracle's restatement against the real skimage.registration.phase_cross_correlation (0.18.3, the
+    un-normalised correlation; fixtures from oracle/make_golden_h5.py run under /opt/conda's interpreter)."""
+    from conftest import GOLDEN
+    from imageanalysis3_amd import synth
+    g = np.load(os.path.join(GOLDEN, "phase.npz"))
+    dd = np.array([0.7, -3.25, 5.5])
+    ref, src, _, _ = synth.make_bead_pair((20, 96, 96), 20, 3, dd, margin=(5, 12, 12), min_sep=12.0)
+    for tag, a, b in (("f32", ref, src), ("u16", ref.astype(np.uint16), src.astype(np.uint16))):
+        for up in (1, 10, 100):
+            s, e, p = O.phase_cross_correlation(a, b, upsample_factor=up, normalization=None)
+            exp = g["pcc_%s_%d" % (tag, up)]
+            assert np.allclose(s, exp[:3], atol=1e-9), (tag, up, s, exp[:3])
+            assert abs(e - exp[3]) <= 1e-6 and abs(p - exp[4]) <= 1e-6, (tag, up, e, p, exp[3:])
