@@ -118,6 +118,16 @@ def batch_golden(B, d, td):
               warp_image=warp, correction_args=dict(cargs), fitting_args=dict(fit, max_num_seeds=3),
               overwrite_spot=True, verbose=warp)
         dump(path, 'unique', tag + "over_", d, with_ims=False)
+    # drift measured by the reference itself (phase correlation of the bead channel, scikit-image 0.18.3) instead of a
+    # stored one: nothing is given, everything downstream (warp, fit, stored drifts) hangs on that measurement
+    nb, Z = case["nb"], case["Z"]
+    bead = np.ascontiguousarray(case["raw"][nb + (3 - nb) % 4::4][:Z])
+    bead_ref = np.roll(bead, (1, -2), axis=(1, 2))
+    path = os.path.join(td, "d_fov.hdf5")
+    make_save_file(path, 'unique', [5, 2, 9], ['750', '647', '561'], size, 4)
+    quiet(B.batch_process_image_to_spots, movie, ['750', '647'], path, 'unique', [5, 2], bead_ref,
+          warp_image=True, correction_args=dict(corr), fitting_args=dict(fit), verbose=True)
+    dump(path, 'unique', "d_", d, with_ims=False)
     d['raw_crc'] = crc(case["raw"])
 
 

@@ -1166,3 +1166,36 @@ def test_phase_correlation_and_align_image_vs_scikit_image_golden(monkeypatch):
         drift, flag = alignment.align_image(a, b, crop_list=crops, use_autocorr=True, verbose=False)
         assert flag == int(g[key + "_flag"])
         assert np.allclose(drift, g[key + "_drift"], atol=1e-9), (key, drift, g[key + "_drift"])
+
+
+def test_batch_process_image_to_spots_measured_drift_golden(tmp_path):
+    """The same entry with nothing stored: the drift comes from the phase correlation of the bead channel against a
+    reference bead image (scikit-image in the reference's run), the images are warped with it, spots fitted — stored
+    drift, flags and images identical to the reference's file, tables within the fit tolerance."""
+    import contextlib, io
+    from conftest import batch_inputs, write_dax
+    from imageanalysis3_amd.classes import batch_functions as B
+    from imageanalysis3_amd.io_tools import h5lite as H
+    if not H.available():
+        pytest.skip("libhdf5 not present")
+    gold = load_golden("h5batch.npz")
+    case, size, corr, corr_nowarp, fit = batch_inputs()
+    os.makedirs(str(tmp_path / "H1R1"))
+    movie = str(tmp_path / "H1R1" / "Conv_zscan_05.dax")
+    write_dax(movie, case["raw"])
+    nb, Z = case["nb"], case["Z"]
+    bead = np.ascontiguousarray(case["raw"][nb + (3 - nb) % 4::4][:Z])
+    bead_ref = np.roll(bead, (1, -2), axis=(1, 2))
+    path = str(tmp_path / "fov.hdf5")
+    B.create_fov_save_file(path, 'unique', [5, 2, 9], ['750', '647', '561'], size, max_num_seeds=4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], bead_ref, warp_image=True,
+                                       correction_args=dict(corr), fitting_args=dict(fit), verbose=True)
+    with H.File(path, "r") as f:
+        g = f['unique']
+        assert np.array_equal(g['flags'][...], gold['d_flags'])
+        assert np.allclose(g['drifts'][...], gold['d_drifts'], atol=1e-6), (g['drifts'][...], gold['d_drifts'])
+        crcs = [zlib.crc32(np.ascontiguousarray(g['ims'][i]).tobytes()) & 0xFFFFFFFF for i in range(3)]
+        assert crcs == [int(c) for c in gold['d_ims_crc']], crcs
+        _spot_tables_close(g['spots'][...], gold['d_spots'], 'd_spots')
+        _spot_tables_close(g['raw_spots'][...], gold['d_raw_spots'], 'd_raw_spots')
