@@ -156,6 +156,77 @@ __device__ __forceinline__ double row_sum16(double v) {   // every lane of a row
   return v;
 }
 
+// geom_scalars (ia3_model.h) across the lanes of the wave.  Its ~20 exponentials, ~20 divisions and 2 square roots are
+// independent library sequences of 20-35 dependent instructions each; a wave that owns its SIMD (every fit does: one
+// wave per SIMD) sits through all of them one after the other — 6.5 k cycles of the 38 k an LM iteration takes
+// (scripts/lone_fit.py).  Here every lane takes one of them: stage 1 one exponential per lane, stage 2 one division
+// per lane (operands prepared per kind, results post-processed per kind), stage 3 the reciprocals of the widths and
+// the two cosines; values travel through 64 doubles of LDS.  Each lane performs the operations of the serial code on
+// the same operands, so the scalars are the ones geom_scalars returns.
+__device__ __forceinline__ void geom_scalars_wave(const double* x, const FitCfg& cfg, GeomScalars& q, double* sc) {
+  const int ln = threadIdx.x & 63;
+  const int variant = cfg.variant;
+  const double delta = cfg.delta, min_ws = cfg.min_ws, max_ws = cfg.max_ws;
+  // ---- stage 1: sc[i] = exp(arg_i) ------------------------------------------------------------------------------
+  //  0 tp   1 pp   2-4 w1..3   5-7 centre (variant 1: numerator exp(-a))   8-10 variant 1: exp(-b)
+  //  11-13 -|xp|,-|yp|,-|zp|   14-16 -|w1..3|   17 -|pp|/2   18 -|tp|/2   19 bk   20 clipped bk
+  if (ln < 21) {
+    double arg;
+    if (ln < 2) arg = x[9 - ln];
+    else if (ln < 5) arg = x[3 + ln];
+    else if (ln < 8) arg = variant == 1 ? -x[ln == 5 ? 2 : 3] : x[ln - 3];
+    else if (ln < 11) arg = -x[ln - 6];
+    else if (ln < 14) arg = -fabs(x[ln - 9]);
+    else if (ln < 17) arg = -fabs(x[ln - 9]);
+    else if (ln < 19) arg = -fabs(x[ln - 9]) / 2;          // 17: pp = x[8], 18: tp = x[9]
+    else if (ln == 19) arg = x[0];
+    else { const double bk = x[0]; arg = bk < -709.78 ? -709.78 : (bk > 709.78 ? 709.78 : bk); }
+    sc[ln] = exp(arg);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- stage 2: r = A / B, then the per-kind tail ---------------------------------------------------------------
+  //  0,1 t,p (sig_sine)   2-4 ws (sig_ws)   5-7 centre   8-10 d centre   11-13 norm_w   14 np_   15 nt_
+  if (ln < 16) {
+    double A, B, v = 0.0;
+    const double dws = max_ws - min_ws;
+    if (ln < 2) { v = x[9 - ln]; A = 2.; B = 1. + sc[ln]; }
+    else if (ln < 5) { v = x[3 + ln]; A = dws; B = 1. + sc[ln]; }
+    else if (ln < 8) {
+      if (variant == 1) { A = 2. * delta * sc[ln]; B = 1. + sc[ln + 3]; }
+      else { v = x[ln - 3]; A = 2. * delta; B = 1. + sc[ln]; }
+    }
+    else if (ln < 11) { const double e = sc[ln + 3]; A = -delta * e; B = (1 + e) * (1 + e); }
+    else if (ln < 14) {
+      const double w = x[ln - 6], e = sc[ln + 3];
+      const double d = w > 0 ? max_ws * e + min_ws : min_ws * e + max_ws;
+      A = 0.5 * (max_ws - min_ws) * e; B = d * d;
+    }
+    else { const double e = sc[ln + 3]; A = e; B = 1 + e * e; }
+    double r = A / B;
+    if (ln < 2) { r = r - 1.; if (v >= IA3_LOGMAX) r = -1.; if (v <= -IA3_LOGMAX) r = 1.; }
+    else if (ln < 5) { r = r + min_ws; if (v >= IA3_LOGMAX) r = min_ws; if (v <= -IA3_LOGMAX) r = dws + min_ws; }
+    else if (ln < 8) {
+      const double c0 = cfg.c0[ln - 5];
+      r = r - delta + c0;
+      if (variant != 1) { if (v >= IA3_LOGMAX) r = -delta + c0; if (v <= -IA3_LOGMAX) r = delta + c0; }
+    }
+    sc[32 + ln] = r;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- stage 3: 1 / ws_k (lanes 0-2), cosines (lanes 3, 4) ------------------------------------------------------
+  if (ln < 3) sc[48 + ln] = 1. / sc[34 + ln];
+  else if (ln < 5) { const double u = sc[29 + ln]; const double u2 = u * u; sc[48 + ln] = sqrt(1 - u2); }   // 3: t, 4: p
+  __builtin_amdgcn_wave_barrier();
+  q.t = sc[32]; q.p = sc[33];
+  q.tc = sc[51]; q.pc = sc[52];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { q.s[k] = sc[48 + k]; q.c[k] = sc[37 + k]; q.nc[k] = sc[40 + k]; q.nw[k] = sc[43 + k]; }
+  q.np_ = sc[46]; q.nt_ = sc[47];
+  q.ebk_j = sc[19];
+  q.ebk_f = variant == 1 ? sc[19] : sc[20];
+  __builtin_amdgcn_wave_barrier();   // sc is reused by the next evaluation only after these reads
+}
+
 // Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
 struct BallLds { float dat[SLOTS][64], cz[SLOTS][64], cx[SLOTS][64], cy[SLOTS][64]; };   // [slot][lane]: 8 KB per wave
 
@@ -164,10 +235,15 @@ struct WaveEval {
   // mask (voxel data and the fit configuration are parked in LDS, not in scratch memory)
   const BallLds* b;
   const FitCfg* cfgp;
+  double* gsc;        // 64 doubles of LDS for geom_scalars_wave
   unsigned valid;     // bit s: slot s of this lane holds a voxel
   __device__ double eval(const double* x, double* A, double* g) {
     Geom gm;
-    make_geom(x, *cfgp, gm);
+    {
+      GeomScalars gs;
+      geom_scalars_wave(x, *cfgp, gs, gsc);
+      geom_assemble(x, gs, gm);
+    }
     double a[NTRI], gg[NP], ss = 0.0;
 #pragma unroll
     for (int k = 0; k < NTRI; ++k) a[k] = 0.0;
@@ -280,9 +356,11 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const
   cfg_sh.variant = fa.variant; cfg_sh.iw[0] = fa.iw[0]; cfg_sh.iw[1] = fa.iw[1]; cfg_sh.iw[2] = fa.iw[2];
   __builtin_amdgcn_wave_barrier();
   const FitCfg& cfg = cfg_sh;
+  __shared__ double geom_sc[64];
   WaveEval ev;
   ev.b = &bl;
   ev.cfgp = &cfg_sh;
+  ev.gsc = geom_sc;
   ev.valid = ball.valid;
   double lo10[10], hi10[10];
   wave_extremes(vals, ball.valid, lo10, hi10);

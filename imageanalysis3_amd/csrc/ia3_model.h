@@ -93,17 +93,50 @@ struct Geom {
   double m[5][6];
 };
 
-IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
-  const double bk = x[0], h = x[1], xp = x[2], yp = x[3], zp = x[4];
+// The transcendental part of the geometry: everything that needs an exponential, a division or a square root.
+struct GeomScalars {
+  double t, p, tc, pc;        // sines of the two angles and their cosines
+  double s[3];                // 1 / ws_k
+  double c[3];                // centre
+  double nc[3];               // d centre_k / d (unconstrained centre_k)
+  double nw[3];               // d ws_k / d w_k (norm_w)
+  double np_, nt_;            // derivative factors of the two angle sigmoids
+  double ebk_f, ebk_j;
+};
+
+IA3_HD void geom_scalars(const double* x, const FitCfg& cfg, GeomScalars& q) {
+  const double bk = x[0], xp = x[2], yp = x[3], zp = x[4];
   const double w1 = x[5], w2 = x[6], w3 = x[7], pp = x[8], tp = x[9];
-  const double t = sig_sine(tp), p = sig_sine(pp);
+  q.t = sig_sine(tp); q.p = sig_sine(pp);
   const double ws1 = sig_ws(w1, cfg.min_ws, cfg.max_ws);
   const double ws2 = sig_ws(w2, cfg.min_ws, cfg.max_ws);
   const double ws3 = sig_ws(w3, cfg.min_ws, cfg.max_ws);
-  centers_of(x, cfg, g.c);
+  centers_of(x, cfg, q.c);
+  const double p2 = q.p * q.p, t2 = q.t * q.t, tc2 = 1 - t2, pc2 = 1 - p2;
+  q.tc = sqrt(tc2); q.pc = sqrt(pc2);
+  q.s[0] = 1. / ws1; q.s[1] = 1. / ws2; q.s[2] = 1. / ws3;
+  double bkc = bk < -709.78 ? -709.78 : (bk > 709.78 ? 709.78 : bk);
+  q.ebk_f = cfg.variant == 1 ? exp(bk) : exp(bkc);   // Fitting_v3.py:119 has no clip
+  q.ebk_j = exp(bk);
+  const double d = cfg.delta;
+  const double e_xp = exp(-fabs(xp)), e_yp = exp(-fabs(yp)), e_zp = exp(-fabs(zp));
+  q.nc[0] = -d * e_xp / ((1 + e_xp) * (1 + e_xp));
+  q.nc[1] = -d * e_yp / ((1 + e_yp) * (1 + e_yp));
+  q.nc[2] = -d * e_zp / ((1 + e_zp) * (1 + e_zp));
+  q.nw[0] = norm_w(w1, cfg.min_ws, cfg.max_ws);
+  q.nw[1] = norm_w(w2, cfg.min_ws, cfg.max_ws);
+  q.nw[2] = norm_w(w3, cfg.min_ws, cfg.max_ws);
+  const double e_p = exp(-fabs(pp) / 2), e_t = exp(-fabs(tp) / 2);
+  q.np_ = e_p / (1 + e_p * e_p); q.nt_ = e_t / (1 + e_t * e_t);
+}
+
+// products only: the coefficient tables of f and of the Jacobian columns
+IA3_HD void geom_assemble(const double* x, const GeomScalars& q, Geom& g) {
+  const double h = x[1];
+  const double t = q.t, p = q.p, tc = q.tc, pc = q.pc;
   const double p2 = p * p, t2 = t * t, tc2 = 1 - t2, pc2 = 1 - p2;
-  const double tc = sqrt(tc2), pc = sqrt(pc2);
-  const double s1 = 1. / ws1, s2 = 1. / ws2, s3 = 1. / ws3;
+  const double s1 = q.s[0], s2 = q.s[1], s3 = q.s[2];
+  g.c[0] = q.c[0]; g.c[1] = q.c[1]; g.c[2] = q.c[2];
   const double x2c = pc2 * tc2 * s1 + t2 * s2 + p2 * tc2 * s3;
   const double y2c = pc2 * t2 * s1 + tc2 * s2 + p2 * t2 * s3;
   const double z2c = p2 * s1 + pc2 * s3;
@@ -112,20 +145,13 @@ IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
   const double yzc = 2 * p * pc * t * (s3 - s1);
   g.q[0] = x2c; g.q[1] = y2c; g.q[2] = z2c; g.q[3] = xyc; g.q[4] = xzc; g.q[5] = yzc;
   g.h = h;
-  double bkc = bk < -709.78 ? -709.78 : (bk > 709.78 ? 709.78 : bk);
-  g.ebk_f = cfg.variant == 1 ? exp(bk) : exp(bkc);   // Fitting_v3.py:119 has no clip
-  g.ebk_j = exp(bk);
-  const double d = cfg.delta;
-  const double e_xp = exp(-fabs(xp)), e_yp = exp(-fabs(yp)), e_zp = exp(-fabs(zp));
-  const double nxp = -d * e_xp / ((1 + e_xp) * (1 + e_xp));
-  const double nyp = -d * e_yp / ((1 + e_yp) * (1 + e_yp));
-  const double nzp = -d * e_zp / ((1 + e_zp) * (1 + e_zp));
+  g.ebk_f = q.ebk_f;
+  g.ebk_j = q.ebk_j;
+  const double nxp = q.nc[0], nyp = q.nc[1], nzp = q.nc[2];
   g.l[0][0] = 2 * x2c * nxp; g.l[0][1] = xyc * nxp;     g.l[0][2] = xzc * nxp;
   g.l[1][0] = xyc * nyp;     g.l[1][1] = 2 * y2c * nyp; g.l[1][2] = yzc * nyp;
   g.l[2][0] = xzc * nzp;     g.l[2][1] = yzc * nzp;     g.l[2][2] = 2 * z2c * nzp;
-  const double nw1 = norm_w(w1, cfg.min_ws, cfg.max_ws);
-  const double nw2 = norm_w(w2, cfg.min_ws, cfg.max_ws);
-  const double nw3 = norm_w(w3, cfg.min_ws, cfg.max_ws);
+  const double nw1 = q.nw[0], nw2 = q.nw[1], nw3 = q.nw[2];
   // order of the 6 monomials: xt², xt·yt, yt², xt·zt, yt·zt, zt²
   g.m[0][0] = -pc2 * tc2 * nw1;       g.m[0][1] = -2 * pc2 * t * tc * nw1; g.m[0][2] = -pc2 * t2 * nw1;
   g.m[0][3] = 2 * p * pc * tc * nw1;  g.m[0][4] = 2 * p * pc * t * nw1;    g.m[0][5] = -p2 * nw1;
@@ -133,14 +159,19 @@ IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
   g.m[1][3] = 0;                      g.m[1][4] = 0;                       g.m[1][5] = 0;
   g.m[2][0] = -p2 * tc2 * nw3;        g.m[2][1] = -2 * p2 * t * tc * nw3;  g.m[2][2] = -p2 * t2 * nw3;
   g.m[2][3] = -2 * p * pc * tc * nw3; g.m[2][4] = -2 * p * pc * t * nw3;   g.m[2][5] = -pc2 * nw3;
-  const double e_p = exp(-fabs(pp) / 2), e_t = exp(-fabs(tp) / 2);
-  const double np_ = e_p / (1 + e_p * e_p), nt_ = e_t / (1 + e_t * e_t);
+  const double np_ = q.np_, nt_ = q.nt_;
   const double a9 = (s3 - s1) * np_, b9 = 2 * pc2 - 1., ppc = p * pc;
   g.m[3][0] = a9 * ppc * tc2;         g.m[3][1] = a9 * ppc * 2 * t * tc;   g.m[3][2] = a9 * ppc * t2;
   g.m[3][3] = a9 * b9 * tc;           g.m[3][4] = a9 * b9 * t;             g.m[3][5] = -a9 * ppc;
   const double a10 = (pc2 * s1 - s2 + p2 * s3) * nt_, b10 = ppc * (s1 - s3) * nt_;
   g.m[4][0] = -a10 * t * tc;          g.m[4][1] = -a10 * (t2 - tc2);       g.m[4][2] = a10 * t * tc;
   g.m[4][3] = b10 * t;                g.m[4][4] = -b10 * tc;               g.m[4][5] = 0;
+}
+
+IA3_HD void make_geom(const double* x, const FitCfg& cfg, Geom& g) {
+  GeomScalars q;
+  geom_scalars(x, cfg, q);
+  geom_assemble(x, q, g);
 }
 
 // signal part f0 = exp(h - xᵀAx/2) at a voxel (coordinates are exact small integers)
