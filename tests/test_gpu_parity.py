@@ -922,6 +922,13 @@ def test_batch_process_image_to_spots_golden(tag, warp, tmp_path):
                                                  overwrite_spot=True, verbose=warp, return_spots=True)
         check(tag + "over_")
     assert len(sp) == 2 and all(len(s) <= 3 for s in sp)
+    # the channels of a movie fitted one after the other or by inner threads: same tables
+    one = B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], ref_im, warp_image=warp, save_spots=False,
+                                         correction_args=dict(cargs), fitting_args=dict(fit), return_spots=True, fit_workers=1)
+    two = B.batch_process_image_to_spots(movie, ['750', '647'], path, 'unique', [5, 2], ref_im, warp_image=warp, save_spots=False,
+                                         correction_args=dict(cargs), fitting_args=dict(fit), return_spots=True, fit_workers=2)
+    for a, b in zip(one[0] + one[1], two[0] + two[1]):
+        assert np.array_equal(a, b)
     # argument checks of the reference (:92-118)
     with pytest.raises(IOError):
         B.batch_process_image_to_spots(movie[:-4] + ".tif", ['750'], path, 'unique', [5], ref_im)
