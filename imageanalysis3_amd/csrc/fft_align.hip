@@ -337,6 +337,66 @@ __global__ __launch_bounds__(256) void dft_contract_k(const cplx* __restrict__ K
       if (m0 + tm + 16 * q < M) out[(size_t)(r0 + tr) * M + m0 + tm + 16 * q] = acc[q];
 }
 
+int g_dft_valu = 0;   // IA3_TUNE_DFT_VALU: 1 = the vector-unit contraction (tests compare the two)
+
+// The same contraction on the matrix cores: out[r][m] = sum_n K[r][n] * in[m][n] is a complex (R x N) x (N x M) product
+// — 15.7 Gflop for the first axis of a 50 x 512 x 512 crop — and the LDS-tiled kernel above spends five 16-byte LDS
+// reads on every four complex multiply-adds.  v_mfma_f64_16x16x4_f64 takes one float64 of A and of B per lane
+// (A[lane & 15][k = lane >> 4], B[k][lane & 15]) and leaves D[row = (lane >> 4) + 4 v][col = lane & 15] in four
+// registers; a complex tile needs four real products (Kr Dr, Ki Di, Kr Di, Ki Dr).  A wave owns 16 rows r and 64
+// columns m (four 16 x 16 tiles, 128 accumulator registers).  The sum over n does not care about order, so k slot
+// q = lane >> 4 is given the run n0 + 8 q .. n0 + 8 q + 7 of a 32-sample chunk: every lane then reads whole 128-byte
+// lines of K and of `in` straight from global memory (eight complex values each), no LDS, and eight MFMA steps consume
+// them.  Float64 accumulation in the matrix unit: the upsampled peak search is as accurate as with the vector kernel.
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dft_contract_mfma_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
+                                                           cplx* __restrict__ out, int R, int M, int N) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int r0 = blockIdx.y * 16, m0 = (blockIdx.x * 4 + wv) * 64;
+  if (m0 >= M) return;                                  // whole wave
+  const int rr = r0 + li < R ? r0 + li : R - 1;         // rows past the end repeat the last one and are not stored
+  const cplx* krow = K + (size_t)rr * N;
+  const cplx* drow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int mm = m0 + 16 * t + li;
+    drow[t] = in + (size_t)(mm < M ? mm : M - 1) * N;
+  }
+  v4d acc_rr[4], acc_ii[4], acc_ri[4], acc_ir[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { acc_rr[t] = v4d{0, 0, 0, 0}; acc_ii[t] = acc_rr[t]; acc_ri[t] = acc_rr[t]; acc_ir[t] = acc_rr[t]; }
+  for (int n0 = 0; n0 < N; n0 += 32) {
+    const int nb = n0 + 8 * kq;                          // this lane's run of eight samples
+    cplx kv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) kv[s] = nb + s < N ? krow[nb + s] : cplx{0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      cplx dv[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) dv[s] = nb + s < N ? drow[t][nb + s] : cplx{0, 0};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc_rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[s].x, acc_rr[t], 0, 0, 0);
+        acc_ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[s].y, acc_ii[t], 0, 0, 0);
+        acc_ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[s].y, acc_ri[t], 0, 0, 0);
+        acc_ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[s].x, acc_ir[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[row = kq + 4 v][col = li]: row -> r, col -> m
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int mm = m0 + 16 * t + li;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = r0 + kq + 4 * v;
+      if (r < R && mm < M) out[(size_t)r * M + mm] = cplx{acc_rr[t][v] - acc_ii[t][v], acc_ri[t][v] + acc_ir[t][v]};
+    }
+  }
+}
+
 int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
   hipStream_t st = stream();
   const int nb = 512;
@@ -355,6 +415,8 @@ int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
 }
 
 }  // namespace
+
+namespace ia3k { void set_dft_valu(int on) { g_dft_valu = on != 0; } }
 
 extern "C" {
 
@@ -491,7 +553,10 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     if (!K.p || !t1.p || !t2.p || !t3.p) return IA3_ENOMEM;
     auto contract = [&](const cplx* in, cplx* out, int M, int N, double o) {
       hipLaunchKernelGGL(dft_kernel_k, dim3((N + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, N, o, u);
-      hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
+      if (g_dft_valu)
+        hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
+      else
+        hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
     };
     contract(fa.as<cplx>(), t1.as<cplx>(), Z * X, Y, off[2]);   // (R_y, Z, X)
     contract(t1.as<cplx>(), t2.as<cplx>(), R * Z, X, off[1]);   // (R_x, R_y, Z)

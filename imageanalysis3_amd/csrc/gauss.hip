@@ -630,6 +630,7 @@ int ia3_set_tuning(int key, int value) {
     g_cert = value;
     return 0;
   }
+  if (key == IA3_TUNE_DFT_VALU) { ia3k::set_dft_valu(value); return 0; }
   return set_error(IA3_EINVAL, "unknown tuning key");
 }
 

@@ -79,6 +79,7 @@ void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& r
 }  // namespace ia3rt
 
 // ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
+namespace ia3k { void set_dft_valu(int on); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
 namespace ia3k {
 // separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.
 int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w, int radius, int mode,

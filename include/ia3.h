@@ -53,6 +53,9 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * certified fused-multiply-add path of the long Gaussian passes; -2 default (4R+8), -1 path off (always the
  * reference operation sequence), large values send every output through the reference sequence after the check. */
 #define IA3_TUNE_GAUSS_CERT 1
+/* IA3_TUNE_DFT_VALU: 1 = the upsampled-DFT contractions of the phase correlation run on the vector unit (first
+ * version) instead of the f64 matrix cores; shifts agree to rounding. */
+#define IA3_TUNE_DFT_VALU 2
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

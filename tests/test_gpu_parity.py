@@ -1206,3 +1206,27 @@ def test_batch_process_image_to_spots_measured_drift_golden(tmp_path):
         assert crcs == [int(c) for c in gold['d_ims_crc']], crcs
         _spot_tables_close(g['spots'][...], gold['d_spots'], 'd_spots')
         _spot_tables_close(g['raw_spots'][...], gold['d_raw_spots'], 'd_raw_spots')
+
+
+def test_upsampled_dft_on_matrix_cores_equals_vector_unit():
+    """The three contractions of the upsampled DFT (skimage's _upsampled_dft) run as v_mfma_f64 tiles; the first
+    version on the vector unit is kept behind IA3_TUNE_DFT_VALU: same shifts, error and phase to rounding, on crops
+    whose sizes are not multiples of the tiles."""
+    import ctypes as C
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.correction_tools import alignment
+    out = {}
+    cases = []
+    for shape, nb, d in (((20, 96, 96), 20, (0.7, -3.25, 5.5)), ((13, 70, 121), 12, (-1.31, 2.77, -0.46))):
+        ref, src, _, _ = synth.make_bead_pair(shape, nb, 3, np.array(d), margin=(3, 10, 10), min_sep=10.0)
+        cases += [(ref, src), (ref.astype(np.uint16), src.astype(np.uint16))]
+    try:
+        for valu in (0, 1):
+            L.check(L.lib().ia3_set_tuning(C.c_int(2), C.c_int(valu)))
+            out[valu] = [alignment.phase_cross_correlation(a, b, upsample_factor=up, normalization=nm)
+                         for a, b in cases for up in (10, 100) for nm in (None, "phase")]
+    finally:
+        L.check(L.lib().ia3_set_tuning(C.c_int(2), C.c_int(0)))
+    for (s0, e0, p0), (s1, e1, p1) in zip(out[0], out[1]):
+        assert np.array_equal(s0, s1), (s0, s1)
+        assert abs(e0 - e1) <= 1e-9 and abs(p0 - p1) <= 1e-9
