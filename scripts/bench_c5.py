@@ -76,4 +76,5 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("C5_TMP", "/tmp")) as td:
     run("warmup", 1, False, 1)   # every variant must report the same number of rows per movie
     run("seq_nosave", 1, False, N_MOVIES)
     run("thr4_nosave", 4, False, N_MOVIES)
+    run("thr8_nosave", 8, False, N_MOVIES)
     run("thr4_save", 4, True, N_MOVIES)
