@@ -86,6 +86,7 @@ struct Chol {        // A + par D² = LᵀL, L upper; transient (registers)
 // last bit of every step anyway — take 8-15 % less time.
 IA3_HD double lm_rsqrt(double s) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  // (safe for every normal s: y <= 6.7e153, s * y = sqrt(s); lm_factor does not pass subnormal pivots)
   double y = __builtin_amdgcn_rsq(s);
   double e = __builtin_fma(-(s * y), y, 1.0);
   y = __builtin_fma(0.5 * y, e, y);
@@ -108,7 +109,7 @@ IA3_HD void lm_factor(const double* A, const double* diag, double par, Chol& c) 
       IA3_UNROLL
       for (int k = 0; k < i; ++k) s -= c.L[tri(k, i)] * c.L[tri(k, j)];
       if (i == j) {
-        if (s > 0.0) c.L[tri(j, j)] = lm_rsqrt(s);
+        if (s >= IA3_DWARF) c.L[tri(j, j)] = lm_rsqrt(s);   // a subnormal pivot is a vanished column, like s <= 0
         else { c.L[tri(j, j)] = 0.0; c.skip |= 1u << j; }
       } else {
         c.L[tri(i, j)] = s * c.L[tri(i, i)];
