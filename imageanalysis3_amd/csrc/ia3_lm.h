@@ -19,7 +19,9 @@
 // Every loop has compile-time bounds (NP = 10) and is fully unrolled, so on the GPU all matrix
 // and vector accesses are statically indexed: the persistent state (LMWork, in LDS) is read with
 // immediate offsets and the per-call temporaries (Cholesky factor, work vectors) live in
-// registers.  The factor stores reciprocal diagonals, so a factorisation costs 10 divisions.
+// registers.  The factor stores reciprocal diagonals: ten reciprocal square roots per factorisation (lm_rsqrt: the
+// hardware estimate plus two Newton steps on the device, 1 / sqrt on the host — the only place where the two builds
+// differ, by about an ulp).
 //
 // Host/device agnostic. `Eval` supplies:  double eval(const double* x, double* A, double* g)
 // which returns |f(x)| and fills the packed upper triangle of JᵀJ (row-major, NTRI entries) and
