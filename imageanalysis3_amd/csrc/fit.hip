@@ -163,7 +163,11 @@ __device__ __forceinline__ double row_sum16(double v) {   // every lane of a row
 // per lane (operands prepared per kind, results post-processed per kind), stage 3 the reciprocals of the widths and
 // the two cosines; values travel through 64 doubles of LDS.  Each lane performs the operations of the serial code on
 // the same operands, so the scalars are the ones geom_scalars returns.
-__device__ __forceinline__ void geom_scalars_wave(const double* x, const FitCfg& cfg, GeomScalars& q, double* sc) {
+#define IA3_LDS __attribute__((address_space(3)))
+// (x, cfg and sc live in LDS: typed pointers make these ds_read / ds_write instead of flat accesses, which the
+// not-inlined evaluation would otherwise get because its pointers travel through memory)
+__device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const IA3_LDS FitCfg& cfg, GeomScalars& q,
+                                                  IA3_LDS double* sc) {
   const int ln = threadIdx.x & 63;
   const int variant = cfg.variant;
   const double delta = cfg.delta, min_ws = cfg.min_ws, max_ws = cfg.max_ws;
@@ -239,10 +243,12 @@ struct WaveEval {
   unsigned valid;     // bit s: slot s of this lane holds a voxel
   __device__ double eval(const double* x, double* A, double* g) {
     Geom gm;
+    const IA3_LDS BallLds* bl = (const IA3_LDS BallLds*)b;   // everything the evaluation touches is in LDS
     {
       GeomScalars gs;
-      geom_scalars_wave(x, *cfgp, gs, gsc);
-      geom_assemble(x, gs, gm);
+      geom_scalars_wave((const IA3_LDS double*)x, *(const IA3_LDS FitCfg*)cfgp, gs, (IA3_LDS double*)gsc);
+      const double xh[2] = {0.0, ((const IA3_LDS double*)x)[1]};
+      geom_assemble(xh, gs, gm);
     }
     double a[NTRI], gg[NP], ss = 0.0;
 #pragma unroll
@@ -256,8 +262,8 @@ struct WaveEval {
       if (valid & (1u << s)) {
         const int ln = threadIdx.x & 63;
         double J[NP];
-        double F = model_jac(gm, (double)b->cz[s][ln], (double)b->cx[s][ln], (double)b->cy[s][ln], J);
-        double r = (gm.ebk_f + F) - (double)b->dat[s][ln];
+        double F = model_jac(gm, (double)bl->cz[s][ln], (double)bl->cx[s][ln], (double)bl->cy[s][ln], J);
+        double r = (gm.ebk_f + F) - (double)bl->dat[s][ln];
         r_nan = r != r;
         r_inf = !r_nan && (r - r != 0.0);
         ss += r * r;
@@ -291,8 +297,8 @@ struct WaveEval {
         const double tot = row_sum16(swap16_add(p1[2 * n], p1[2 * n + 1]));
         const int vi = 4 * n + sel;
         if ((lane & 15) == 0) {
-          if (vi < NTRI) A[vi] = tot;
-          else if (vi < NV) g[vi - NTRI] = tot;
+          if (vi < NTRI) ((IA3_LDS double*)A)[vi] = tot;
+          else if (vi < NV) ((IA3_LDS double*)g)[vi - NTRI] = tot;
         }
       }
       __builtin_amdgcn_wave_barrier();   // A, g live in LDS: later reads by every lane follow these writes in order
