@@ -109,16 +109,20 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
   // The window is a ring of W = K + 2R registers.  When K divides W the chunk loop is unrolled W/K times and the
   // ring is indexed with compile-time offsets, so sliding costs nothing; otherwise (ROT = 1) the window is shifted
   // with 2R register moves per chunk.
-  constexpr int W = K + 2 * R;
-  constexpr int U = (W % K == 0) ? W / K : 1;   // chunks per unrolled body
+  constexpr int W0 = K + 2 * R;                                    // samples a chunk needs
+  constexpr bool RING = (W0 % K == 0) || FAST;                     // long filters: pad the ring to a multiple of K
+  constexpr int W = RING ? ((W0 + K - 1) / K) * K : W0;            // (spare slots take the prefetched inputs)
+  constexpr int U = RING ? W / K : 1;   // chunks per unrolled body
   double win[W];
   unsigned sbits = 0;   // OR of the raw inputs this thread has loaded: bit 31 set = a negative (or -0, nan) was seen
 #pragma unroll
-  for (int i = 0; i < W; ++i) {
+  for (int i = 0; i < W0; ++i) {
     const T v = in[base + (size_t)bmap[q_begin + i] * stride];
     if constexpr (FAST) sbits |= sign_of<T>(v);
     win[i] = (double)v;
   }
+#pragma unroll
+  for (int i = W0; i < W; ++i) win[i] = 0.0;
   for (int qq = q_begin; qq < q_end; qq += K * U) {
     // the U chunks of one turn of the ring, expanded at compile time (static_for_until: stops at the segment end)
     auto chunk = [&](auto cc) -> bool {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
         for (int i = 0; i < K; ++i) win[2 * R + i] = (double)nxt[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < K; ++i) win[(o + i) % W] = (double)nxt[i];   // the K oldest slots take the new inputs
+        for (int i = 0; i < K; ++i) win[(o + W0 + i) % W] = (double)nxt[i];   // spare slots first, then the oldest ones
       }
       return true;
     };
