@@ -664,38 +664,35 @@ class DaxProcesser():
         from ..segmentation_tools.cell import segmentation_mask_2_bounding_box
         from ..spot_tools.fitting import fit_fov_image
         from .partition_spots import Spots_Partition
-        _drift = getattr(self, 'drift', np.zeros(len(self.image_size)))
+        drift = getattr(self, 'drift', np.zeros(len(self.image_size)))
         if self.verbose:
             print(f"- Start fitting spots in each segmentation")
-        _cell_ids = np.unique(seg_label)
-        _cell_ids = _cell_ids[_cell_ids > 0]
-        _stack = self._dev[str(channel)]
-        _all_spots, _all_cell_ids = [], []
-        for _cell_id in _cell_ids:
-            _cell_mask = (seg_label == _cell_id)
-            _crop = segmentation_mask_2_bounding_box(_cell_mask, 3)   # sic (:1117): 3 lands in cell_id, margin stays 1
-            _drift_crop = _crop.translate_drift(drift=_drift)
-            _local = _stack.crop(_drift_crop.array)
+        stack = self._dev[str(channel)]
+        labels = np.unique(seg_label)
+        tables, owners = [], []
+        for label in labels[labels > 0]:
+            mask = seg_label == label
+            # the reference calls segmentation_mask_2_bounding_box(mask, 3): the 3 lands in `cell_id` (:1117), the margin
+            # stays at its default of one voxel
+            box = segmentation_mask_2_bounding_box(mask, 3).translate_drift(drift=drift)
+            crop = stack.crop(box.array)
             try:
-                _spots = fit_fov_image(_local, str(channel), th_seed=th_seed, max_num_seeds=num_spots,
-                                       verbose=verbose, **fitting_kwargs)
+                rows = fit_fov_image(crop, str(channel), th_seed=th_seed, max_num_seeds=num_spots, verbose=verbose,
+                                     **fitting_kwargs)
             finally:
-                _local.free()
-            if len(_spots) > 0:
-                _spots = Spots3D(_spots)
-                _spots[:, _spots.coordinate_indices] = _spots[:, _spots.coordinate_indices] + _drift_crop.array[:, 0]
-                _kept_flg = Spots_Partition.spots_to_labels(_cell_mask, _spots, search_radius=segment_search_radius,
-                                                            verbose=False)
-                _spots = _spots[_kept_flg > 0]
-                if len(_spots) > 0:
-                    _all_spots.append(_spots)
-                    _all_cell_ids.append(np.ones(len(_spots), dtype=np.int32) * _cell_id)
-        if len(_all_spots) > 0:
-            _all_spots = np.concatenate(_all_spots)
-            _all_cell_ids = np.concatenate(_all_cell_ids)
+                crop.free()
+            if len(rows) == 0:
+                continue
+            rows = Spots3D(rows)
+            rows[:, rows.coordinate_indices] = rows[:, rows.coordinate_indices] + box.array[:, 0]   # back to FOV coordinates
+            inside = Spots_Partition.spots_to_labels(mask, rows, search_radius=segment_search_radius, verbose=False) > 0
+            if inside.any():
+                tables.append(rows[inside])
+                owners.append(np.full(int(inside.sum()), label, dtype=np.int32))
+        if tables:
+            _all_spots, _all_cell_ids = np.concatenate(tables), np.concatenate(owners)
         else:
-            _all_spots = np.array([])
-            _all_cell_ids = np.array([])
+            _all_spots, _all_cell_ids = np.array([]), np.array([])
             print(f"No spots detected.")
         if save_attrs:
             setattr(self, f"spots_{channel}", _all_spots)
