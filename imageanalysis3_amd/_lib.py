@@ -27,7 +27,8 @@ EXPORTS = [
     "ia3_z_shift_correction_dev", "ia3_illumination_correct_dev", "ia3_bleedthrough_correct_dev",
     "ia3_illumination_rescale_dev", "ia3_bleedthrough_rescale_dev",
     "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_run", "ia3_fit_results", "ia3_fit_results_ex", "ia3_fit_nfev", "ia3_fit_stats",
-    "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_gaussfit_voxels",
+    "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_fit_fov_stats", "ia3_fit_fovs",
+    "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
     "ia3_stack_crop", "ia3_warp3d", "ia3_warp3d_dev",
 ]
@@ -54,6 +55,12 @@ class FitParams(C.Structure):
                 ("n_max_iter", C.c_int), ("max_dist_th", C.c_double), ("min_w", C.c_double),
                 ("max_w", C.c_double), ("init_w", C.c_double),
                 ("model_variant", C.c_int), ("init_w_zxy", C.c_double * 3)]
+
+
+class FovJob(C.Structure):
+    _fields_ = [("host", C.c_void_p), ("dev", C.c_void_p), ("rows", C.c_void_p), ("capacity", C.c_int),
+                ("n_rows", C.c_int), ("n_seeds", C.c_int), ("n_iter", C.c_int), ("rc", C.c_int),
+                ("fits", C.c_longlong), ("nfev", C.c_longlong), ("voxel_evals", C.c_longlong)]
 
 
 _lib = None
@@ -279,3 +286,38 @@ def make_fit_params(radius_fit=5, min_delta_center=1., max_delta_center=2.5, n_m
     p.max_dist_th = float(max_dist_th)
     p.min_w, p.max_w, p.init_w = float(min_w), float(max_w), float(init_w)
     return p
+
+
+def fit_fovs(ims, seed_params, fit_params, in_flight=4, capacity=16384):
+    """``ia3_fit_fovs`` on a list of same-shape, same-dtype images (ndarrays and/or resident ``DeviceStack``s):
+    list of (M,11) float32 tables in input order + per-image dicts (n_seeds, n_iter, fits, nfev, voxel_evals).
+    One C call; uploads, filters and fits of different images overlap on library-owned threads and streams."""
+    ims = list(ims)
+    if not ims:
+        return [], []
+    arrs = [im if isinstance(im, DeviceStack) else as_stack_array(im) for im in ims]
+    shape, dt = tuple(arrs[0].shape), np.dtype(arrs[0].dtype)
+    for a in arrs:
+        if tuple(a.shape) != shape or np.dtype(a.dtype) != dt:
+            raise ValueError("fit_fovs: every image of a batch must have the same shape and dtype")
+    code = IA3_F32 if dt == np.float32 else IA3_U16
+    n = len(arrs)
+    while True:
+        jobs = (FovJob * n)()
+        rows = [np.empty((capacity, 11), dtype=np.float32) for _ in range(n)]
+        for j, a, r in zip(jobs, arrs, rows):
+            if isinstance(a, DeviceStack):
+                j.dev = a._h
+            else:
+                j.host = a.ctypes.data
+            j.rows, j.capacity = r.ctypes.data, capacity
+        rc = lib().ia3_fit_fovs(jobs, n, code, shape[0], shape[1], shape[2], C.byref(seed_params), C.byref(fit_params),
+                                int(in_flight))
+        if rc == IA3_ECAPACITY:
+            capacity = max(j.n_rows for j in jobs)
+            continue
+        check(rc)
+        break
+    tables = [r[:j.n_rows].copy() for j, r in zip(jobs, rows)]
+    info = [dict(n_seeds=j.n_seeds, n_iter=j.n_iter, fits=j.fits, nfev=j.nfev, voxel_evals=j.voxel_evals) for j in jobs]
+    return tables, info

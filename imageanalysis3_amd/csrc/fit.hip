@@ -37,7 +37,7 @@ using namespace ia3;
 namespace {
 
 constexpr int SLOTS = 8;  // voxel slots per lane
-constexpr int MAXNB = 64; // neighbour slots per seed (seeds within 2r; more than this is reported as an error)
+constexpr int MAXNB = 64; // neighbour slots per seed (seeds within 2r); denser seeds re-scan the seed list instead
 constexpr int MAXBALL = 64 * SLOTS;
 
 struct SeedState {
@@ -52,8 +52,10 @@ struct SeedState {
 struct FitArgs {
   const void* im; int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
-  const int* nbr_cnt;       // n: number of neighbours of seed i (clamped to MAXNB)
-  const int* nbr_idx;       // n x MAXNB: seeds j != i with |c_i - c_j|² <= (2r)², ascending
+  int n;                    // number of seeds
+  double nb_r2;             // (2r)²: seeds closer than this interact
+  const int* nbr_cnt;       // n: number of neighbours of seed i (NOT clamped: > MAXNB = list overflow, see each_neighbour)
+  const int* nbr_idx;       // n x MAXNB: the first MAXNB seeds j != i with |c_i - c_j|² <= (2r)², ascending
   const signed char* ball;  // nball x 4 (dz,dx,dy,0), np.indices order
   int nball, radius;
   SeedState* state;
@@ -62,7 +64,7 @@ struct FitArgs {
   int* nfev;                // n (accumulated function evaluations)
   unsigned char* conv;      // n
   int* n_iter;              // max sweeps over components
-  unsigned long long* counters;  // [0] fits run, [1] function evaluations
+  unsigned long long* counters;  // [0] fits run, [1] function evaluations, [2] voxel evaluations (sum of nfev x voxels)
   double min_ws, max_ws, init_w, delta_first, delta_repeat, dist_th2;
   int n_max_iter;
   double ftol, xtol, gtol; int maxfev; double factor;
@@ -401,6 +403,7 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, const flo
       for (int k = 0; k < 11; ++k) st_sc1(&fa.ps[(size_t)i * 11 + k], p[k]);
       atomicAdd(&fa.counters[0], 1ull);
       atomicAdd(&fa.counters[1], (unsigned long long)nfev);
+      atomicAdd(&fa.counters[2], (unsigned long long)nfev * (unsigned long long)n);
     }
   }
 }
@@ -430,8 +433,37 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
     c += __popcll(m);
   }
   if (lane == 0) {
-    if (c > MAXNB) { atomicMax(overflow, c); c = MAXNB; }
+    if (c > MAXNB) atomicMax(overflow, c);   // statistics only: consumers fall back to each_neighbour's scan
     cnt[i] = c;
+  }
+}
+
+// f(j) for every seed j != i within 2r of seed i, ascending j, wave-uniform.  Seeds with at most MAXNB neighbours read
+// their list; denser ones (the reference has no cap: Fitting_v4.py:601,612 query a cKDTree) scan the whole seed list,
+// 64 candidates per step with a ballot.  f returns false to stop early.
+template <class F>
+__device__ __forceinline__ void each_neighbour(const FitArgs& fa, int i, F f) {
+  const int cnt = fa.nbr_cnt[i];
+  if (cnt <= MAXNB) {
+    for (int q = i * MAXNB; q < i * MAXNB + cnt; ++q)
+      if (!f(fa.nbr_idx[q])) return;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const double cz = fa.seeds[3 * i], cx = fa.seeds[3 * i + 1], cy = fa.seeds[3 * i + 2];
+  for (int j0 = 0; j0 < fa.n; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < fa.n && j != i) {
+      const double a = cz - fa.seeds[3 * j], b = cx - fa.seeds[3 * j + 1], d = cy - fa.seeds[3 * j + 2];
+      hit = a * a + b * b + d * d <= fa.nb_r2;
+    }
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (!f(j0 + b)) return;
+    }
   }
 }
 
@@ -440,17 +472,37 @@ __device__ __forceinline__ void do_first(const FitArgs& fa, LMWork& w, int i) {
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
-  const int nb0 = i * MAXNB, nb1 = nb0 + fa.nbr_cnt[i];
+  const int ncnt = fa.nbr_cnt[i];
+  const int nb0 = i * MAXNB, nb1 = nb0 + (ncnt <= MAXNB ? ncnt : 0);
   Ball ball;
   double vals[SLOTS];
   ball.valid = 0;
+  unsigned lost = 0;   // list overflow only: bit s = slot s belongs to another seed's Voronoi cell
+  if (ncnt > MAXNB) {
+    each_neighbour(fa, i, [&](int j) {
+      const double sz = fa.seeds[3 * j], sx = fa.seeds[3 * j + 1], sy = fa.seeds[3 * j + 2];
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int vi = lane + 64 * s;
+        if (vi < fa.nball) {
+          const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
+          const double dz = z - c0[0], dx = x - c0[1], dy = y - c0[2];
+          const double dme = dz * dz + dx * dx + dy * dy;
+          const double ez = z - sz, ex = x - sx, ey = y - sy;
+          const double dj = ez * ez + ex * ex + ey * ey;
+          if (dj < dme || (dj == dme && j < i)) lost |= 1u << s;
+        }
+      }
+      return true;
+    });
+  }
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int vi = lane + 64 * s;
     ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
     if (vi < fa.nball) {
       const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
-      bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y;
+      bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y && !(lost & (1u << s));
       if (ok) {
         // Voronoi (:612, :422-424): drop the voxel if another seed is strictly nearer, or equally
         // near with a lower index (the reference's cKDTree leaves exact ties to its tree layout).
@@ -502,10 +554,9 @@ __device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
     }
   }
   // subtract the current reconstructions of the overlapping seeds (= im_add + own rec, :658-662)
-  for (int q = i * MAXNB; q < i * MAXNB + fa.nbr_cnt[i]; ++q) {
-    const int j = fa.nbr_idx[q];
+  each_neighbour(fa, i, [&](int j) {
     const SeedState& sj = fa.state[j];
-    if (!LDH(&sj.has_rec)) continue;
+    if (!LDH(&sj.has_rec)) return true;
     FitCfg cj;
     cj.min_ws = fa.min_ws; cj.max_ws = fa.max_ws; cj.delta = LDH(&sj.delta); cj.init_w = fa.init_w;
     cj.variant = fa.variant;
@@ -524,7 +575,8 @@ __device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
           vals[s] -= model_f0(gj, (double)ball.cz[s], (double)ball.cx[s], (double)ball.cy[s]);
       }
     }
-  }
+    return true;
+  });
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) ball.dat[s] = (float)vals[s];
   const int n = (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
@@ -617,10 +669,9 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
   if (!wait_done(done, i, k, ctl)) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return; }   // converged: skipped (:652)
-  for (int q = i * MAXNB; q < i * MAXNB + fa.nbr_cnt[i]; ++q) {
-    const int j = fa.nbr_idx[q];
-    if (!wait_done(done, j, j < i ? k + 1 : k, ctl)) return;
-  }
+  bool alive = true;
+  each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
+  if (!alive) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const bool cv = do_repeat(fa, w, i);
   if (lane == 0) {
@@ -705,6 +756,7 @@ struct ia3_fitter {
       *d_counters, *d_done, *d_ctl, *d_nbr_overflow;
   bool first_done;
   StageCtl host_ctl;
+  unsigned long long host_counters[3];   // copy of d_counters as of the last ia3_fit_results(_ex)
   std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
 };
 
@@ -722,6 +774,7 @@ int build_ball(int r, std::vector<signed char>& ball) {
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
+  a.n = f->n; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
@@ -790,10 +843,10 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   f->d_nvox = base + o; o += b_nvox;
   f->d_nfev = base + o; o += b_nfev;
   f->d_conv = base + o; o += b_conv;
-  f->d_counters = base + o; o += b_cnt;
   f->d_done = base + o; o += b_done;
-  // [n_iter | stage control | overflow flag | rows]: contiguous, so the results come back in ONE device-to-host
-  // copy (every separate copy into pageable memory costs a ~25 us round trip)
+  // [counters | n_iter | stage control | overflow flag | rows]: contiguous, so the results come back in ONE
+  // device-to-host copy (every separate copy into pageable memory costs a ~25 us round trip)
+  f->d_counters = base + o; o += b_cnt;
   f->d_niter = base + o; o += b_niter;
   f->d_ctl = base + o; o += b_ctl;
   f->d_nbr_overflow = base + o; o += b_ovf;
@@ -833,6 +886,9 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 }  // extern "C"
 
 namespace ia3k {
+void fit_host_counters(const ia3_fitter* f, long long out[3]) {
+  for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
+}
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out) {
   return fit_create_impl(im, nullptr, d_centers_zxy, n, p, out);
 }
@@ -932,25 +988,26 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
   StageCtl hc = StageCtl{0u, 0, 0, 0};
   int ovf = 0;
   if (f->n > 0) {
-    // one copy: the three 256-byte control slots and the row table sit back to back in the pool
-    const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_niter);
+    // one copy: the four 256-byte control slots and the row table sit back to back in the pool
+    const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_counters);
     const size_t rows = ps ? sizeof(float) * 11 * (size_t)f->n : 0;
     std::vector<char>& hb = f->host_stage;
     hb.resize(head + rows);
-    IA3_HIP(hipMemcpyAsync(hb.data(), f->d_niter, head + rows, hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipMemcpyAsync(hb.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
     if (nvox) IA3_HIP(hipMemcpyAsync(nvox, f->d_nvox, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     if (success) {
       stv.resize(f->n);
       IA3_HIP(hipMemcpyAsync(stv.data(), f->d_state, sizeof(SeedState) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     }
     IA3_HIP(hipStreamSynchronize(st));
-    if (n_iter) memcpy(n_iter, hb.data(), sizeof(int));
-    memcpy(&hc, hb.data() + ((char*)f->d_ctl - (char*)f->d_niter), sizeof(StageCtl));
-    memcpy(&ovf, hb.data() + ((char*)f->d_nbr_overflow - (char*)f->d_niter), sizeof(int));
+    memcpy(f->host_counters, hb.data(), sizeof(f->host_counters));
+    if (n_iter) memcpy(n_iter, hb.data() + ((char*)f->d_niter - (char*)f->d_counters), sizeof(int));
+    memcpy(&hc, hb.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));
+    memcpy(&ovf, hb.data() + ((char*)f->d_nbr_overflow - (char*)f->d_counters), sizeof(int));
     if (rows) memcpy(ps, hb.data() + head, rows);
   }
   if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
-  if (ovf) return set_error(IA3_EUNSUPPORTED, "a seed has %d other seeds within 2*radius_fit (limit %d): field too dense", ovf, MAXNB);
+  (void)ovf;   // > MAXNB neighbours somewhere: those seeds scanned the seed list instead (each_neighbour); not an error
   if (success) for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)stv[i].success;
   return IA3_OK;
 }

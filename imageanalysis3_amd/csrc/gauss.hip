@@ -635,6 +635,7 @@ int ia3_set_tuning(int key, int value) {
     return 0;
   }
   if (key == IA3_TUNE_DFT_VALU) { ia3k::set_dft_valu(value); return 0; }
+  if (key == IA3_TUNE_UPLOAD_THREADS) return ia3rt::set_upload_threads(value);
   return set_error(IA3_EINVAL, "unknown tuning key");
 }
 

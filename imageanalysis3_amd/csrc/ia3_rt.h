@@ -22,6 +22,7 @@ int set_error(int code, const char* fmt, ...);
 int ensure_init();
 hipStream_t stream();
 int num_cus();  // compute units of the selected device
+int set_upload_threads(int n);   // IA3_TUNE_UPLOAD_THREADS
 inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 
 // Cached device scratch: get(bytes) returns a buffer that stays valid until put(); buffers are
@@ -108,4 +109,6 @@ struct SeedDev {
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
 // fitter from centres that are already resident (n x 3 float64)
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
+// fits run / model evaluations / voxel evaluations of a fitter, as of its last ia3_fit_results(_ex)
+void fit_host_counters(const ia3_fitter* f, long long out[3]);
 }  // namespace ia3k

@@ -3,8 +3,18 @@
 #include "ia3_rt.h"
 #include <math.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <unistd.h>
 
 using namespace ia3rt;
+
+// counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
+static thread_local long long t_last_stats[3] = {0, 0, 0};
 
 extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
                                float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter) {
@@ -16,6 +26,7 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   if (n_seeds) *n_seeds = n;
   if (n_iter) *n_iter = 0;
   *n_rows = 0;
+  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = 0;
   if (n == 0) return IA3_OK;  // fitting.py:206-207
   ia3_fitter* f = nullptr;
   if (sd.on_device) {
@@ -28,6 +39,7 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   std::vector<float> ps((size_t)n * 11);
   rc = ia3_fit_run(f);
   if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
+  if (!rc) ia3k::fit_host_counters(f, t_last_stats);
   ia3_fit_destroy(f);
   if (rc) return rc;
   int m = 0;
@@ -42,5 +54,107 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   }
   *n_rows = m;
   if (m > capacity) return set_error(IA3_ECAPACITY, "row buffer too small: need %d rows", m);
+  return IA3_OK;
+}
+
+extern "C" int ia3_fit_fov_stats(int64_t* fits, int64_t* nfev, int64_t* voxel_evals) {
+  if (fits) *fits = t_last_stats[0];
+  if (nfev) *nfev = t_last_stats[1];
+  if (voxel_evals) *voxel_evals = t_last_stats[2];
+  return IA3_OK;
+}
+
+// ---- library-owned worker threads ------------------------------------------------------------------------------
+// Created on first use and kept for the life of the process (detached, idle on a condition variable): each keeps its
+// HIP streams, scratch ordering and pinned staging ring (runtime.cpp: all thread-local), so a batch call costs no
+// stream creation or hipHostMalloc.  A forked child starts with an empty pool (threads do not survive fork).
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  int threads = 0;
+  pid_t pid = 0;
+};
+Pool* g_pool = nullptr;        // leaked on purpose: workers may outlive static destruction
+std::mutex g_pool_mu;
+
+void pool_run(int workers, const std::function<void()>& fn) {
+  Pool* p;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool || g_pool->pid != getpid()) { g_pool = new Pool(); g_pool->pid = getpid(); }
+    p = g_pool;
+  }
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  int left = workers;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (; p->threads < workers; ++p->threads)
+      std::thread([p] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [p] { return !p->q.empty(); });
+            job = std::move(p->q.front());
+            p->q.pop_front();
+          }
+          job();
+        }
+      }).detach();
+    for (int t = 0; t < workers; ++t)
+      p->q.push_back([&] {
+        fn();
+        std::lock_guard<std::mutex> lk(done_mu);
+        if (--left == 0) done_cv.notify_all();
+      });
+  }
+  p->cv.notify_all();
+  std::unique_lock<std::mutex> lk(done_mu);
+  done_cv.wait(lk, [&] { return left == 0; });
+}
+}  // namespace
+
+// A batch of independent FOVs from ONE caller thread.  The reference spreads its per-image tasks over an mp.Pool
+// (classes/field_of_view.py:1129-1142); here `in_flight` library threads take the jobs in order, each with its own pair
+// of HIP streams (runtime.cpp ThreadCtx) and its own pinned staging ring, so the upload of one FOV, the filters of
+// another and the long tail of a third one's fit kernel (uint16 stacks: a few plateau-duplicate seeds that run to
+// maxfev) overlap on the device.  Results are exactly those of ia3_fit_fov_dev job by job.
+extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int X, int Y, const ia3_seed_params* sp,
+                            const ia3_fit_params* fp, int in_flight) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (n_jobs < 0 || (n_jobs > 0 && !jobs) || !sp || !fp) return set_error(IA3_EINVAL, "null argument");
+  for (int k = 0; k < n_jobs; ++k)
+    if (!jobs[k].host && !jobs[k].dev) return set_error(IA3_EINVAL, "job %d has neither a host nor a resident stack", k);
+  if (n_jobs == 0) return IA3_OK;
+  if (in_flight <= 0) in_flight = 4;
+  if (in_flight > 16) in_flight = 16;
+  if (in_flight > n_jobs) in_flight = n_jobs;
+  std::atomic<int> next{0};
+  std::vector<std::string> errs((size_t)n_jobs);
+  auto worker = [&]() {
+    const int init_rc = ensure_init();   // this thread's streams
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= n_jobs) break;
+      ia3_fov_job& j = jobs[k];
+      j.n_rows = j.n_seeds = j.n_iter = 0;
+      j.fits = j.nfev = j.voxel_evals = 0;
+      ia3_stack* up = nullptr;
+      int r = init_rc;
+      if (!r && !j.dev) r = ia3_stack_upload(j.host, dtype, Z, X, Y, &up);
+      if (!r) r = ia3_fit_fov_dev(j.dev ? j.dev : up, sp, fp, j.rows, j.capacity, &j.n_rows, &j.n_seeds, &j.n_iter);
+      if (!r) { j.fits = t_last_stats[0]; j.nfev = t_last_stats[1]; j.voxel_evals = t_last_stats[2]; }
+      if (up) ia3_stack_free(up);
+      j.rc = r;
+      if (r) errs[(size_t)k] = ia3_last_error();
+    }
+  };
+  if (in_flight <= 1) worker();
+  else pool_run(in_flight, worker);
+  for (int k = 0; k < n_jobs; ++k)
+    if (jobs[k].rc) return set_error(jobs[k].rc, "FOV %d: %s", k, errs[(size_t)k].c_str());
   return IA3_OK;
 }

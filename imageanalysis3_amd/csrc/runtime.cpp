@@ -9,6 +9,9 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <mutex>
+#include <atomic>
+#include <thread>
+#include <sched.h>
 
 namespace ia3rt {
 
@@ -326,39 +329,118 @@ int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
   *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes, (void*)t_ctx.main};
   return IA3_OK;
 }
+// Host array -> resident stack.  A plain hipMemcpyAsync from pageable memory lets the runtime pin and copy the caller's
+// pages piecewise on the calling thread; here the array is cut into STAGE_BYTES pieces that helper threads copy into a
+// ring of pinned staging buffers (one buffer per helper) while the calling thread queues one asynchronous H2D copy per
+// finished piece, so page touching, the host-side copy and the PCIe transfer overlap.  IA3_UPLOAD_THREADS (default 4;
+// 0 = the plain pageable copy) sets the number of helpers.  The call returns when the stack is resident.
+namespace {
+constexpr size_t STAGE_BYTES = 16u << 20;
+constexpr int MAX_STAGE = 8;
+struct Staging {
+  void* buf[MAX_STAGE] = {};
+  hipEvent_t ev[MAX_STAGE] = {};
+  int n = 0;
+  pid_t pid = 0;
+};
+thread_local Staging t_stage;
+std::atomic<int> g_upload_threads{-1};   // -1: from IA3_UPLOAD_THREADS (default 4)
+int upload_threads() {
+  int n = g_upload_threads.load(std::memory_order_relaxed);
+  if (n < 0) {
+    const char* e = getenv("IA3_UPLOAD_THREADS");
+    n = e ? atoi(e) : 4;
+    n = n < 0 ? 0 : (n > MAX_STAGE ? MAX_STAGE : n);
+    g_upload_threads.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+int staging_ready(int want) {
+  Staging& s = t_stage;
+  if (s.pid != getpid()) { s = Staging(); s.pid = getpid(); }
+  for (; s.n < want; ++s.n) {
+    if (hipHostMalloc(&s.buf[s.n], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev[s.n], hipEventDisableTiming) != hipSuccess)
+      return set_error(IA3_ENOMEM, "cannot allocate pinned staging buffers");
+  }
+  return IA3_OK;
+}
+// dst (device) <- src (pageable host), queued on st; returns after the last piece has been queued AND copied out of
+// the staging ring (the caller synchronises the stream)
+int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  const int T = upload_threads();
+  if (T == 0 || bytes < 2 * STAGE_BYTES) {
+    IA3_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return IA3_OK;
+  }
+  int rc = staging_ready(T); if (rc) return rc;
+  Staging& sg = t_stage;
+  const size_t pieces = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+  // filled[k] = piece k sits in buffer k % T; queued[b] = number of pieces of buffer b whose H2D copy has been queued
+  std::vector<std::atomic<int>> filled(pieces);
+  for (auto& f : filled) f.store(0, std::memory_order_relaxed);
+  std::atomic<long long> queued[MAX_STAGE];
+  for (int b = 0; b < T; ++b) queued[b].store(0, std::memory_order_relaxed);
+  std::atomic<int> failed{0};
+  const int dev = g_device;
+  auto helper = [&](int b) {
+    (void)hipSetDevice(dev);
+    long long mine = 0;   // pieces this helper has filled so far
+    for (size_t k = (size_t)b; k < pieces; k += (size_t)T, ++mine) {
+      if (mine > 0) {   // the copy that read this buffer last must have been queued, then finished
+        while (queued[b].load(std::memory_order_acquire) < mine && !failed.load()) sched_yield();
+        if (failed.load() || hipEventSynchronize(sg.ev[b]) != hipSuccess) { failed.store(1); return; }
+      }
+      const size_t off = k * STAGE_BYTES, n = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+      memcpy(sg.buf[b], (const char*)src + off, n);
+      filled[k].store(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int b = 0; b < T; ++b) th.emplace_back(helper, b);
+  hipError_t e = hipSuccess;
+  for (size_t k = 0; k < pieces && e == hipSuccess; ++k) {
+    const int b = (int)(k % (size_t)T);
+    while (!filled[k].load(std::memory_order_acquire) && !failed.load()) sched_yield();
+    if (failed.load()) break;
+    const size_t off = k * STAGE_BYTES, n = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+    e = hipMemcpyAsync((char*)dst + off, sg.buf[b], n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(sg.ev[b], st);
+    if (e != hipSuccess) failed.store(1);
+    queued[b].fetch_add(1, std::memory_order_release);
+  }
+  if (e != hipSuccess) failed.store(1);
+  for (auto& t : th) t.join();
+  if (failed.load()) return set_error(IA3_EHIP, "staged H2D copy failed: %s", hipGetErrorString(e));
+  return IA3_OK;
+}
+}  // namespace
+extern "C++" {
+namespace ia3rt {
+int set_upload_threads(int n) {
+  if (n < 0 || n > MAX_STAGE) return set_error(IA3_EINVAL, "IA3_TUNE_UPLOAD_THREADS: 0..%d", MAX_STAGE);
+  g_upload_threads.store(n, std::memory_order_relaxed);
+  return IA3_OK;
+}
+}  // namespace ia3rt
+}  // extern "C++"
+
 int ia3_stack_upload(const void* host, int dtype, int Z, int X, int Y, ia3_stack** out) {
   if (!host) return set_error(IA3_EINVAL, "null host pointer");
   int rc = ia3_stack_alloc(dtype, Z, X, Y, out); if (rc) return rc;
-  hipError_t e = hipMemcpyAsync((*out)->d, host, (*out)->bytes, hipMemcpyHostToDevice, stream());
-  if (e == hipSuccess) e = hipStreamSynchronize(stream());
-  if (e != hipSuccess) {
+  rc = staged_h2d((*out)->d, host, (*out)->bytes, stream());
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipStreamSynchronize(stream());
+  if (rc || e != hipSuccess) {
     ia3_stack_free(*out); *out = nullptr;
-    return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
+    return rc ? rc : set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e));
   }
   return IA3_OK;
 }
 // Raw movie file -> resident uint16 stack (what DaxReader.loadAll + an upload do, visual_tools.py:974-1083): the file
-// is read in 32 MiB pieces into two pinned staging buffers per host thread and every piece is sent with an async copy
-// while the next one is being read, so a movie costs max(file read, PCIe) instead of read + pageable copy.
+// is read in STAGE_BYTES pieces into two of the calling thread's pinned staging buffers and every piece is sent with an
+// async copy while the next one is being read, so a movie costs max(file read, PCIe) instead of read + pageable copy.
 namespace {
-constexpr size_t STAGE_BYTES = 32u << 20;
-struct Staging {
-  void* buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  pid_t pid = 0;
-};
-thread_local Staging t_stage;
-int staging_ready() {
-  Staging& s = t_stage;
-  if (s.pid == getpid()) return IA3_OK;
-  for (int i = 0; i < 2; ++i) {
-    if (hipHostMalloc(&s.buf[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess)
-      return set_error(IA3_ENOMEM, "cannot allocate pinned staging buffers");
-  }
-  s.pid = getpid();
-  return IA3_OK;
-}
 __global__ void bswap16_k(uint16_t* p, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) { uint16_t v = p[i]; p[i] = (uint16_t)((v >> 8) | (v << 8)); }
@@ -377,7 +459,7 @@ int ia3_stack_load_file(const char* path, long long offset_bytes, int frames, in
     close(fd);
     return set_error(IA3_EINVAL, "%s holds fewer than %d frames of %d x %d uint16", path, frames, X, Y);
   }
-  rc = staging_ready();
+  rc = staging_ready(2);
   if (!rc) rc = ia3_stack_alloc(IA3_U16, frames, X, Y, out);
   if (rc) { close(fd); return rc; }
   Staging& sg = t_stage;

@@ -172,6 +172,20 @@ def fit_fov_images(ims, channels=None, n_workers=2, **kwargs):
     if any(isinstance(_im, L.DeviceStack) for _im in ims):
         L.check(L.lib().ia3_sync())   # resident inputs may still be in production on this thread's stream
     kwargs.setdefault("verbose", False)
+    # plain seed + fit on same-sized images: one ia3_fit_fovs call (library-owned threads and streams, no Python threads)
+    _plain = {"th_seed", "max_num_seeds", "use_dynamic_th", "dynamic_niters", "min_dynamic_seeds", "remove_hot_pixel",
+              "fit_radius", "verbose"}
+    if (n_workers > 1 and len(ims) > 1 and set(kwargs) <= _plain
+            and len({(tuple(_im.shape), np.dtype(_im.dtype).str) for _im in ims if hasattr(_im, "shape")}) == 1
+            and all(isinstance(_im, (np.ndarray, L.DeviceStack)) and len(_im.shape) == 3 for _im in ims)):
+        _sp, _keep = L.make_seed_params(float(kwargs.get("th_seed", 300)), max_num_seeds=kwargs.get("max_num_seeds", 500),
+                                        use_dynamic_th=kwargs.get("use_dynamic_th", True),
+                                        dynamic_niters=kwargs.get("dynamic_niters", 10),
+                                        min_dynamic_seeds=kwargs.get("min_dynamic_seeds", 1),
+                                        remove_hot_pixel=kwargs.get("remove_hot_pixel", True))
+        _tables, _info = L.fit_fovs(ims, _sp, L.make_fit_params(radius_fit=kwargs.get("fit_radius", 5)),
+                                    in_flight=n_workers)
+        return [_t if _i["n_seeds"] else np.array([]) for _t, _i in zip(_tables, _info)]   # no seeds: fitting.py:206-207
     if n_workers <= 1 or len(ims) <= 1:
         return [fit_fov_image(_im, _ch, **kwargs) for _im, _ch in zip(ims, channels)]
     with ThreadPoolExecutor(max_workers=int(n_workers)) as pool:
@@ -249,8 +263,10 @@ def get_centers(im, seeds=None, th_seed=150,
     if verbose:
         print(f"-- fitting {len(rows)} points.")
     if remove_close_pts:                                                     # :319-326
-        sq = ((centers[:, None, :] - centers[None, :, :]) ** 2).sum(axis=-1)
-        crowded = (sq < close_threshold).sum(axis=1) > 1                     # itself + at least one more
+        crowded = np.zeros(len(centers), dtype=bool)
+        for i0 in range(0, len(centers), 256):                               # row blocks: no n x n x 3 temporary
+            sq = ((centers[i0:i0 + 256, None, :] - centers[None, :, :]) ** 2).sum(axis=-1)
+            crowded[i0:i0 + 256] = (sq < close_threshold).sum(axis=1) > 1    # itself + at least one more
         outside = (centers < 0).any(axis=1) | (centers > np.array(im.shape)).any(axis=1)
         drop = np.isnan(centers).any(axis=1) | crowded | outside
         centers = centers[~drop]

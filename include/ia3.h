@@ -56,6 +56,9 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_DFT_VALU: 1 = the upsampled-DFT contractions of the phase correlation run on the vector unit (first
  * version) instead of the f64 matrix cores; shifts agree to rounding. */
 #define IA3_TUNE_DFT_VALU 2
+/* IA3_TUNE_UPLOAD_THREADS: helper threads that copy a host array into the pinned staging ring of ia3_stack_upload
+ * (default 4, environment IA3_UPLOAD_THREADS); 0 = one plain hipMemcpyAsync from pageable memory. */
+#define IA3_TUNE_UPLOAD_THREADS 3
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
@@ -244,6 +247,26 @@ int ia3_fit_seeds(const void* im, int dtype, int Z, int X, int Y, const double* 
 int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
                     float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter);
 
+/* fits run, model evaluations and voxel evaluations (sum over fits of evaluations x voxels) of the calling thread's
+ * last ia3_fit_fov_dev: what the counted-flop rate of the fit kernel is computed from (bench.py). */
+int ia3_fit_fov_stats(int64_t* fits, int64_t* nfev, int64_t* voxel_evals);
+
+/* A batch of independent FOVs in one call: the per-image tasks the reference spreads over an mp.Pool
+ * (classes/field_of_view.py:1129-1142, worker classes/batch_functions.py:60).  Each job is either a host stack
+ * (uploaded here through pinned staging buffers while other jobs compute) or a resident one; `in_flight` jobs
+ * (<= 0: 4, at most 16) are processed side by side on library-owned threads and streams.  Per job the outputs are those
+ * of ia3_fit_fov_dev; the call returns the first failing job's code (every job's own code is in `rc`). */
+typedef struct ia3_fov_job {
+  const void* host;       /* (Z,X,Y) stack of `dtype` in host memory, or NULL */
+  const ia3_stack* dev;   /* resident stack (used when not NULL) */
+  float* rows;            /* capacity x 11 float32 */
+  int capacity;
+  int n_rows, n_seeds, n_iter, rc;          /* out */
+  long long fits, nfev, voxel_evals;        /* out: see ia3_fit_fov_stats */
+} ia3_fov_job;
+int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int X, int Y, const ia3_seed_params* sp,
+                 const ia3_fit_params* fp, int in_flight);
+
 /* ---- drift ------------------------------------------------------------------------------------
  * alignment_tools.py:286-328 fftalign_2d: (xt, yt) of the normalised full cross-correlation peak of two
  * 2-D float64 images inside a +-max_disp window around `center`. */
@@ -254,8 +277,8 @@ int ia3_fft3d_from2d(const void* im1, const void* im2, int dtype, int Z, int X, 
                      int* out_zxy);
 int ia3_fft3d_from2d_dev(const ia3_stack* im1, const ia3_stack* im2, double max_disp, int* out_zxy);
 /* skimage.registration.phase_cross_correlation(reference, moving, upsample_factor) as called at
- * correction_tools/alignment.py:491-494,631-632 and classes/preprocess.py:831-835 (published algorithm;
- * parity unpinned).  normalization: 1 = "phase", 0 = None.  shift[3] = (dz, dx, dy) to apply to `moving`. */
+ * correction_tools/alignment.py:491-494,631-632 and classes/preprocess.py:831-835 (published algorithm; pinned
+ * against scikit-image 0.18.3 for normalization None, tests/golden/phase.npz).  normalization: 1 = "phase", 0 = None.  shift[3] = (dz, dx, dy) to apply to `moving`. */
 int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X, int Y, int upsample,
                       int normalization, double* shift, double* err, double* phasediff);
 int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsample, int normalization,

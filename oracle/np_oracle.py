@@ -356,7 +356,9 @@ class GaussianFit(object):
         if len(self.p_) > len(self.im):
             self.success = False
         else:
-            parmsf, _ = leastsq(self.calc_eps, self.p_, Dfun=self.calc_jac, maxfev=1000)
+            parmsf, _, info, _, self.ier = leastsq(self.calc_eps, self.p_, Dfun=self.calc_jac, maxfev=1000,
+                                                    full_output=True)
+            self.nfev = int(info["nfev"])   # bookkeeping for the tests: a fit that stops at maxfev (ier 5) is unconverged
             self.p_ = parmsf
             self.to_natural_paramaters()
             self.center = self.p[1:4]
@@ -434,6 +436,7 @@ class iter_fit_seed_points(object):
             from scipy.spatial import cKDTree
             self.ps, self.ims_rec, self.centers_fit, self.success, self.gparms = [], [], [], [], []
             self.im_subtr = np.array(self.im, dtype=float)
+            self.nfev_last = np.zeros(len(self.centers), dtype=int)   # evaluations of each seed's latest fit
             self.tree = cKDTree(self.centers)
             for ic, (zc, xc, yc) in enumerate(self.centers):
                 z, x, y = int(zc) + self.zb, int(xc) + self.xb, int(yc) + self.yb
@@ -444,6 +447,7 @@ class iter_fit_seed_points(object):
                 im_ = self.im[X[0], X[1], X[2]]
                 obj = self._gfit(im_, X, [zc, xc, yc], self.min_delta_center)
                 obj.fit()
+                self.nfev_last[ic] = getattr(obj, "nfev", 0)
                 self.gparms.append([im_, X, [zc, xc, yc]])
                 self.success.append(obj.success)
                 if obj.success:
@@ -476,6 +480,7 @@ class iter_fit_seed_points(object):
                         im_ = self.ims_rec[ic] + im_
                     obj = self._gfit(im_, X, [zc, xc, yc], self.max_delta_center)
                     obj.fit()
+                    self.nfev_last[ic] = getattr(obj, "nfev", 0)
                     self.success[ic] = obj.success
                     if obj.success:
                         im_rec = obj.get_im()
