@@ -453,10 +453,12 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
 int g_cert = -2;   // -2: default guard (4R+8 ulps), -1: fused path off, >= 0: guard distance in ulps (tests)
 inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
 
+// axes: bit 0 = the axis-0 pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst)
 template <class T, int R, int KS, int KC, int KZ = KS>
-int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s) {
+int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s, int axes) {
   const size_t plane = (size_t)X * Y;
-  if constexpr (R <= 3) {   // R = 6 was measured too: fused 2.26 ms, three passes 1.17 ms (2048x2048x50 f32)
+  if constexpr (R <= 3) {
+    if (axes != 3) return ia3rt::set_error(IA3_EUNSUPPORTED, "the fused short filter runs all three axes at once");   // R = 6 was measured too: fused 2.26 ms, three passes 1.17 ms (2048x2048x50 f32)
     // maps must cover the halo of the last (partial) tile: positions up to ceil(len/tile)*tile + 2R
     static const std::string nf = "gauss_fused3_R" + std::to_string(R);
     ia3rt::ProfScope ps(nf.c_str());
@@ -500,12 +502,13 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   };
   auto seg_for = [&](int len, long long lines) { return seg_for_k(len, lines, KS); };
   // axis 0: src -> dst
-  {
+  if (axes & 1) {
     ia3rt::ProfScope ps(nz.c_str());
     const int seg = seg_for_k(Z, (long long)plane, KZ);
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
     hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg, cert_for(R));
   }
+  if (!(axes & 2)) return 0;
   if constexpr (R >= 16) {
     // long filters are f64-VALU-bound: give the contiguous axis the register-window kernel too, by transposing
     // each plane on the way out of the axis-1 pass and again on the way out of the axis-2 pass
@@ -547,17 +550,18 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
 
 template <class T>
 int run_generic(const T* src, int Z, int X, int Y, const double* w_host, int R, int mode, T* dst, T* tmp,
-                hipStream_t s) {
+                hipStream_t s, int axes) {
   const size_t plane = (size_t)X * Y;
   ia3rt::Scratch wd((size_t)(R + 1) * sizeof(double));
   if (!wd.p) return IA3_ENOMEM;
   if (hipMemcpyAsync(wd.p, w_host, (size_t)(R + 1) * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
     return ia3rt::set_error(IA3_EHIP, "tap upload failed");
   const double* w = wd.as<double>();
-  {
+  if (axes & 1) {
     dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)(Z < 64 ? Z : 64));
     hipLaunchKernelGGL((gauss_generic<T>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, (size_t)1, w, R, mode);
   }
+  if (!(axes & 2)) return 0;
   {
     dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)(X < 64 ? X : 64));
     hipLaunchKernelGGL((gauss_generic<T>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, (size_t)1, w, R, mode);
@@ -572,23 +576,23 @@ int run_generic(const T* src, int Z, int X, int Y, const double* w_host, int R, 
 }
 
 template <class T>
-int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int mode, T* dst, T* tmp) {
+int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int mode, T* dst, T* tmp, int axes) {
   hipStream_t s = ia3rt::stream();
   // taps by offset: wj[j] = w[R + j] (symmetric)
   if (R <= 63) {
     Taps t;
     for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
     switch (R) {
-      case 3:  return run_fixed<T, 3, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 6:  return run_fixed<T, 6, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 10: return run_fixed<T, 10, 12, 16>(src, Z, X, Y, t, mode, dst, tmp, s);
-      case 30: return run_fixed<T, 30, 8, 8, 6>(src, Z, X, Y, t, mode, dst, tmp, s);
+      case 3:  return run_fixed<T, 3, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s, axes);
+      case 6:  return run_fixed<T, 6, 16, 16>(src, Z, X, Y, t, mode, dst, tmp, s, axes);
+      case 10: return run_fixed<T, 10, 12, 16>(src, Z, X, Y, t, mode, dst, tmp, s, axes);
+      case 30: return run_fixed<T, 30, 8, 8, 6>(src, Z, X, Y, t, mode, dst, tmp, s, axes);
       default: break;
     }
   }
   std::vector<double> wj(R + 1);
   for (int j = 0; j <= R; ++j) wj[j] = w[R + j];
-  return run_generic<T>(src, Z, X, Y, wj.data(), R, mode, dst, tmp, s);
+  return run_generic<T>(src, Z, X, Y, wj.data(), R, mode, dst, tmp, s, axes);
 }
 
 }  // namespace
@@ -596,14 +600,14 @@ int gaussian3d_t(const T* src, int Z, int X, int Y, const double* w, int R, int 
 namespace ia3k {
 
 int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w, int radius, int mode,
-               void* dst, void* tmp) {
+               void* dst, void* tmp, int axes) {
   if (radius < 0 || !w) return ia3rt::set_error(IA3_EINVAL, "bad taps");
   for (int j = 1; j <= radius; ++j)
     if (w[radius + j] != w[radius - j]) return ia3rt::set_error(IA3_EUNSUPPORTED, "taps must be symmetric");
   if ((size_t)X * Y > 0x7fffffffULL) return ia3rt::set_error(IA3_EUNSUPPORTED, "plane too large");
   int rc;
-  if (dtype == IA3_F32) rc = gaussian3d_t<float>((const float*)src, Z, X, Y, w, radius, mode, (float*)dst, (float*)tmp);
-  else rc = gaussian3d_t<uint16_t>((const uint16_t*)src, Z, X, Y, w, radius, mode, (uint16_t*)dst, (uint16_t*)tmp);
+  if (dtype == IA3_F32) rc = gaussian3d_t<float>((const float*)src, Z, X, Y, w, radius, mode, (float*)dst, (float*)tmp, axes);
+  else rc = gaussian3d_t<uint16_t>((const uint16_t*)src, Z, X, Y, w, radius, mode, (uint16_t*)dst, (uint16_t*)tmp, axes);
   if (rc) return rc;
   IA3_KCHECK();
   return IA3_OK;
@@ -636,6 +640,7 @@ int ia3_set_tuning(int key, int value) {
   }
   if (key == IA3_TUNE_DFT_VALU) { ia3k::set_dft_valu(value); return 0; }
   if (key == IA3_TUNE_UPLOAD_THREADS) return ia3rt::set_upload_threads(value);
+  if (key == IA3_TUNE_SEED_DENSE) { ia3k::set_seed_dense(value); return 0; }
   return set_error(IA3_EINVAL, "unknown tuning key");
 }
 

@@ -80,11 +80,12 @@ void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& r
 }  // namespace ia3rt
 
 // ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
-namespace ia3k { void set_dft_valu(int on); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
+namespace ia3k { void set_dft_valu(int on); void set_seed_dense(int on); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
 namespace ia3k {
-// separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.
+// separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.  axes: bit 0 = the axis-0
+// pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst); radius <= 3 runs fused (axes == 3 only).
 int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w, int radius, int mode,
-               void* dst, void* tmp);
+               void* dst, void* tmp, int axes = 3);
 // out = im - low ; out[low > im] = 0   (correction_tools/filter.py:17-18)
 int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out);
 // get_seeds on a resident stack (seed.hip)

@@ -239,6 +239,239 @@ __global__ __launch_bounds__(256) void seed_detect3_tiled(const T* __restrict__ 
   }
 }
 
+
+// ==== lazy background filter ===================================================================================
+// The background filter (sigma 7.5: 61 taps per axis) is by far the most expensive part of get_seeds, but min_im
+// enters the result only at voxels that are 3x3x3 maxima of max_im with max_im - min_im above the lowest threshold
+// level — a few thousand voxels in a 2 x 10^8 voxel stack — and at their 26 neighbours (the not-a-local-minimum
+// test).  So only the first (axis-0) pass is run on the whole stack.  From its output zp a rigorous lower bound of
+// min_im follows without the other two passes: every later pass is a correlation with non-negative taps summing to 1,
+// re-quantised monotonically, so min_im(z, x, y) >= min of zp(z, ., .) over the (x +- R, y +- R) window (reflected
+// indices fall inside the clipped window), minus the rounding slack of two passes.  The window minimum is taken from
+// per-plane B x B block minima (B >= R: the window touches at most 3 x 3 blocks).  Voxels that pass the local-maximum
+// test, the edge test and `max_im - bound >= lowest level` are the candidates; for each of them one wave evaluates the
+// axis-1 pass on the nine (z', x') rows it needs and the axis-2 pass at the 27 neighbourhood positions with exactly
+// the dense kernels' arithmetic (NI_Correlate1D order, unfused multiply and add, re-quantisation after each axis), and
+// applies the reference's tests to the exact values.  Seeds are therefore identical to the dense path bit for bit;
+// the bound only decides where the exact computation happens.
+struct Cand0 { int z, x, y; float cmax; };   // local maximum of max_im that passed the bound test
+
+__device__ __forceinline__ int reflect_idx(int q, int n, int mode) {   // scipy 'reflect' / 'nearest' (gauss.hip border_idx)
+  if (mode == IA3_MODE_NEAREST) return q < 0 ? 0 : (q >= n ? n - 1 : q);
+  if (q >= 0 && q < n) return q;
+  int p = 2 * n;
+  q %= p;
+  if (q < 0) q += p;
+  return q < n ? q : p - 1 - q;
+}
+
+// per plane z and B x B block: minimum and maximum magnitude of zp.  One 256-thread block reads B rows of 256
+// consecutive y (coalesced), every thread reduces its column over the rows, then 32-lane groups reduce across y.
+template <class T, int B>
+__global__ __launch_bounds__(256) void blockmin_k(const T* __restrict__ zp, int Z, int X, int Y, int nbx, int nby,
+                                                  float* __restrict__ bmin, float* __restrict__ babs) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  const int bx = blockIdx.y, z = blockIdx.z;
+  const int x0 = bx * B, x1 = x0 + B < X ? x0 + B : X;
+  float m = INFINITY, a = 0.f;
+  if (y < Y) {
+    const T* p = zp + ((size_t)z * X + x0) * Y + y;
+    for (int x = x0; x < x1; ++x, p += Y) { const float v = (float)*p; m = v < m ? v : m; const float av = fabsf(v); a = av > a ? av : a; }
+  }
+#pragma unroll
+  for (int o = B / 2; o >= 1; o >>= 1) {
+    const float m2 = __shfl_xor(m, o), a2 = __shfl_xor(a, o);
+    m = m2 < m ? m2 : m; a = a2 > a ? a2 : a;
+  }
+  if ((threadIdx.x & (B - 1)) == 0 && y < Y) {
+    const size_t o = ((size_t)z * nbx + bx) * nby + y / B;
+    bmin[o] = m; babs[o] = a;
+  }
+}
+
+// lower bound of min_im over each block: minimum over the 3 x 3 block neighbourhood minus the rounding slack of the two
+// remaining passes (float32: a relative 2e-6 of the largest magnitude involved; uint16: each pass truncates, so up to
+// one count per pass)
+__global__ __launch_bounds__(256) void blockbound_k(const float* __restrict__ bmin, const float* __restrict__ babs, int Z,
+                                                    int nbx, int nby, int is_u16, double* __restrict__ lb) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)Z * nbx * nby;
+  if (i >= n) return;
+  const int by = (int)(i % nby), bx = (int)((i / nby) % nbx);
+  const size_t pz = i - (size_t)bx * nby - by;
+  float m = INFINITY, a = 0.f;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int xx = bx + dx, yy = by + dy;
+      if (xx < 0 || xx >= nbx || yy < 0 || yy >= nby) continue;
+      const float v = bmin[pz + (size_t)xx * nby + yy], w = babs[pz + (size_t)xx * nby + yy];
+      m = v < m ? v : m; a = w > a ? w : a;
+    }
+  lb[i] = (double)m - 2e-6 * (double)a - (is_u16 ? 2.0 : 0.0);
+}
+
+// 3x3x3 local maxima of max_im that pass the edge test and the bound test -> Cand0 list.  Same tiling as
+// seed_detect3_tiled (16 x 64 tile + halo in LDS, double-buffered, rolling three-plane pipeline along z), one stack.
+template <class T, int ZC, int B>
+__global__ __launch_bounds__(256) void seed_cand3_tiled(const T* __restrict__ mx, const double* __restrict__ lb, int nbx, int nby,
+                                                        int Z, int X, int Y, int edge, double th_test,
+                                                        Cand0* __restrict__ out, unsigned capacity,
+                                                        SeedCtl* __restrict__ ctl) {
+  constexpr int TX = 16, TY = 64, HX = TX + 2, HY = TY + 2, NE = (HX * HY + 255) / 256;
+  static_assert(B % TX == 0, "a tile must lie inside one block row");
+  __shared__ T tmax[2][HX][HY + 2];
+  const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
+  const int tile = xcd_tile(blockIdx.x, nty * ntx);
+  if (tile < 0) return;
+  const int x0 = (tile / nty) * TX, y0 = (tile % nty) * TY;
+  const int z0 = blockIdx.z * ZC, z1 = z0 + ZC < Z ? z0 + ZC : Z;
+  const int ty = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  size_t goff[NE]; int lr[NE], lc[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int r = e / HY, c = e % HY;
+    lr[i] = e < HX * HY ? r : -1; lc[i] = c;
+    const int gx = min(max(x0 + r - 1, 0), X - 1), gy = min(max(y0 + c - 1, 0), Y - 1);
+    goff[i] = (size_t)gx * Y + gy;
+  }
+  T ra[NE];
+  auto fetch = [&](int q) {
+    const int zq = q < 0 ? 0 : (q >= Z ? Z - 1 : q);
+    const size_t pz = (size_t)zq * X * Y;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (lr[i] >= 0) ra[i] = mx[pz + goff[i]];
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (lr[i] >= 0) tmax[buf][lr[i]][lc[i]] = ra[i];
+  };
+  T pM[4][3], cM[4][2];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { pM[v][0] = pM[v][1] = pM[v][2] = 0; cM[v][0] = cM[v][1] = 0; }
+  const int yb = min(y0 + ty, Y - 1) / B;
+  const size_t lrow = (size_t)(x0 / B) * nby + yb;
+  fetch(z0 - 1);
+  stash(0);
+  __syncthreads();
+  for (int q = z0 - 1, buf = 0; q <= z1; ++q, buf ^= 1) {
+    if (q < z1) fetch(q + 1);
+    {
+      const int c = ty + 1;
+      T hM[6], ce[4];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        const int r = tg * 4 + rr;
+        const T a0 = tmax[buf][r][c - 1], a1 = tmax[buf][r][c], a2 = tmax[buf][r][c + 1];
+        hM[rr] = max3v(a0, a1, a2);
+        if (rr >= 1 && rr <= 4) ce[rr - 1] = a1;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const T a = max3v(hM[v], hM[v + 1], hM[v + 2]);
+        pM[v][0] = pM[v][1]; pM[v][1] = pM[v][2]; pM[v][2] = a;
+        cM[v][0] = cM[v][1]; cM[v][1] = ce[v];
+      }
+    }
+    if (q < z1) stash(buf ^ 1);
+    __syncthreads();
+    const int z = q - 1;
+    if (z < z0) continue;
+    const double bound = lb[(size_t)z * nbx * nby + lrow];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int x = x0 + tg * 4 + v, y = y0 + ty;
+      const T vmax = max3v(pM[v][0], pM[v][1], pM[v][2]);
+      const T cmax = cM[v][0];
+      bool hit = x < X && y < Y && (vmax == cmax) && ((double)cmax - bound >= th_test);
+      if (edge > 0)
+        hit = hit && z >= edge && z <= Z - edge && x >= edge && x <= X - edge && y >= edge && y <= Y - edge;
+      const unsigned long long ballot = __ballot(hit);
+      if (ballot) {
+        const int lane = threadIdx.x & 63;
+        unsigned basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&ctl->n_cand, (unsigned)__popcll(ballot));
+        basepos = __shfl(basepos, 0);
+        if (hit) {
+          unsigned pos = basepos + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
+          if (pos < capacity) out[pos] = Cand0{z, x, y, (float)cmax};
+          else ctl->overflow = 1;
+        }
+      }
+    }
+  }
+}
+
+template <class T> __device__ __forceinline__ float quant(double v);
+template <> __device__ __forceinline__ float quant<float>(double v) { return (float)v; }
+template <> __device__ __forceinline__ float quant<uint16_t>(double v) { return (float)(uint16_t)(int)v; }
+
+struct TapsD { double w[64]; };   // w[j] = tap at offset j (symmetric), j <= R
+
+// One wave per candidate (grid-stride): exact min_im at the candidate and its 26 neighbours from the axis-0 result zp.
+//   rows r = 3 * dz + dx (z' = clamp(z + dz - 1), x' = clamp(x + dx - 1)), positions i = 0 .. 2R+2 <-> y'' = y - 1 - R + i
+//   (reflected): trow[r][i] = axis-1 pass of zp at (z', x', y''), quantised to the stack dtype (lanes run along i, so
+//   every load is a contiguous row piece); then lane k < 27 runs the axis-2 pass at (row k / 3, y' = clamp(y + k % 3 - 1))
+//   over its row in LDS.  Both passes: acc = in[0] * w0; for j = R..1: acc = acc + (in[-j] + in[+j]) * w[j]  (this file is
+//   compiled with -ffp-contract=off), as NI_Correlate1D and the dense kernels do.
+template <class T>
+__global__ __launch_bounds__(256) void bg_sparse_k(const T* __restrict__ zp, int Z, int X, int Y, TapsD taps, int R, int mode,
+                                                   const Cand0* __restrict__ c0, const SeedCtl* __restrict__ ctl0,
+                                                   unsigned cap0, double th_low, Cand* __restrict__ out, unsigned capacity,
+                                                   SeedCtl* __restrict__ ctl) {
+  constexpr int NI = 2 * 63 + 3;              // positions per row at the largest supported radius
+  __shared__ float trow[4][9][NI + 1];
+  __shared__ float mval[4][32];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned n0 = ctl0->n_cand < cap0 ? ctl0->n_cand : cap0;
+  const int ni = 2 * R + 3;
+  for (unsigned c = blockIdx.x * 4 + wv; c < n0; c += gridDim.x * 4) {
+    const Cand0 k = c0[c];
+    // ---- axis 1 on the nine rows ----
+    for (int r = 0; r < 9; ++r) {
+      const int zz = min(max(k.z + r / 3 - 1, 0), Z - 1), xx = min(max(k.x + r % 3 - 1, 0), X - 1);
+      const T* pl = zp + (size_t)zz * X * Y;
+      for (int i = lane; i < ni; i += 64) {
+        const int yy = reflect_idx(k.y - 1 - R + i, Y, mode);
+        double acc = (double)pl[(size_t)xx * Y + yy] * taps.w[0];
+#pragma unroll 4
+        for (int j = R; j >= 1; --j) {
+          const double a = (double)pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
+          const double b = (double)pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
+          acc = acc + (a + b) * taps.w[j];
+        }
+        trow[wv][r][i] = quant<T>(acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- axis 2 at the 27 neighbourhood positions ----
+    if (lane < 27) {
+      const int r = lane / 3;
+      const int yc = min(max(k.y + lane % 3 - 1, 0), Y - 1);
+      const int i0 = yc - (k.y - 1 - R);        // in [R, R + 2]
+      const float* t = trow[wv][r];
+      // positions yc + j reflect inside the image exactly as positions of the row array do: the array was built from
+      // reflected y'' = y - 1 - R + i, and reflect(yc + j) = reflect(y - 1 - R + (i0 + j))
+      double acc = (double)t[i0] * taps.w[0];
+      for (int j = R; j >= 1; --j) acc = acc + ((double)t[i0 - j] + (double)t[i0 + j]) * taps.w[j];
+      mval[wv][lane] = quant<T>(acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const float cmin = mval[wv][13];
+      float vmin = cmin;
+      for (int q = 0; q < 27; ++q) vmin = mval[wv][q] < vmin ? mval[wv][q] : vmin;
+      const float diff = k.cmax - cmin;                       // float32(max_im) - float32(min_im), fitting.py:106
+      if (vmin != cmin && (double)diff >= th_low) {
+        const unsigned pos = atomicAdd(&ctl->n_cand, 1u);
+        if (pos < capacity) out[pos] = Cand{k.z, k.x, k.y, diff};
+        else ctl->overflow = 1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <class T>
 void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, int edge, double th_low,
                    Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s, int rule = 0) {
@@ -355,10 +588,14 @@ __global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sc
 __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
                                                      const FinCtl* fc, const unsigned* __restrict__ hotcnt,
                                                      int hot_th, const unsigned* __restrict__ rank, int max_num,
-                                                     double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw) {
+                                                     double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw,
+                                                     const SeedCtl* __restrict__ lazy, unsigned cap0) {
   const unsigned n = fin_n(sctl);
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) { fcw->n_cand = sctl->n_cand; fcw->overflow = sctl->overflow; }
+  if (i == 0) {   // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
+    fcw->n_cand = sctl->n_cand;
+    fcw->overflow = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
+  }
   if (i >= n) return;
   const double th = lev.th[fc->chosen];
   const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
@@ -433,7 +670,53 @@ static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed
 
 static double now_ms() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
-static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out, SeedDev* dev) {
+int g_seed_dense = 0;   // IA3_TUNE_SEED_DENSE: 1 = always run the dense background filter (tests compare the two paths)
+void set_seed_dense(int on) { g_seed_dense = on ? 1 : 0; }
+
+constexpr unsigned LAZY_CAP = 1u << 17;   // first-stage candidates of the lazy background path (2 MB)
+
+template <class T>
+static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, const double* w, int R, int edge,
+                        double th_low, void* bnd, Cand0* c0, SeedCtl* ctl0, Cand* out, unsigned capacity, SeedCtl* ctl,
+                        hipStream_t s, int stage) {
+  const int B = R <= 32 ? 32 : 64;
+  const int nbx = (X + B - 1) / B, nby = (Y + B - 1) / B;
+  const size_t nb = (size_t)Z * nbx * nby;
+  float* bmin = (float*)bnd;
+  float* babs = bmin + nb;
+  double* lb = (double*)(babs + nb + (nb & 1));
+  if (stage == 0) {   // needs only the axis-0 result: queued before the front filter is joined
+    ProfScope ps("seed_blockmin");
+    dim3 g((unsigned)((Y + 255) / 256), (unsigned)nbx, (unsigned)Z);
+    if (B == 32) hipLaunchKernelGGL((blockmin_k<T, 32>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    else hipLaunchKernelGGL((blockmin_k<T, 64>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    hipLaunchKernelGGL(blockbound_k, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, (const float*)bmin, (const float*)babs,
+                       Z, nbx, nby, (int)(sizeof(T) == 2), lb);
+    return;
+  }
+  {
+    ProfScope ps("seed_detect");
+    constexpr int ZT = 64;
+    const unsigned tiles = (unsigned)((Y + 63) / 64) * (unsigned)((X + 15) / 16);
+    dim3 gt(8 * ((tiles + 7) / 8), 1, (unsigned)((Z + ZT - 1) / ZT));
+    const double th_test = th_low - fabs(th_low) * 1e-6 - 1e-300;   // the exact test is made in float32: keep the bound test looser
+    if (B == 32)
+      hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 32>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
+                         th_test, c0, LAZY_CAP, ctl0);
+    else
+      hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 64>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
+                         th_test, c0, LAZY_CAP, ctl0);
+  }
+  {
+    ProfScope ps("seed_sparse_bg");
+    TapsD t;
+    for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
+    hipLaunchKernelGGL((bg_sparse_k<T>), dim3(2048), dim3(256), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
+                       (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
+  }
+}
+
+static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out, SeedDev* dev, bool force_dense = false) {
   hipStream_t s = stream();
   const bool dbg = getenv("IA3_DEBUG_TIMING") != nullptr;
   const double t0 = now_ms();
@@ -449,12 +732,28 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     double t = p.th_seed * (1 - (double)i / (double)niter);
     lev.th[i] = p.th_compare_f32 ? (double)(float)t : t;
   }
+  double th_low = lev.th[0];
+  for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
   // filtered stacks
   Scratch a(bytes), b(bytes), tmp(bytes), tmp2(bytes);   // tmp2: ping-pong buffer of the front filter (own stream)
   if (!a.p || !b.p || !tmp.p || !tmp2.p) return IA3_ENOMEM;
   const void* maxim = im->d;
   const void* minim = im->d;
-  std::vector<double> w; int R, rc;
+  std::vector<double> w, wb; int R, Rb = 0, rc;
+  if (p.background_gfilt_size > 0) {
+    if (p.w_back) { wb.assign(p.w_back, p.w_back + 2 * p.r_back + 1); Rb = p.r_back; }
+    else gaussian_taps(p.background_gfilt_size, 4.0, wb, Rb);
+  }
+  // lazy background filter (see the kernels above): axis 0 everywhere, axes 1 and 2 only around candidate maxima
+  bool lazy = !force_dense && !g_seed_dense && p.filt_size == 3 && p.background_gfilt_size > 0 && Rb > 3 && Rb <= 63;
+  if (lazy)
+    for (int j = 0; j <= 2 * Rb; ++j)   // the bound needs non-negative taps (any Gaussian; explicit taps are checked)
+      if (!(wb[j] >= 0.0) || wb[j] != wb[2 * Rb - j]) lazy = false;
+  const int Bk = Rb <= 32 ? 32 : 64;
+  const size_t nblk = (size_t)Z * ((X + Bk - 1) / Bk) * ((Y + Bk - 1) / Bk);
+  Scratch bnd(lazy ? (nblk + (nblk & 1)) * 2 * sizeof(float) + nblk * sizeof(double) : 256);
+  Scratch c0buf(lazy ? (size_t)LAZY_CAP * sizeof(Cand0) : 256);
+  if (!bnd.p || !c0buf.p) return IA3_ENOMEM;
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
   // background (long, f64-VALU-bound) one; the detector waits for both.
   bool forked = false;
@@ -470,30 +769,37 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     maxim = a.p;
   }
   if (p.background_gfilt_size > 0) {
-    if (p.w_back) { w.assign(p.w_back, p.w_back + 2 * p.r_back + 1); R = p.r_back; }
-    else gaussian_taps(p.background_gfilt_size, 4.0, w, R);
-    rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, b.p, tmp.p);
+    rc = gaussian3d(im->d, im->dtype, Z, X, Y, wb.data(), Rb, IA3_MODE_REFLECT, b.p, tmp.p, lazy ? 1 : 3);
     if (rc) { if (forked) aux_join(); return rc; }
     minim = b.p;
+    if (lazy) {
+      if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+      else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+    }
   }
   if (forked) { rc = aux_join(); if (rc) return rc; }
   const double t1 = now_ms();
-  double th_low = lev.th[0];
-  for (int i = 1; i < lev.n; ++i) th_low = lev.th[i] < th_low ? lev.th[i] : th_low;
-  // device buffer = [SeedCtl | Cand x capacity]; the header and the first FIRST candidates come back in ONE
-  // copy (the common case: a few thousand seeds), the rest only if there are more
+  // device buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity]; the header and the first FIRST candidates come back
+  // in ONE copy (the common case: a few thousand seeds), the rest only if there are more
   unsigned capacity = 1u << 20;
   constexpr unsigned FIRST = 8192;
+  constexpr size_t HDR = 2 * sizeof(SeedCtl);
   std::vector<Cand> cand;
-  std::vector<char> hbuf(sizeof(SeedCtl) + (size_t)FIRST * sizeof(Cand));
-  SeedCtl hctl;
+  std::vector<char> hbuf(HDR + (size_t)FIRST * sizeof(Cand));
+  SeedCtl hctl, hlazy;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    Scratch buf(sizeof(SeedCtl) + (size_t)capacity * sizeof(Cand));
+    Scratch buf(HDR + (size_t)capacity * sizeof(Cand));
     if (!buf.p) return IA3_ENOMEM;
     SeedCtl* dctl = (SeedCtl*)buf.p;
-    Cand* dcand = (Cand*)((char*)buf.p + sizeof(SeedCtl));
-    IA3_HIP(hipMemsetAsync(dctl, 0, sizeof(SeedCtl), s));
-    {
+    SeedCtl* dlazy = dctl + 1;
+    Cand* dcand = (Cand*)((char*)buf.p + HDR);
+    IA3_HIP(hipMemsetAsync(dctl, 0, HDR, s));
+    if (lazy) {
+      if (im->dtype == IA3_F32)
+        launch_lazy<float>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1);
+      else
+        launch_lazy<uint16_t>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1);
+    } else {
       ProfScope ps("seed_detect");
       if (im->dtype == IA3_F32)
         launch_detect<float>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, dcand, capacity, dctl, s);
@@ -521,13 +827,18 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
           hipLaunchKernelGGL(fin_hot_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc, hot);
         hipLaunchKernelGGL(fin_rank_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, fc, (const unsigned*)hot, hot_th, rank);
         hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_CAP / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc,
-                           (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h), fc);
+                           (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h), fc,
+                           lazy ? (const SeedCtl*)dlazy : (const SeedCtl*)nullptr, LAZY_CAP);
       }
       FinCtl hfc;
       fe = hipGetLastError();
       if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
       if (fe == hipSuccess) fe = hipStreamSynchronize(s);
       if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe)); }
+      if (hfc.overflow & 2u) {   // more first-stage candidates than the lazy path is sized for: dense filter instead
+        ws_put(fin);
+        return dog_seed_impl(im, p, out, dev, true);
+      }
       hctl.n_cand = hfc.n_cand; hctl.overflow = hfc.overflow;
       if (hctl.n_cand <= FIN_CAP && !hctl.overflow) {
         int n = (int)hfc.n_alive;
@@ -546,10 +857,12 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     IA3_HIP(hipMemcpyAsync(hbuf.data(), buf.p, hbuf.size(), hipMemcpyDeviceToHost, s));
     IA3_HIP(hipStreamSynchronize(s));
     memcpy(&hctl, hbuf.data(), sizeof(SeedCtl));
+    memcpy(&hlazy, hbuf.data() + sizeof(SeedCtl), sizeof(SeedCtl));
+    if (lazy && (hlazy.overflow || hlazy.n_cand > LAZY_CAP)) return dog_seed_impl(im, p, out, dev, true);
     if (hctl.n_cand <= capacity) {
       cand.resize(hctl.n_cand);
       const unsigned nfirst = hctl.n_cand < FIRST ? hctl.n_cand : FIRST;
-      if (nfirst) memcpy(cand.data(), hbuf.data() + sizeof(SeedCtl), (size_t)nfirst * sizeof(Cand));
+      if (nfirst) memcpy(cand.data(), hbuf.data() + HDR, (size_t)nfirst * sizeof(Cand));
       if (hctl.n_cand > FIRST) {
         IA3_HIP(hipMemcpyAsync(cand.data() + FIRST, dcand + FIRST, (size_t)(hctl.n_cand - FIRST) * sizeof(Cand), hipMemcpyDeviceToHost, s));
         IA3_HIP(hipStreamSynchronize(s));

@@ -59,6 +59,10 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_UPLOAD_THREADS: helper threads that copy a host array into the pinned staging ring of ia3_stack_upload
  * (default 4, environment IA3_UPLOAD_THREADS); 0 = one plain hipMemcpyAsync from pageable memory. */
 #define IA3_TUNE_UPLOAD_THREADS 3
+/* IA3_TUNE_SEED_DENSE: 1 = get_seeds always runs all three passes of the background filter on the whole stack; 0
+ * (default) = the lazy form: the axis-0 pass everywhere, the other two only around candidate maxima (seed.hip).  Seeds
+ * are identical either way. */
+#define IA3_TUNE_SEED_DENSE 4
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

@@ -437,6 +437,7 @@ class iter_fit_seed_points(object):
             self.ps, self.ims_rec, self.centers_fit, self.success, self.gparms = [], [], [], [], []
             self.im_subtr = np.array(self.im, dtype=float)
             self.nfev_last = np.zeros(len(self.centers), dtype=int)   # evaluations of each seed's latest fit
+            self.nfev_peak = np.zeros(len(self.centers), dtype=int)   # ... and of its longest fit so far
             self.tree = cKDTree(self.centers)
             for ic, (zc, xc, yc) in enumerate(self.centers):
                 z, x, y = int(zc) + self.zb, int(xc) + self.xb, int(yc) + self.yb
@@ -448,6 +449,7 @@ class iter_fit_seed_points(object):
                 obj = self._gfit(im_, X, [zc, xc, yc], self.min_delta_center)
                 obj.fit()
                 self.nfev_last[ic] = getattr(obj, "nfev", 0)
+                self.nfev_peak[ic] = max(self.nfev_peak[ic], self.nfev_last[ic])
                 self.gparms.append([im_, X, [zc, xc, yc]])
                 self.success.append(obj.success)
                 if obj.success:
@@ -481,6 +483,7 @@ class iter_fit_seed_points(object):
                     obj = self._gfit(im_, X, [zc, xc, yc], self.max_delta_center)
                     obj.fit()
                     self.nfev_last[ic] = getattr(obj, "nfev", 0)
+                    self.nfev_peak[ic] = max(self.nfev_peak[ic], self.nfev_last[ic])
                     self.success[ic] = obj.success
                     if obj.success:
                         im_rec = obj.get_im()

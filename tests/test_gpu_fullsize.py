@@ -48,7 +48,14 @@ def test_bench_fov_window_vs_oracle(dtype):
     fo.firstfit()
     fo.repeatfit()
     po = np.array(fo.ps, dtype=np.float64)
-    stuck = fo.nfev_last >= 1000
+    # a fit that stops at maxfev ends wherever its last trust-region step happened to land, and every seed whose ball
+    # overlaps it (within 2 r) then sees a different residual image: exclude those seeds and their neighbours
+    from scipy.spatial import cKDTree
+    stuck = fo.nfev_peak >= 1000
+    for _ in range(3):
+        near = cKDTree(so[:, :3]).query_ball_point(so[stuck, :3], 10.0 + 1e-9)
+        if len(near):
+            stuck[np.unique(np.concatenate([np.asarray(q, dtype=int) for q in near]))] = True
     assert len(so) > 1200
     # ---- device on the same window: everything must agree -------------------------------------------------------------
     sw = get_seeds(win, th_seed=600.0, return_h=True)
@@ -59,7 +66,7 @@ def test_bench_fov_window_vs_oracle(dtype):
     assert np.isnan(pw).any(1).sum() == np.isnan(po).any(1).sum()
     rel = _rel(pw[ok], po[ok])
     assert rel.max() <= 1e-4, rel.max()
-    assert stuck.sum() <= (0 if dtype == np.float32 else 40)
+    assert stuck.sum() <= (0 if dtype == np.float32 else 60)
     # ---- device on the whole FOV: production-size launches ----------------------------------------------------------
     sf = get_seeds(im, th_seed=600.0, return_h=True)
     in_f = (sf[:, 1] < INNER) & (sf[:, 2] < INNER)
@@ -75,7 +82,6 @@ def test_bench_fov_window_vs_oracle(dtype):
                                         C.byref(n_seeds), C.byref(n_it)))
     t = rows[:n_rows.value].astype(np.float64)
     assert n_seeds.value == len(sf)
-    from scipy.spatial import cKDTree
     sel = np.where(ok & in_o & (so[:, 1] < INNER - 16) & (so[:, 2] < INNER - 16))[0]
     d, j = cKDTree(t[:, 1:4]).query(po[sel, 1:4])
     assert len(sel) > 1000 and d.max() < 1e-3, d.max()
@@ -211,3 +217,53 @@ def test_dense_cluster_beyond_neighbour_list_vs_oracle():
     assert np.nanmax(_rel(first[-3:], first_o[-3:])) <= 1e-4
     assert np.nanmax(_rel(p[-3:], po[-3:])) <= 1e-4
     assert np.nanmedian(_rel(p[conv], po[conv])) <= 1e-4
+
+
+def _seed_dense(on):
+    from imageanalysis3_amd import _lib as L
+    L.check(L.lib().ia3_set_tuning(4, 1 if on else 0))   # IA3_TUNE_SEED_DENSE
+
+
+def test_lazy_background_filter_equals_dense_filter():
+    """get_seeds with the lazy background filter (axis-0 pass everywhere, axes 1 and 2 only around candidate maxima,
+    seed.hip) against the same call with all three passes on the whole stack: identical tables (coordinates, heights,
+    order), on the golden cases, ragged shapes, small stacks whose reflect border wraps several times, a filter radius
+    above 32 (64-voxel bound blocks), adversarial values (plateaus, mixed signs, zeros) and a field with more
+    first-stage candidates than the lazy path holds (falls back to the dense filter)."""
+    from conftest import build_case
+    from imageanalysis3_amd import synth
+    from imageanalysis3_amd.spot_tools.fitting import get_seeds
+    rng = np.random.RandomState(3)
+    cases = []
+    for name in ("c1_f32", "c1_u16", "m_f32", "edge_f32", "hot_u16", "clu_f32"):
+        cases.append((name, build_case(name), dict(th_seed=600.0)))
+    for shape, dt in (((9, 45, 83), np.float32), ((30, 70, 130), np.uint16), ((12, 33, 257), np.float32),
+                      ((5, 31, 65), np.uint16), ((64, 33, 40), np.float32)):
+        im, c, h = synth.make_fov(shape, 12, 17, dtype=dt, margin=(2, 6, 6), layout="uniform")
+        cases.append(("ragged%s" % (shape,), im, dict(th_seed=300.0)))
+    im, c, h = synth.make_fov((24, 200, 200), 40, 5, dtype=np.uint16)
+    cases.append(("sigma12", im, dict(th_seed=400.0, background_gfilt_size=12.0)))          # R = 48
+    cases.append(("lowest_level", im, dict(th_seed=60000.0, dynamic_niters=10)))             # nothing at the top levels
+    steps = (np.arange(24 * 96 * 96).reshape(24, 96, 96) // 517 % 7 * 500 + 300).astype(np.uint16)
+    steps[10:13, 40:43, 50:53] += 2000
+    cases.append(("plateaus_u16", steps, dict(th_seed=200.0)))
+    mixed = rng.normal(0, 50, size=(20, 90, 110)).astype(np.float32)
+    mixed[8:11, 30:33, 60:63] += 900
+    mixed[5, 70, 20] = -4000.0
+    cases.append(("mixed_sign_f32", mixed, dict(th_seed=150.0)))
+    zeros = np.zeros((16, 64, 64), np.float32)
+    zeros[6:9, 20:23, 30:33] = 800
+    cases.append(("zeros_f32", zeros, dict(th_seed=100.0)))
+    noise = rng.normal(400, 60, size=(30, 512, 512)).astype(np.float32)
+    cases.append(("overflow_noise", noise, dict(th_seed=5.0, use_dynamic_th=False, remove_hot_pixel=False)))
+    try:
+        for name, im, kw in cases:
+            _seed_dense(True)
+            dense = get_seeds(im, return_h=True, **kw)
+            _seed_dense(False)
+            lazy = get_seeds(im, return_h=True, **kw)
+            assert dense.shape == lazy.shape and np.array_equal(dense, lazy), (name, dense.shape, lazy.shape)
+            if name not in ("zeros_f32", "lowest_level"):
+                assert len(dense) > 0, name
+    finally:
+        _seed_dense(False)
