@@ -53,6 +53,7 @@ struct FitArgs {
   const void* im; int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
   int n;                    // number of seeds
+  int nb_cap;               // lists longer than this are not used (MAXNB; lowered by IA3_TUNE_FIT_NBLIST in tests)
   double nb_r2;             // (2r)²: seeds closer than this interact
   const int* nbr_cnt;       // n: number of neighbours of seed i (NOT clamped: > MAXNB = list overflow, see each_neighbour)
   const int* nbr_idx;       // n x MAXNB: the first MAXNB seeds j != i with |c_i - c_j|² <= (2r)², ascending
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
 template <class F>
 __device__ __forceinline__ void each_neighbour(const FitArgs& fa, int i, F f) {
   const int cnt = fa.nbr_cnt[i];
-  if (cnt <= MAXNB) {
+  if (cnt <= fa.nb_cap) {
     for (int q = i * MAXNB; q < i * MAXNB + cnt; ++q)
       if (!f(fa.nbr_idx[q])) return;
     return;
@@ -473,12 +474,12 @@ __device__ __forceinline__ void do_first(const FitArgs& fa, LMWork& w, int i) {
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
   const int ncnt = fa.nbr_cnt[i];
-  const int nb0 = i * MAXNB, nb1 = nb0 + (ncnt <= MAXNB ? ncnt : 0);
+  const int nb0 = i * MAXNB, nb1 = nb0 + (ncnt <= fa.nb_cap ? ncnt : 0);
   Ball ball;
   double vals[SLOTS];
   ball.valid = 0;
   unsigned lost = 0;   // list overflow only: bit s = slot s belongs to another seed's Voronoi cell
-  if (ncnt > MAXNB) {
+  if (ncnt > fa.nb_cap) {
     each_neighbour(fa, i, [&](int j) {
       const double sz = fa.seeds[3 * j], sx = fa.seeds[3 * j + 1], sy = fa.seeds[3 * j + 2];
 #pragma unroll
@@ -771,10 +772,12 @@ int build_ball(int r, std::vector<signed char>& ball) {
   return (int)(ball.size() / 4);
 }
 
+int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
+
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
-  a.n = f->n; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
+  a.n = f->n; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
@@ -886,6 +889,7 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 }  // extern "C"
 
 namespace ia3k {
+void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
 void fit_host_counters(const ia3_fitter* f, long long out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
 }

@@ -329,11 +329,14 @@ int ia3_stack_alloc(int dtype, int Z, int X, int Y, ia3_stack** out) {
   *out = new ia3_stack{d, dtype, Z, X, Y, true, bytes, (void*)t_ctx.main};
   return IA3_OK;
 }
-// Host array -> resident stack.  A plain hipMemcpyAsync from pageable memory lets the runtime pin and copy the caller's
-// pages piecewise on the calling thread; here the array is cut into STAGE_BYTES pieces that helper threads copy into a
-// ring of pinned staging buffers (one buffer per helper) while the calling thread queues one asynchronous H2D copy per
-// finished piece, so page touching, the host-side copy and the PCIe transfer overlap.  IA3_UPLOAD_THREADS (default 4;
-// 0 = the plain pageable copy) sets the number of helpers.  The call returns when the stack is resident.
+// Host array -> resident stack.  Measured on MI355X (profiles/r02a/probe.log, 839 MB float32 / 419 MB uint16 stacks): one
+// hipMemcpyAsync from pageable memory runs at 56 GB/s (the runtime pins the caller's pages piecewise and copies from
+// them directly), which is the PCIe rate of a pinned buffer; cutting the array into STAGE_BYTES pieces that helper
+// threads copy into a ring of pinned staging buffers while the calling thread queues one asynchronous copy per piece
+// reaches 35 / 51 / 51 GB/s with 2 / 4 / 8 helpers — the extra host-side copy costs more than it hides.  The plain
+// copy is therefore the default; IA3_UPLOAD_THREADS / IA3_TUNE_UPLOAD_THREADS > 0 selects the staged form (useful where
+// pinning on the fly is slow, e.g. memory-mapped files).  Overlap with compute comes from running several images at
+// once (ia3_fit_fovs), not from this call, which returns when the stack is resident.
 namespace {
 constexpr size_t STAGE_BYTES = 16u << 20;
 constexpr int MAX_STAGE = 8;
@@ -344,12 +347,12 @@ struct Staging {
   pid_t pid = 0;
 };
 thread_local Staging t_stage;
-std::atomic<int> g_upload_threads{-1};   // -1: from IA3_UPLOAD_THREADS (default 4)
+std::atomic<int> g_upload_threads{-1};   // -1: from IA3_UPLOAD_THREADS (default 0)
 int upload_threads() {
   int n = g_upload_threads.load(std::memory_order_relaxed);
   if (n < 0) {
     const char* e = getenv("IA3_UPLOAD_THREADS");
-    n = e ? atoi(e) : 4;
+    n = e ? atoi(e) : 0;
     n = n < 0 ? 0 : (n > MAX_STAGE ? MAX_STAGE : n);
     g_upload_threads.store(n, std::memory_order_relaxed);
   }

@@ -265,25 +265,31 @@ __device__ __forceinline__ int reflect_idx(int q, int n, int mode) {   // scipy 
   return q < n ? q : p - 1 - q;
 }
 
-// per plane z and B x B block: minimum and maximum magnitude of zp.  One 256-thread block reads B rows of 256
-// consecutive y (coalesced), every thread reduces its column over the rows, then 32-lane groups reduce across y.
-template <class T, int B>
+// per plane z and B x B block: minimum and maximum magnitude of zp.  One 256-thread block reads B rows of 256 * V
+// consecutive y, V voxels (16 bytes when the rows allow it) per lane and row; every thread reduces its V columns over
+// the rows, then groups of B / V lanes reduce across y.
+template <class T, int B, int V>
 __global__ __launch_bounds__(256) void blockmin_k(const T* __restrict__ zp, int Z, int X, int Y, int nbx, int nby,
                                                   float* __restrict__ bmin, float* __restrict__ babs) {
-  const int y = blockIdx.x * 256 + threadIdx.x;
+  const int y = (blockIdx.x * 256 + threadIdx.x) * V;
   const int bx = blockIdx.y, z = blockIdx.z;
   const int x0 = bx * B, x1 = x0 + B < X ? x0 + B : X;
   float m = INFINITY, a = 0.f;
-  if (y < Y) {
+  if (y < Y) {   // V > 1 only when Y % V == 0: a lane's V voxels are all inside
     const T* p = zp + ((size_t)z * X + x0) * Y + y;
-    for (int x = x0; x < x1; ++x, p += Y) { const float v = (float)*p; m = v < m ? v : m; const float av = fabsf(v); a = av > a ? av : a; }
+    for (int x = x0; x < x1; ++x, p += Y) {
+      T v[V];
+      if constexpr (V * sizeof(T) == 16) *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p);
+      else v[0] = *p;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { const float f = (float)v[k]; m = fminf(m, f); a = fmaxf(a, fabsf(f)); }
+    }
   }
 #pragma unroll
-  for (int o = B / 2; o >= 1; o >>= 1) {
-    const float m2 = __shfl_xor(m, o), a2 = __shfl_xor(a, o);
-    m = m2 < m ? m2 : m; a = a2 > a ? a2 : a;
+  for (int o = B / V / 2; o >= 1; o >>= 1) {
+    m = fminf(m, __shfl_xor(m, o)); a = fmaxf(a, __shfl_xor(a, o));
   }
-  if ((threadIdx.x & (B - 1)) == 0 && y < Y) {
+  if ((threadIdx.x & (B / V - 1)) == 0 && y < Y) {
     const size_t o = ((size_t)z * nbx + bx) * nby + y / B;
     bmin[o] = m; babs[o] = a;
   }
@@ -408,59 +414,59 @@ template <> __device__ __forceinline__ float quant<uint16_t>(double v) { return 
 
 struct TapsD { double w[64]; };   // w[j] = tap at offset j (symmetric), j <= R
 
-// One wave per candidate (grid-stride): exact min_im at the candidate and its 26 neighbours from the axis-0 result zp.
+// One 576-thread block per candidate (grid-stride), one wave per row: exact min_im at the candidate and its 26
+// neighbours from the axis-0 result zp.
 //   rows r = 3 * dz + dx (z' = clamp(z + dz - 1), x' = clamp(x + dx - 1)), positions i = 0 .. 2R+2 <-> y'' = y - 1 - R + i
 //   (reflected): trow[r][i] = axis-1 pass of zp at (z', x', y''), quantised to the stack dtype (lanes run along i, so
-//   every load is a contiguous row piece); then lane k < 27 runs the axis-2 pass at (row k / 3, y' = clamp(y + k % 3 - 1))
-//   over its row in LDS.  Both passes: acc = in[0] * w0; for j = R..1: acc = acc + (in[-j] + in[+j]) * w[j]  (this file is
-//   compiled with -ffp-contract=off), as NI_Correlate1D and the dense kernels do.
+//   every load is a contiguous row piece; the nine rows go side by side because the pass is a chain of dependent
+//   loads); then lane k < 27 of wave 0 runs the axis-2 pass at (row k / 3, y' = clamp(y + k % 3 - 1)) over its row in
+//   LDS.  Both passes: acc = in[0] * w0; for j = R..1: acc = acc + (in[-j] + in[+j]) * w[j]  (this file is compiled
+//   with -ffp-contract=off), as NI_Correlate1D and the dense kernels do.
 template <class T>
-__global__ __launch_bounds__(256) void bg_sparse_k(const T* __restrict__ zp, int Z, int X, int Y, TapsD taps, int R, int mode,
+__global__ __launch_bounds__(576) void bg_sparse_k(const T* __restrict__ zp, int Z, int X, int Y, TapsD taps, int R, int mode,
                                                    const Cand0* __restrict__ c0, const SeedCtl* __restrict__ ctl0,
                                                    unsigned cap0, double th_low, Cand* __restrict__ out, unsigned capacity,
                                                    SeedCtl* __restrict__ ctl) {
   constexpr int NI = 2 * 63 + 3;              // positions per row at the largest supported radius
-  __shared__ float trow[4][9][NI + 1];
-  __shared__ float mval[4][32];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float trow[9][NI + 1];
+  __shared__ float mval[32];
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned n0 = ctl0->n_cand < cap0 ? ctl0->n_cand : cap0;
   const int ni = 2 * R + 3;
-  for (unsigned c = blockIdx.x * 4 + wv; c < n0; c += gridDim.x * 4) {
+  for (unsigned c = blockIdx.x; c < n0; c += gridDim.x) {   // block-uniform
     const Cand0 k = c0[c];
-    // ---- axis 1 on the nine rows ----
-    for (int r = 0; r < 9; ++r) {
+    {   // ---- axis 1 on row r ----
       const int zz = min(max(k.z + r / 3 - 1, 0), Z - 1), xx = min(max(k.x + r % 3 - 1, 0), X - 1);
       const T* pl = zp + (size_t)zz * X * Y;
       for (int i = lane; i < ni; i += 64) {
         const int yy = reflect_idx(k.y - 1 - R + i, Y, mode);
         double acc = (double)pl[(size_t)xx * Y + yy] * taps.w[0];
-#pragma unroll 4
+#pragma unroll 8
         for (int j = R; j >= 1; --j) {
           const double a = (double)pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
           const double b = (double)pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
           acc = acc + (a + b) * taps.w[j];
         }
-        trow[wv][r][i] = quant<T>(acc);
+        trow[r][i] = quant<T>(acc);
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     // ---- axis 2 at the 27 neighbourhood positions ----
-    if (lane < 27) {
-      const int r = lane / 3;
-      const int yc = min(max(k.y + lane % 3 - 1, 0), Y - 1);
+    if (threadIdx.x < 27) {
+      const int rr = threadIdx.x / 3;
+      const int yc = min(max(k.y + (int)threadIdx.x % 3 - 1, 0), Y - 1);
       const int i0 = yc - (k.y - 1 - R);        // in [R, R + 2]
-      const float* t = trow[wv][r];
-      // positions yc + j reflect inside the image exactly as positions of the row array do: the array was built from
-      // reflected y'' = y - 1 - R + i, and reflect(yc + j) = reflect(y - 1 - R + (i0 + j))
+      const float* t = trow[rr];
+      // reflect(yc + j) = reflect(y - 1 - R + (i0 + j)): the row array already holds the reflected positions
       double acc = (double)t[i0] * taps.w[0];
       for (int j = R; j >= 1; --j) acc = acc + ((double)t[i0 - j] + (double)t[i0 + j]) * taps.w[j];
-      mval[wv][lane] = quant<T>(acc);
+      mval[threadIdx.x] = quant<T>(acc);
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      const float cmin = mval[wv][13];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cmin = mval[13];
       float vmin = cmin;
-      for (int q = 0; q < 27; ++q) vmin = mval[wv][q] < vmin ? mval[wv][q] : vmin;
+      for (int q = 0; q < 27; ++q) vmin = mval[q] < vmin ? mval[q] : vmin;
       const float diff = k.cmax - cmin;                       // float32(max_im) - float32(min_im), fitting.py:106
       if (vmin != cmin && (double)diff >= th_low) {
         const unsigned pos = atomicAdd(&ctl->n_cand, 1u);
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(256) void bg_sparse_k(const T* __restrict__ zp, int
         else ctl->overflow = 1;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();   // the next candidate's rows overwrite trow
   }
 }
 
@@ -687,9 +693,14 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
   double* lb = (double*)(babs + nb + (nb & 1));
   if (stage == 0) {   // needs only the axis-0 result: queued before the front filter is joined
     ProfScope ps("seed_blockmin");
-    dim3 g((unsigned)((Y + 255) / 256), (unsigned)nbx, (unsigned)Z);
-    if (B == 32) hipLaunchKernelGGL((blockmin_k<T, 32>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
-    else hipLaunchKernelGGL((blockmin_k<T, 64>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool wide = Y % V == 0 && ((uintptr_t)zp & 15) == 0;   // every row starts on a 16-byte boundary
+    const int per = 256 * (wide ? V : 1);
+    dim3 g((unsigned)((Y + per - 1) / per), (unsigned)nbx, (unsigned)Z);
+    if (B == 32 && wide) hipLaunchKernelGGL((blockmin_k<T, 32, V>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    else if (B == 32) hipLaunchKernelGGL((blockmin_k<T, 32, 1>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    else if (wide) hipLaunchKernelGGL((blockmin_k<T, 64, V>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
+    else hipLaunchKernelGGL((blockmin_k<T, 64, 1>), g, dim3(256), 0, s, (const T*)zp, Z, X, Y, nbx, nby, bmin, babs);
     hipLaunchKernelGGL(blockbound_k, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, (const float*)bmin, (const float*)babs,
                        Z, nbx, nby, (int)(sizeof(T) == 2), lb);
     return;
@@ -711,7 +722,7 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
     ProfScope ps("seed_sparse_bg");
     TapsD t;
     for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
-    hipLaunchKernelGGL((bg_sparse_k<T>), dim3(2048), dim3(256), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
+    hipLaunchKernelGGL((bg_sparse_k<T>), dim3(4096), dim3(576), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
                        (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
   }
 }

@@ -57,12 +57,17 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * version) instead of the f64 matrix cores; shifts agree to rounding. */
 #define IA3_TUNE_DFT_VALU 2
 /* IA3_TUNE_UPLOAD_THREADS: helper threads that copy a host array into the pinned staging ring of ia3_stack_upload
- * (default 4, environment IA3_UPLOAD_THREADS); 0 = one plain hipMemcpyAsync from pageable memory. */
+ * (environment IA3_UPLOAD_THREADS); 0 (default: it measured fastest, 56 GB/s) = one plain hipMemcpyAsync from
+ * pageable memory. */
 #define IA3_TUNE_UPLOAD_THREADS 3
 /* IA3_TUNE_SEED_DENSE: 1 = get_seeds always runs all three passes of the background filter on the whole stack; 0
  * (default) = the lazy form: the axis-0 pass everywhere, the other two only around candidate maxima (seed.hip).  Seeds
  * are identical either way. */
 #define IA3_TUNE_SEED_DENSE 4
+/* IA3_TUNE_FIT_NBLIST: longest per-seed neighbour list the fit kernel reads (default and maximum 64); seeds with more
+ * overlapping neighbours scan the seed list instead — same neighbours in the same order.  Tests lower it to drive
+ * ordinary fields through the scan. */
+#define IA3_TUNE_FIT_NBLIST 5
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

@@ -14,6 +14,7 @@ from test_gpu_parity import crc, seed_set
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPE = (50, 2048, 2048)
 WIN = 1088          # bench.py's cpu_baseline sample: [0:50, 0:1088, 0:1088]
 INNER = 1024        # seeds with x, y < INNER see the same filters in the window and in the whole FOV (halo 30 + 3)
@@ -65,6 +66,10 @@ def test_bench_fov_window_vs_oracle(dtype):
     ok = ~stuck & ~np.isnan(po).any(1)
     assert np.isnan(pw).any(1).sum() == np.isnan(po).any(1).sum()
     rel = _rel(pw[ok], po[ok])
+    if rel.max() > 1e-4:   # leave the evidence where gpurun collects it
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "window_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw,
+                 nfev_peak=fo.nfev_peak, nfev_last=fo.nfev_last, stuck=stuck)
     assert rel.max() <= 1e-4, rel.max()
     assert stuck.sum() <= (0 if dtype == np.float32 else 60)
     # ---- device on the whole FOV: production-size launches ----------------------------------------------------------
@@ -110,7 +115,7 @@ def test_drift_crops_full_size_vs_oracle():
         assert abs(eg - eo) <= 1e-6 * max(1.0, abs(eo))
     drift, flag = A.align_image(src, ref, crop_list=None, use_autocorr=True, drift_channel='488',
                                 all_channels=['488'], verbose=False)
-    do, fl = O.align_image(src, ref, use_autocorr=True)
+    do, fl = O.align_image(src, ref, use_autocorr=True, normalization=None)
     assert flag == fl == 0
     assert np.abs(drift - do).max() <= 1e-9, (drift, do)
     assert np.abs(drift - true).max() < 0.06, (drift, true)
@@ -183,40 +188,65 @@ def test_correct_fov_image_chain_mid_and_production_width_vs_oracle(shape, highp
         assert crc(a) == crc(b), int((a != b).sum())
 
 
-def test_dense_cluster_beyond_neighbour_list_vs_oracle():
-    """More than 64 seeds within 2 r of one seed (the fixed neighbour list of fit.hip overflows): the kernel scans the
-    seed list for those seeds instead; the reference has no cap (Fitting_v4.py:601,612).  Rows against the oracle with
-    the kernel's tie rule."""
+def test_neighbour_scan_equals_neighbour_list():
+    """Seeds with more overlapping neighbours than the fixed per-seed list of fit.hip holds (64) scan the seed list
+    instead (the reference has no cap: Fitting_v4.py:601,612 query a cKDTree).  With the list capacity turned down to 2
+    the 333-seed clustered field takes that path for most seeds: tables, sweep count and Voronoi cell sizes must be
+    those of the list path bit for bit."""
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
+    from imageanalysis3_amd.spot_tools.fitting import get_seeds
+    im, c, h = synth.make_fov((50, 512, 512), 400, 3, layout="clustered", n_territories=16)
+    seeds = get_seeds(im, th_seed=600.0)
+    res = []
+    try:
+        for cap in (64, 2, 0):
+            L.check(L.lib().ia3_set_tuning(5, cap))      # IA3_TUNE_FIT_NBLIST
+            f = iter_fit_seed_points(im, seeds.T)
+            f.firstfit()
+            first, nvox = np.array(f.ps), np.array(f.nvox)
+            f.repeatfit()
+            res.append((first, nvox, np.array(f.ps), f.n_iter))
+    finally:
+        L.check(L.lib().ia3_set_tuning(5, 64))
+    assert res[0][3] >= 4
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and r[3] == res[0][3]
+        assert np.array_equal(r[0], res[0][0], equal_nan=True) and np.array_equal(r[2], res[0][2], equal_nan=True)
+
+
+def test_dense_grid_beyond_neighbour_list_vs_oracle():
+    """A 7 x 7 x 7 lattice of narrow spots 3.5 voxels apart: the inner seeds have ~90 other seeds within 2 r = 10
+    voxels, more than the neighbour list holds.  Voronoi cell sizes exact, sweep count equal, rows against the oracle
+    (kernel's tie rule)."""
     import np_oracle as O
     from imageanalysis3_amd import synth
     from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
-    im, c, h = synth.make_fov((24, 96, 96), 20, 5, layout="uniform", margin=(5, 10, 10))
-    rng = np.random.RandomState(7)
-    core = np.array([12, 48, 48]) + rng.randint(-3, 4, size=(400, 3)) * np.array([1, 1, 1])
-    core = np.unique(core, axis=0)[:90].astype(np.float64)          # 90 distinct integer seeds inside a 7^3 cube
-    halo = np.array([[12., 20., 20.], [12., 75., 30.], [8., 30., 70.]])
-    seeds = np.concatenate([core, halo])
+    g = np.arange(7) * 3.5
+    centers = np.stack(np.meshgrid(5.2 + g, 8.4 + g, 8.1 + g, indexing="ij"), -1).reshape(-1, 3)
+    heights = 1500.0 + 4500.0 * synth.uniform01(9, 3, np.arange(len(centers)))
+    im = synth.render((34, 40, 40), centers, heights, 9, sigma=(0.75, 0.75, 0.75))
+    seeds = np.round(centers)
     d2 = ((seeds[:, None] - seeds[None]) ** 2).sum(-1)
     assert ((d2 <= 100).sum(1) - 1).max() > 64
-    fo = O.iter_fit_seed_points(im, seeds.T, voronoi="lowest_index", n_max_iter=2)
+    fo = O.iter_fit_seed_points(im, seeds.T, voronoi="lowest_index")
     fo.firstfit()
     first_o = np.array(fo.ps, dtype=np.float64)
+    nvox_o = np.array([gp[1].shape[1] for gp in fo.gparms])
     fo.repeatfit()
     po = np.array(fo.ps, dtype=np.float64)
-    f = iter_fit_seed_points(im, seeds.T, n_max_iter=2)
+    f = iter_fit_seed_points(im, seeds.T)
     f.firstfit()
     first = np.array(f.ps, dtype=np.float64)
+    assert np.array_equal(np.array(f.nvox), nvox_o)
     f.repeatfit()
     p = np.array(f.ps, dtype=np.float64)
-    assert np.array_equal(np.isnan(first).any(1), np.isnan(first_o).any(1))
-    okf = ~np.isnan(first_o).any(1) & (fo.nfev_last < 1000)
     assert f.n_iter == fo.n_iter
-    conv = ~np.isnan(po).any(1) & (fo.nfev_last < 1000)
-    # Voronoi cells of a 90-seed cube are a few voxels each: the first fits are badly conditioned, compare loosely there
-    # and to 1e-4 for the isolated seeds; refits (full balls minus 89 reconstructions each) to 1e-3
-    assert np.nanmax(_rel(first[-3:], first_o[-3:])) <= 1e-4
-    assert np.nanmax(_rel(p[-3:], po[-3:])) <= 1e-4
-    assert np.nanmedian(_rel(p[conv], po[conv])) <= 1e-4
+    ok = ~np.isnan(first_o).any(1) & ~np.isnan(po).any(1) & (fo.nfev_peak < 1000)
+    assert ok.sum() > 300
+    r1, r2 = _rel(first[ok], first_o[ok]), _rel(p[ok], po[ok])
+    assert np.median(r1) <= 1e-6 and np.median(r2) <= 1e-6, (np.median(r1), np.median(r2))
+    assert r1.max() <= 1e-4 and r2.max() <= 1e-4, (r1.max(), r2.max())
 
 
 def _seed_dense(on):
@@ -243,7 +273,7 @@ def test_lazy_background_filter_equals_dense_filter():
         cases.append(("ragged%s" % (shape,), im, dict(th_seed=300.0)))
     im, c, h = synth.make_fov((24, 200, 200), 40, 5, dtype=np.uint16)
     cases.append(("sigma12", im, dict(th_seed=400.0, background_gfilt_size=12.0)))          # R = 48
-    cases.append(("lowest_level", im, dict(th_seed=60000.0, dynamic_niters=10)))             # nothing at the top levels
+    cases.append(("lowest_level", im, dict(th_seed=20000.0, dynamic_niters=10)))             # nothing at the top levels
     steps = (np.arange(24 * 96 * 96).reshape(24, 96, 96) // 517 % 7 * 500 + 300).astype(np.uint16)
     steps[10:13, 40:43, 50:53] += 2000
     cases.append(("plateaus_u16", steps, dict(th_seed=200.0)))
@@ -263,7 +293,7 @@ def test_lazy_background_filter_equals_dense_filter():
             _seed_dense(False)
             lazy = get_seeds(im, return_h=True, **kw)
             assert dense.shape == lazy.shape and np.array_equal(dense, lazy), (name, dense.shape, lazy.shape)
-            if name not in ("zeros_f32", "lowest_level"):
+            if name != "zeros_f32":
                 assert len(dense) > 0, name
     finally:
         _seed_dense(False)
