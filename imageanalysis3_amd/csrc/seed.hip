@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void blockmin_k(const T* __restrict__ zp, int 
   if (y < Y) {   // V > 1 only when Y % V == 0: a lane's V voxels are all inside
     const T* p = zp + ((size_t)z * X + x0) * Y + y;
     for (int x = x0; x < x1; ++x, p += Y) {
-      T v[V];
+      alignas(16) T v[V];
       if constexpr (V * sizeof(T) == 16) *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p);
       else v[0] = *p;
 #pragma unroll
