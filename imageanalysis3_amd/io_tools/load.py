@@ -464,7 +464,8 @@ def correct_fov_image(dax_filename, sel_channels,
                                 'num_empty_frames': num_empty_frames}
             if illumination_corr:
                 _drift_corr_args['illumination_profile'] = illumination_profile
-            _drift, _drift_flag = align_image(_ims[_load_channels.index(_drift_channel)].download(), ref_filename,
+            # the bead channel is already resident: align_image crops it on the device (no download / second upload)
+            _drift, _drift_flag = align_image(_ims[_load_channels.index(_drift_channel)], ref_filename,
                                               use_autocorr=use_autocorr, correction_args=_drift_corr_args,
                                               verbose=verbose, **_updated_drift_args)
         else:
