@@ -63,7 +63,16 @@ def test_bench_fov_window_vs_oracle(dtype):
     assert np.array_equal(seed_set(sw), seed_set(so))
     pw, n_iter = _fitted(so, win)           # same seed order as the oracle: rows align by index
     assert n_iter == fo.n_iter
-    ok = ~stuck & ~np.isnan(po).any(1)
+    # ... and the twin seeds of uint16 plateaus that refit what their neighbour's Gaussian left behind (height ~ noise,
+    # widths and angles on their bounds) sit in a flat valley where MINPACK itself needs 100-1000 evaluations: where it
+    # stops depends on the path.  Rows are required to agree to 1e-4 for every fit MINPACK finishes in < 100 evaluations
+    # (> 99.5 % of them) and to 2e-2 for the rest.
+    finite = ~np.isnan(po).any(1)
+    slow = ~stuck & finite & (fo.nfev_peak >= 100)
+    ok = ~stuck & finite & ~slow
+    assert ok.sum() >= 0.995 * len(so) - stuck.sum()
+    if slow.any():
+        assert _rel(pw[slow], po[slow]).max() <= 2e-2
     assert np.isnan(pw).any(1).sum() == np.isnan(po).any(1).sum()
     rel = _rel(pw[ok], po[ok])
     if rel.max() > 1e-4:   # leave the evidence where gpurun collects it
