@@ -96,8 +96,21 @@ def test_bench_fov_window_vs_oracle(dtype):
                                         C.byref(n_seeds), C.byref(n_it)))
     t = rows[:n_rows.value].astype(np.float64)
     assert n_seeds.value == len(sf)
-    sel = np.where(ok & in_o & (so[:, 1] < INNER - 16) & (so[:, 2] < INNER - 16))[0]
+    # Twin seeds of a uint16 plateau have EQUAL DoG heights; which of the two comes first (and therefore keeps the spot
+    # in the ordered refit) is decided by np.argsort's introsort in the reference — implementation-defined for ties —
+    # and by descending coordinates on the device.  The window run above used the oracle's order; here
+    # the device orders the seeds itself, so overlapping equal-height pairs are left out.
+    tree = cKDTree(so[:, :3])
+    tied = np.zeros(len(so), dtype=bool)
+    for i_, nb in enumerate(tree.query_ball_point(so[:, :3], 10.0 + 1e-9)):
+        tied[i_] = any(k_ != i_ and so[k_, 3] == so[i_, 3] for k_ in nb)
+    assert tied.sum() <= (0 if dtype == np.float32 else 0.03 * len(so))
+    sel = np.where(ok & ~tied & in_o & (so[:, 1] < INNER - 16) & (so[:, 2] < INNER - 16))[0]
     d, j = cKDTree(t[:, 1:4]).query(po[sel, 1:4])
+    if d.max() >= 1e-3:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "fullfov_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw, t=t, sf=sf,
+                 sel=sel, nfev_peak=fo.nfev_peak, stuck=stuck)
     assert len(sel) > 1000 and d.max() < 1e-3, d.max()
     rel = _rel(t[j], po[sel])
     assert rel.max() <= 1e-4, rel.max()
