@@ -5,8 +5,8 @@
 //        ±max_disp window.  z-max projection = one HBM pass over each stack.
 //  (a9)  skimage.registration.phase_cross_correlation as called at correction_tools/alignment.py:631 —
 //        published algorithm (Guizar-Sicairos et al. 2008): cross-power spectrum, integer peak, then a
-//        matrix-multiply upsampled DFT in a ceil(1.5·u)³ window around it.  PARITY UNPINNED (scikit-image
-//        is an un-vendored, un-pinned dependency of the reference); validated by known-answer tests.
+//        matrix-multiply upsampled DFT in a ceil(1.5·u)³ window around it.  Pinned against scikit-image 0.18.3
+//        (tests/golden/phase.npz) for the un-normalised correlation.
 //
 // All FFT-side arithmetic is float64 (complex128), the precision SciPy/skimage use for uint16 input.
 #include "ia3_rt.h"
@@ -304,7 +304,7 @@ __global__ void dft_kernel_k(cplx* __restrict__ K, int R, int N, double off, dou
 // out[r, m] = sum_n K[r, n] * in[m, n]     (np.tensordot(K, data, axes=(1, -1)) with data flattened to (M, N))
 // tile: 16 r x 64 m per 256-thread block, 4 m per thread, n staged through LDS in chunks of 32
 __global__ __launch_bounds__(256) void dft_contract_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
-                                                      cplx* __restrict__ out, int R, int M, int N) {
+                                                      cplx* __restrict__ out, int R, int M, int N, int ldk, int ldi) {
   __shared__ cplx sk[16][33];
   __shared__ cplx sd[64][33];
   const int tr = threadIdx.x >> 4, tm = threadIdx.x & 15;
@@ -313,11 +313,11 @@ __global__ __launch_bounds__(256) void dft_contract_k(const cplx* __restrict__ K
   for (int n0 = 0; n0 < N; n0 += 32) {
     for (int e = threadIdx.x; e < 16 * 32; e += 256) {
       int rr = e >> 5, nn = e & 31;
-      sk[rr][nn] = (r0 + rr < R && n0 + nn < N) ? K[(size_t)(r0 + rr) * N + n0 + nn] : cplx{0, 0};
+      sk[rr][nn] = (r0 + rr < R && n0 + nn < N) ? K[(size_t)(r0 + rr) * ldk + n0 + nn] : cplx{0, 0};
     }
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
       int mm = e >> 5, nn = e & 31;
-      sd[mm][nn] = (m0 + mm < M && n0 + nn < N) ? in[(size_t)(m0 + mm) * N + n0 + nn] : cplx{0, 0};
+      sd[mm][nn] = (m0 + mm < M && n0 + nn < N) ? in[(size_t)(m0 + mm) * ldi + n0 + nn] : cplx{0, 0};
     }
     __syncthreads();
 #pragma unroll 8
@@ -350,18 +350,18 @@ int g_dft_valu = 0;   // IA3_TUNE_DFT_VALU: 1 = the vector-unit contraction (tes
 // them.  Float64 accumulation in the matrix unit: the upsampled peak search is as accurate as with the vector kernel.
 typedef double v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void dft_contract_mfma_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
-                                                           cplx* __restrict__ out, int R, int M, int N) {
+                                                           cplx* __restrict__ out, int R, int M, int N, int ldk, int ldi) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int r0 = blockIdx.y * 16, m0 = (blockIdx.x * 4 + wv) * 64;
   if (m0 >= M) return;                                  // whole wave
   const int rr = r0 + li < R ? r0 + li : R - 1;         // rows past the end repeat the last one and are not stored
-  const cplx* krow = K + (size_t)rr * N;
+  const cplx* krow = K + (size_t)rr * ldk;
   const cplx* drow[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int mm = m0 + 16 * t + li;
-    drow[t] = in + (size_t)(mm < M ? mm : M - 1) * N;
+    drow[t] = in + (size_t)(mm < M ? mm : M - 1) * ldi;
   }
   v4d acc_rr[4], acc_ii[4], acc_ri[4], acc_ir[4];
 #pragma unroll
@@ -397,6 +397,91 @@ __global__ __launch_bounds__(256) void dft_contract_mfma_k(const cplx* __restric
   }
 }
 
+
+// ---- real-input form of the same computation -------------------------------------------------------------------
+// Both stacks are real, so their spectra are Hermitian: D2Z transforms produce the half spectrum (Z, X, Yh = Y/2+1),
+// half the work and half the traffic of Z2Z, and the cross-correlation comes back through Z2D as a real array.
+template <class T>
+__global__ void to_real_k(const T* __restrict__ a, double* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = (double)a[i];
+}
+// One pass over the two half spectra: a := A conj(B) (optionally phase-normalised), b := conj(a) (the data of the
+// upsampled DFT), and the block's share of sum |A|^2, sum |B|^2 over the FULL spectrum (columns 0 < ky < Y - ky count
+// twice).  Fixed grid, partials added in index order afterwards: deterministic.
+__global__ __launch_bounds__(256) void half_power_k(cplx* __restrict__ a, cplx* __restrict__ b, size_t n, int Yh, int Y,
+                                                    int phase_norm, double* __restrict__ part_a, double* __restrict__ part_b) {
+  __shared__ double sha[256], shb[256];
+  double sa = 0, sb = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)ABS2_BLOCKS * 256) {
+    const int ky = (int)(i % (size_t)Yh);
+    const double wgt = (ky == 0 || 2 * ky == Y) ? 1.0 : 2.0;
+    const cplx x = a[i], y = b[i];
+    sa += wgt * (x.x * x.x + x.y * x.y);
+    sb += wgt * (y.x * y.x + y.y * y.y);
+    double re = x.x * y.x + x.y * y.y, im = x.y * y.x - x.x * y.y;
+    if (phase_norm) {
+      double m = hypot(re, im);
+      const double lim = 100.0 * 2.220446049250313e-16;
+      m = m > lim ? m : lim;
+      re /= m; im /= m;
+    }
+    a[i] = cplx{re, im};
+    b[i] = cplx{re, -im};
+  }
+  sha[threadIdx.x] = sa; shb[threadIdx.x] = sb;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) { sha[threadIdx.x] += sha[threadIdx.x + k]; shb[threadIdx.x] += shb[threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_a[blockIdx.x] = sha[0]; part_b[blockIdx.x] = shb[0]; }
+}
+__global__ __launch_bounds__(256) void real_argmax_part_k(const double* __restrict__ a, size_t n, double* pv, long long* pi) {
+  __shared__ double sv[256];
+  __shared__ long long si[256];
+  double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+    const double v = a[k] * a[k];
+    if (v > bv) { bv = v; bi = (long long)k; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      double ov = sv[threadIdx.x + s]; long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { pv[blockIdx.x] = sv[0]; pi[blockIdx.x] = si[0]; }
+}
+// First contraction of the upsampled DFT from the half spectrum.  With D the (Hermitian) full data and K[r, Y - k] =
+// conj(K[r, k]):   sum_{ky < Y} K[r, ky] D[kz, kx, ky] = P[r, kz, kx] + conj(P[r, -kz, -kx]) + K[r, 0] D[kz, kx, 0]
+//                  (+ K[r, Y/2] D[kz, kx, Y/2] for even Y),   P[r, kz, kx] = sum_{0 < ky < Y - ky} K[r, ky] D[kz, kx, ky],
+// so the matrix product runs over half the columns.  out / P: (R, Z, X); d: (Z, X, Yh); K: (R, ldk).
+__global__ __launch_bounds__(256) void half_combine_k(const cplx* __restrict__ P, const cplx* __restrict__ d,
+                                                      const cplx* __restrict__ K, int ldk, int R, int Z, int X, int Yh, int Y,
+                                                      cplx* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t zx = (size_t)Z * X;
+  if (i >= (size_t)R * zx) return;
+  const int r = (int)(i / zx);
+  const size_t m = i % zx;
+  const int kz = (int)(m / X), kx = (int)(m % X);
+  const size_t mm = (size_t)((Z - kz) % Z) * X + (size_t)((X - kx) % X);
+  const cplx p = P[i], q = P[(size_t)r * zx + mm];
+  const cplx k0 = K[(size_t)r * ldk], d0 = d[m * Yh];
+  double re = p.x + q.x + (k0.x * d0.x - k0.y * d0.y);
+  double im = p.y - q.y + (k0.x * d0.y + k0.y * d0.x);
+  if (2 * (Yh - 1) == Y) {   // even Y: the Nyquist column stands alone as well
+    const cplx kn = K[(size_t)r * ldk + Yh - 1], dn = d[m * Yh + Yh - 1];
+    re += kn.x * dn.x - kn.y * dn.y;
+    im += kn.x * dn.y + kn.y * dn.x;
+  }
+  out[i] = cplx{re, im};
+}
+
 int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
   hipStream_t st = stream();
   const int nb = 512;
@@ -414,9 +499,29 @@ int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
   return IA3_OK;
 }
 
+
+int real_argmax(const double* a, size_t n, long long* idx, double* val2) {
+  hipStream_t st = stream();
+  const int nb = 512;
+  Scratch pv(nb * sizeof(double)), pi(nb * sizeof(long long));
+  if (!pv.p || !pi.p) return IA3_ENOMEM;
+  hipLaunchKernelGGL(real_argmax_part_k, dim3(nb), dim3(256), 0, st, a, n, pv.as<double>(), pi.as<long long>());
+  IA3_KCHECK();
+  std::vector<double> hv(nb); std::vector<long long> hi(nb);
+  IA3_HIP(hipMemcpyAsync(hv.data(), pv.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipMemcpyAsync(hi.data(), pi.p, nb * sizeof(long long), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  double bv = -1; long long bi = 0;
+  for (int k = 0; k < nb; ++k) if (hv[k] > bv || (hv[k] == bv && hi[k] < bi)) { bv = hv[k]; bi = hi[k]; }
+  *idx = bi; *val2 = bv;
+  return IA3_OK;
+}
+
+int g_fft_c2c = 0;   // IA3_TUNE_FFT_C2C: 1 = complex transforms of the real stacks (first version; tests compare)
+
 }  // namespace
 
-namespace ia3k { void set_dft_valu(int on) { g_dft_valu = on != 0; } }
+namespace ia3k { void set_dft_valu(int on) { g_dft_valu = on != 0; } void set_fft_c2c(int on) { g_fft_c2c = on != 0; } }
 
 extern "C" {
 
@@ -494,37 +599,67 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
   hipStream_t st = stream();
   const int Z = ref->Z, X = ref->X, Y = ref->Y;
   const size_t n = (size_t)Z * X * Y;
-  Scratch fa(n * sizeof(cplx)), fb(n * sizeof(cplx)), sums(2 * sizeof(double)), parts(ABS2_BLOCKS * sizeof(double));
-  if (!fa.p || !fb.p || !sums.p || !parts.p) return IA3_ENOMEM;
+  const int Yh = Y / 2 + 1;
+  const size_t nh = (size_t)Z * X * Yh;
+  const bool half = !g_fft_c2c && Y >= 8;   // real-input transforms (half spectra); tiny rows keep the complex form
+  Scratch fa((half ? nh : n) * sizeof(cplx)), fb((half ? nh : n) * sizeof(cplx)), sums(2 * sizeof(double)),
+      parts(2 * ABS2_BLOCKS * sizeof(double)), rbuf(half ? n * sizeof(double) : 256);
+  if (!fa.p || !fb.p || !sums.p || !parts.p || !rbuf.p) return IA3_ENOMEM;
   const unsigned nb = (unsigned)((n + 255) / 256);
   ProfScope ps("phase_xcorr3d");
-  if (ref->dtype == IA3_F32) {
-    hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)ref->d, fa.as<cplx>(), n);
-    hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)mov->d, fb.as<cplx>(), n);
-  } else {
-    hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)ref->d, fa.as<cplx>(), n);
-    hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)mov->d, fb.as<cplx>(), n);
-  }
-  hipfftHandle plan;
-  { int prc = get_plan(HIPFFT_Z2Z, Z, X, Y, st, &plan); if (prc) return prc; }
-  IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
-  IA3_FFT(hipfftExecZ2Z(plan, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
-  hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fa.as<cplx>(), n, parts.as<double>());
-  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
-  hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fb.as<cplx>(), n, parts.as<double>());
-  hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>() + 1);
-  hipLaunchKernelGGL(cross_power_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), n, normalization);
-  // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
-  IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
-  IA3_KCHECK();
   long long idx; double v2;
-  rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;
-  double hs[2];
-  IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
   cplx ccmax;
-  IA3_HIP(hipMemcpyAsync(&ccmax, fb.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
-  IA3_HIP(hipStreamSynchronize(st));
-  ccmax.x /= (double)n; ccmax.y /= (double)n;
+  double hs[2];
+  if (half) {
+    hipfftHandle fwd, inv;
+    { int prc = get_plan(HIPFFT_D2Z, Z, X, Y, st, &fwd); if (prc) return prc; }
+    { int prc = get_plan(HIPFFT_Z2D, Z, X, Y, st, &inv); if (prc) return prc; }
+    for (int which = 0; which < 2; ++which) {
+      const ia3_stack* s = which ? mov : ref;
+      if (s->dtype == IA3_F32) hipLaunchKernelGGL((to_real_k<float>), dim3(nb), dim3(256), 0, st, (const float*)s->d, rbuf.as<double>(), n);
+      else hipLaunchKernelGGL((to_real_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)s->d, rbuf.as<double>(), n);
+      IA3_FFT(hipfftExecD2Z(fwd, rbuf.as<double>(), which ? fb.as<cplx>() : fa.as<cplx>()));
+    }
+    // fa := prod, fb := conj(prod), power sums of both spectra — one pass
+    hipLaunchKernelGGL(half_power_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, fa.as<cplx>(), fb.as<cplx>(), nh, Yh, Y, normalization,
+                       parts.as<double>(), parts.as<double>() + ABS2_BLOCKS);
+    hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
+    hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)(parts.as<double>() + ABS2_BLOCKS), sums.as<double>() + 1);
+    // rbuf := ifftn(prod), real (unnormalised by hipFFT; the transform may overwrite fa)
+    IA3_FFT(hipfftExecZ2D(inv, fa.as<cplx>(), rbuf.as<double>()));
+    IA3_KCHECK();
+    rc = real_argmax(rbuf.as<double>(), n, &idx, &v2); if (rc) return rc;
+    double cc;
+    IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipMemcpyAsync(&cc, rbuf.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipStreamSynchronize(st));
+    ccmax = cplx{cc / (double)n, 0.0};
+  } else {
+    if (ref->dtype == IA3_F32) {
+      hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)ref->d, fa.as<cplx>(), n);
+      hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)mov->d, fb.as<cplx>(), n);
+    } else {
+      hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)ref->d, fa.as<cplx>(), n);
+      hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)mov->d, fb.as<cplx>(), n);
+    }
+    hipfftHandle plan;
+    { int prc = get_plan(HIPFFT_Z2Z, Z, X, Y, st, &plan); if (prc) return prc; }
+    IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
+    IA3_FFT(hipfftExecZ2Z(plan, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
+    hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fa.as<cplx>(), n, parts.as<double>());
+    hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
+    hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fb.as<cplx>(), n, parts.as<double>());
+    hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>() + 1);
+    hipLaunchKernelGGL(cross_power_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), n, normalization);
+    // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
+    IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
+    IA3_KCHECK();
+    rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;
+    IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipMemcpyAsync(&ccmax, fb.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipStreamSynchronize(st));
+    ccmax.x /= (double)n; ccmax.y /= (double)n;
+  }
   const int dims[3] = {Z, X, Y};
   long long rem = idx;
   int peak[3];
@@ -545,20 +680,33 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     const double dftshift = trunc(R / 2.0);
     double off[3];
     for (int a = 0; a < 3; ++a) off[a] = dftshift - sh[a] * u;
-    // data = conj(prod) in fa; contract last axis three times (axes Y, X, Z), new axis goes first
-    hipLaunchKernelGGL(conj_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), n);
+    // data = conj(prod); contract last axis three times (axes Y, X, Z), new axis goes first
+    if (!half) hipLaunchKernelGGL(conj_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), n);
     const int maxN = Y > X ? (Y > Z ? Y : Z) : (X > Z ? X : Z);
     Scratch K((size_t)R * maxN * sizeof(cplx)), t1((size_t)R * Z * X * sizeof(cplx)), t2((size_t)R * R * Z * sizeof(cplx)),
-        t3((size_t)R * R * R * sizeof(cplx));
-    if (!K.p || !t1.p || !t2.p || !t3.p) return IA3_ENOMEM;
+        t3((size_t)R * R * R * sizeof(cplx)), tp(half ? (size_t)R * Z * X * sizeof(cplx) : 256);
+    if (!K.p || !t1.p || !t2.p || !t3.p || !tp.p) return IA3_ENOMEM;
+    // out[r][m] = sum_{n < cols} Kmat[r][n] in[m][n], rows of Kmat / in ldk / ldi elements apart
+    auto matmul = [&](const cplx* Kmat, const cplx* in, cplx* out, int M, int cols, int ldk, int ldi) {
+      if (g_dft_valu)
+        hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+      else
+        hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+    };
     auto contract = [&](const cplx* in, cplx* out, int M, int N, double o) {
       hipLaunchKernelGGL(dft_kernel_k, dim3((N + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, N, o, u);
-      if (g_dft_valu)
-        hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
-      else
-        hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, (const cplx*)K.as<cplx>(), in, out, R, M, N);
+      matmul((const cplx*)K.as<cplx>(), in, out, M, N, N, N);
     };
-    contract(fa.as<cplx>(), t1.as<cplx>(), Z * X, Y, off[2]);   // (R_y, Z, X)
+    if (half) {
+      // (R_y, Z, X) from the half spectrum in fb: product over the interior columns, then the Hermitian completion
+      hipLaunchKernelGGL(dft_kernel_k, dim3((Y + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, Y, off[2], u);
+      const int inner = (Y - 1) / 2;   // columns 1 .. inner have a distinct mirror image
+      matmul((const cplx*)K.as<cplx>() + 1, (const cplx*)fb.as<cplx>() + 1, tp.as<cplx>(), Z * X, inner, Y, Yh);
+      hipLaunchKernelGGL(half_combine_k, dim3((unsigned)(((size_t)R * Z * X + 255) / 256)), dim3(256), 0, st, (const cplx*)tp.as<cplx>(),
+                         (const cplx*)fb.as<cplx>(), (const cplx*)K.as<cplx>(), Y, R, Z, X, Yh, Y, t1.as<cplx>());
+    } else {
+      contract(fa.as<cplx>(), t1.as<cplx>(), Z * X, Y, off[2]);   // (R_y, Z, X)
+    }
     contract(t1.as<cplx>(), t2.as<cplx>(), R * Z, X, off[1]);   // (R_x, R_y, Z)
     contract(t2.as<cplx>(), t3.as<cplx>(), R * R, Z, off[0]);   // (R_z, R_x, R_y)
     IA3_KCHECK();

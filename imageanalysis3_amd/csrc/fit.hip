@@ -758,6 +758,7 @@ struct ia3_fitter {
   bool first_done;
   StageCtl host_ctl;
   unsigned long long host_counters[3];   // copy of d_counters as of the last ia3_fit_results(_ex)
+  bool cached;         // host_stage holds [counters | n_iter | ctl | overflow | rows] of the finished fit (run_sweeps)
   std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
 };
 
@@ -920,28 +921,42 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   return IA3_OK;
 }
 
+// [counters | n_iter | stage control | overflow flag | rows] -> f->host_stage in one copy, one synchronisation
+static int fetch_block(ia3_fitter* f, bool with_rows) {
+  hipStream_t st = stream();
+  const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_counters);
+  const size_t rows = with_rows ? sizeof(float) * 11 * (size_t)f->n : 0;
+  f->host_stage.resize(head + rows);
+  IA3_HIP(hipMemcpyAsync(f->host_stage.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  return IA3_OK;
+}
+
 // Sweeps are launched two at a time and the next pair only while some seed is still unconverged: a launch costs
-// one block per (stage, seed) even for converged seeds, and most fields converge after the first sweep.
+// one block per (stage, seed) even for converged seeds, and most fields converge after the first sweep.  The check
+// between pairs fetches the row table along with the control words: when nothing is left to refit (the common case)
+// ia3_fit_results finds everything on the host already and the fit costs ONE synchronisation.
 static int run_sweeps(ia3_fitter* f, int stage, bool fresh) {
   const int last = f->prm.n_max_iter + 2;   // sweeps 1 .. n_max_iter+1 (Fitting_v4.py:683)
-  hipStream_t st = stream();
+  f->cached = false;
   while (stage < last) {
     const int s1 = stage + 2 < last ? stage + 2 : last;
     int rc = launch_stages(f, stage, s1, fresh); if (rc) return rc;
     fresh = false;
     stage = s1;
     if (stage >= last) break;
+    rc = fetch_block(f, true); if (rc) return rc;
     StageCtl hc;
-    IA3_HIP(hipMemcpyAsync(&hc, f->d_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipStreamSynchronize(st));
+    memcpy(&hc, f->host_stage.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));
     if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
-    if (hc.n_unconv <= 0) break;
+    if (hc.n_unconv <= 0) { f->cached = true; break; }
   }
   return IA3_OK;
 }
 
 int ia3_fit_first(ia3_fitter* f) {
   if (!f) return set_error(IA3_EINVAL, "null fitter");
+  f->cached = false;
   if (f->n > 0) {
     IA3_HIP(hipMemsetAsync(f->d_done, 0, sizeof(int) * (size_t)f->n, stream()));
     int rc = launch_stages(f, 0, 1, true); if (rc) return rc;
@@ -992,18 +1007,22 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
   StageCtl hc = StageCtl{0u, 0, 0, 0};
   int ovf = 0;
   if (f->n > 0) {
-    // one copy: the four 256-byte control slots and the row table sit back to back in the pool
+    // one copy: the four 256-byte control slots and the row table sit back to back in the pool (already on the host
+    // when the last sweep check found nothing left to refit)
     const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_counters);
     const size_t rows = ps ? sizeof(float) * 11 * (size_t)f->n : 0;
     std::vector<char>& hb = f->host_stage;
-    hb.resize(head + rows);
-    IA3_HIP(hipMemcpyAsync(hb.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
+    const bool have = f->cached && hb.size() >= head + rows;
+    if (!have) {
+      hb.resize(head + rows);
+      IA3_HIP(hipMemcpyAsync(hb.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
+    }
     if (nvox) IA3_HIP(hipMemcpyAsync(nvox, f->d_nvox, sizeof(int) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     if (success) {
       stv.resize(f->n);
       IA3_HIP(hipMemcpyAsync(stv.data(), f->d_state, sizeof(SeedState) * (size_t)f->n, hipMemcpyDeviceToHost, st));
     }
-    IA3_HIP(hipStreamSynchronize(st));
+    if (!have || nvox || success) IA3_HIP(hipStreamSynchronize(st));
     memcpy(f->host_counters, hb.data(), sizeof(f->host_counters));
     if (n_iter) memcpy(n_iter, hb.data() + ((char*)f->d_niter - (char*)f->d_counters), sizeof(int));
     memcpy(&hc, hb.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));

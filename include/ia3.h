@@ -68,6 +68,9 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * overlapping neighbours scan the seed list instead — same neighbours in the same order.  Tests lower it to drive
  * ordinary fields through the scan. */
 #define IA3_TUNE_FIT_NBLIST 5
+/* IA3_TUNE_FFT_C2C: 1 = the phase correlation transforms the (real) stacks with complex-to-complex FFTs (first
+ * version); 0 (default) = real-input transforms on half spectra.  Shifts agree to rounding. */
+#define IA3_TUNE_FFT_C2C 6
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

@@ -319,3 +319,28 @@ def test_lazy_background_filter_equals_dense_filter():
                 assert len(dense) > 0, name
     finally:
         _seed_dense(False)
+
+
+def test_phase_correlation_real_transforms_equal_complex_transforms():
+    """The phase correlation on half spectra (D2Z / Z2D, Hermitian-completed first contraction of the upsampled DFT)
+    against the complex-transform form it replaces: same shifts, error and phase to rounding — even and odd row
+    lengths, both normalisations, float32 and uint16."""
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.correction_tools.alignment import phase_cross_correlation
+    cases = []
+    for shape, d in (((20, 96, 96), (0.7, -3.25, 5.5)), ((17, 63, 81), (-1.2, 2.4, -3.7)), ((12, 40, 33), (0.3, 1.1, 0.45))):
+        ref, src, _, _ = synth.make_bead_pair(shape, 12, 3, np.array(d), margin=(4, 10, 10), min_sep=10.0)
+        cases.append((ref, src))
+        cases.append((ref.astype(np.uint16), src.astype(np.uint16)))
+    try:
+        for ref, src in cases:
+            for norm in (None, "phase"):
+                for up in (1, 100):
+                    L.check(L.lib().ia3_set_tuning(6, 1))      # IA3_TUNE_FFT_C2C
+                    s0, e0, p0 = phase_cross_correlation(ref, src, upsample_factor=up, normalization=norm)
+                    L.check(L.lib().ia3_set_tuning(6, 0))
+                    s1, e1, p1 = phase_cross_correlation(ref, src, upsample_factor=up, normalization=norm)
+                    assert np.abs(np.asarray(s0) - np.asarray(s1)).max() <= 1e-9, (ref.shape, ref.dtype, norm, up, s0, s1)
+                    assert abs(e0 - e1) <= 1e-7 and abs(p0 - p1) <= 1e-7, (ref.shape, norm, up, e0, e1, p0, p1)
+    finally:
+        L.check(L.lib().ia3_set_tuning(6, 0))
