@@ -329,7 +329,7 @@ def test_phase_correlation_real_transforms_equal_complex_transforms():
     from imageanalysis3_amd.correction_tools.alignment import phase_cross_correlation
     cases = []
     for shape, d in (((20, 96, 96), (0.7, -3.25, 5.5)), ((17, 63, 81), (-1.2, 2.4, -3.7)), ((12, 40, 33), (0.3, 1.1, 0.45))):
-        ref, src, _, _ = synth.make_bead_pair(shape, 12, 3, np.array(d), margin=(4, 10, 10), min_sep=10.0)
+        ref, src, _, _ = synth.make_bead_pair(shape, 12 if shape[1] > 50 else 4, 3, np.array(d), margin=(3, 8, 8), min_sep=7.0)
         cases.append((ref, src))
         cases.append((ref.astype(np.uint16), src.astype(np.uint16)))
     try:
