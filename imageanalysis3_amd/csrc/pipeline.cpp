@@ -14,21 +14,29 @@
 using namespace ia3rt;
 
 // counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
-static thread_local long long t_last_stats[3] = {0, 0, 0};
+static thread_local long long t_last_stats[4] = {0, 0, 0, 0};
 
-extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
-                               float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter) {
-  int rc = ensure_init(); if (rc) return rc;
-  if (!im || !sp || !fp || !n_rows) return set_error(IA3_EINVAL, "null argument");
-  ia3k::SeedDev sd;
-  rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
-  const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
-  if (n_seeds) *n_seeds = n;
-  if (n_iter) *n_iter = 0;
-  *n_rows = 0;
-  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = 0;
-  if (n == 0) return IA3_OK;  // fitting.py:206-207
+static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* r = ps + (size_t)i * 11;
+    bool ok = true;
+    for (int k = 0; k < 11; ++k) if (isnan(r[k])) ok = false;                       // :232
+    if (ok) ok = r[1] > 0 && r[2] > 0 && r[3] > 0 && r[1] < im->Z && r[2] < im->X && r[3] < im->Y;  // :235-236
+    if (!ok) continue;
+    if (m < capacity && out_rows) memcpy(out_rows + (size_t)m * 11, r, 11 * sizeof(float));
+    ++m;
+  }
+  *n_rows = m;
+  if (m > capacity) return set_error(IA3_ECAPACITY, "row buffer too small: need %d rows", m);
+  return IA3_OK;
+}
+
+// seeds known on the host (count n; centres on the device or on the host)
+static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, const ia3_fit_params* fp, float* out_rows,
+                           int capacity, int* n_rows, int* n_iter) {
   ia3_fitter* f = nullptr;
+  int rc;
   if (sd.on_device) {
     rc = ia3k::fit_create_dev(im, sd.d_zxy, n, fp, &f); if (rc) return rc;   // the seed list never left HBM
   } else {
@@ -42,19 +50,60 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   if (!rc) ia3k::fit_host_counters(f, t_last_stats);
   ia3_fit_destroy(f);
   if (rc) return rc;
-  int m = 0;
-  for (int i = 0; i < n; ++i) {
-    const float* r = &ps[(size_t)i * 11];
-    bool ok = true;
-    for (int k = 0; k < 11; ++k) if (isnan(r[k])) ok = false;                       // :232
-    if (ok) ok = r[1] > 0 && r[2] > 0 && r[3] > 0 && r[1] < im->Z && r[2] < im->X && r[3] < im->Y;  // :235-236
-    if (!ok) continue;
-    if (m < capacity && out_rows) memcpy(out_rows + (size_t)m * 11, r, 11 * sizeof(float));
-    ++m;
+  return filter_rows(im, ps.data(), n, out_rows, capacity, n_rows);
+}
+
+extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
+                               float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !sp || !fp || !n_rows) return set_error(IA3_EINVAL, "null argument");
+  if (n_seeds) *n_seeds = 0;
+  if (n_iter) *n_iter = 0;
+  *n_rows = 0;
+  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = t_last_stats[3] = 0;
+  // Seeding and the first two fit stages are queued back to back: the seed list AND its length stay on the device
+  // (the fitter is sized for the device finish's capacity and its kernels read the count themselves), so the host
+  // synchronises once per image in the common case — after stage 0 + sweep 1, when it reads the seeder's control record
+  // together with the row table.
+  {
+    ia3k::SeedDev sd;
+    sd.async = true;
+    rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
+    if (sd.on_device && sd.n < 0) {
+      const int cap = ia3k::seed_dev_capacity();
+      ia3_fitter* f = nullptr;
+      rc = ia3k::fit_create_devn(im, sd.d_zxy, sd.d_n, cap, fp, &f, sd.d_ctl); if (rc) return rc;
+      std::vector<float> ps((size_t)cap * 11);
+      char ctl[32];
+      rc = ia3_fit_run(f);
+      if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
+      int redo = 0;
+      if (!rc) {
+        ia3k::fit_seed_ctl(f, ctl);   // the seeder's control record travelled with the fit's result block
+        redo = ia3k::seed_async_check(ctl, sd);
+        if (!redo) ia3k::fit_host_counters(f, t_last_stats);
+      }
+      ia3_fit_destroy(f);
+      if (rc) return rc;
+      if (!redo) {
+        if (n_seeds) *n_seeds = sd.n;
+        return filter_rows(im, ps.data(), sd.n, out_rows, capacity, n_rows);
+      }
+      // more candidates than the device-side finish holds: once more, the synchronous way (below)
+    } else {
+      const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
+      if (n_seeds) *n_seeds = n;
+      if (n == 0) return IA3_OK;  // fitting.py:206-207
+      return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
+    }
   }
-  *n_rows = m;
-  if (m > capacity) return set_error(IA3_ECAPACITY, "row buffer too small: need %d rows", m);
-  return IA3_OK;
+  ia3k::SeedDev sd;
+  rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
+  const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
+  if (n_seeds) *n_seeds = n;
+  if (n_iter) *n_iter = 0;
+  if (n == 0) return IA3_OK;
+  return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
 }
 
 extern "C" int ia3_fit_fov_stats(int64_t* fits, int64_t* nfev, int64_t* voxel_evals) {
