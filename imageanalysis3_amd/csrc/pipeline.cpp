@@ -15,6 +15,8 @@ using namespace ia3rt;
 
 // counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
 static thread_local long long t_last_stats[4] = {0, 0, 0, 0};
+static int g_sync_seeds = 0;   // IA3_TUNE_SYNC_SEEDS: 1 = read the seed count back before the fit is queued (first version)
+namespace ia3k { void set_sync_seeds(int on) { g_sync_seeds = on ? 1 : 0; } }
 
 static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
   int m = 0;
@@ -67,7 +69,7 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   // together with the row table.
   {
     ia3k::SeedDev sd;
-    sd.async = true;
+    sd.async = !g_sync_seeds;
     rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
     if (sd.on_device && sd.n < 0) {
       const int cap = ia3k::seed_dev_capacity();
