@@ -54,9 +54,7 @@ struct SeedState {
 struct FitArgs {
   const void* im; int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
-  int n;                    // number of seeds (host value; replaced by *d_n inside the kernels when d_n is set)
-  const int* d_n;           // seed count that is still on the device (ia3_fit_fov_dev: the seeder's result is not read back)
-  int n_cap;                // capacity the fitter was sized for (d_n path): n = min(*d_n, n_cap)
+  int n;                    // number of seeds
   int nb_cap;               // lists longer than this are not used (MAXNB; lowered by IA3_TUNE_FIT_NBLIST in tests)
   double nb_r2;             // (2r)²: seeds closer than this interact
   const int* nbr_cnt;       // n: number of neighbours of seed i (NOT clamped: > MAXNB = list overflow, see each_neighbour)
@@ -417,8 +415,7 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, const flo
 // ballot + prefix rank, so every list comes out in ascending index order (5 k seeds: 25 M distance tests, ~10 µs;
 // the seed list never goes back to the host for this)
 __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ seeds, int n, double r2, int* __restrict__ cnt,
-                                                   int* __restrict__ idx, int* __restrict__ overflow, const int* __restrict__ d_n) {
-  if (d_n) { const int m = *d_n; n = m < n ? m : n; }   // n arrives as the capacity
+                                                   int* __restrict__ idx, int* __restrict__ overflow) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;   // whole wave leaves together
@@ -654,7 +651,6 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
                                                    int* done) {
   __shared__ LMWork w;
   const int lane = threadIdx.x & 63;
-  if (fa.d_n) { const int m = *fa.d_n; n = m < fa.n_cap ? m : fa.n_cap; fa.n = n; }
   const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
   unsigned pos = 0;
   if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
@@ -748,26 +744,22 @@ __global__ __launch_bounds__(64) void fit_voxels_k(VoxArgs va, int n_fits, doubl
 
 // One launch prepares a fitter's pooled block: the zero-initialised arrays, NaN rows (all-ones float32: failed fits stay
 // NaN rows, Fitting_v4.py:636), the stage control record, and — when the seeds never left the device — the seed
-// coordinates and their count.  (Nine separate memset / copy operations of ~5 us each before.)
+// coordinates.  (Nine separate memset / copy operations of ~5 us each before.)
 struct InitArgs {
   uint4* zero0; size_t zero_words;      // 16-byte words to clear, head block excluded
   uint4* rows; size_t row_words;        // 16-byte words to fill with ones
   unsigned long long* counters;         // head block: [counters | n_iter | ctl | overflow], 256 bytes each
   int* niter; StageCtl* ctl; int* ovf;
   double* seeds; const double* src;     // optional device-to-device copy of 3 n doubles
-  const int* d_n; int n;                // n, or its capacity when d_n is set
-  const unsigned* seed_ctl;             // optional: 8 words of the seeder's control record, parked in counters[8..11] so
-};                                      // that they reach the host with the results (one copy for everything)
+  int n;
+};
 __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
-  int n = a.n;
-  if (a.d_n) { const int m = *a.d_n; n = m < n ? m : n; }
+  const int n = a.n;
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
   for (size_t i = t; i < a.zero_words; i += step) a.zero0[i] = uint4{0u, 0u, 0u, 0u};
   for (size_t i = t; i < a.row_words; i += step) a.rows[i] = uint4{~0u, ~0u, ~0u, ~0u};
   if (a.src) for (size_t i = t; i < (size_t)3 * n; i += step) a.seeds[i] = a.src[i];
-  if (t < 32 && !(a.seed_ctl && t >= 8 && t < 12))
-    a.counters[t] = t == 3 ? (unsigned long long)n : 0ull;   // counters[3] = the seed count, for the host
-  if (a.seed_ctl && t >= 40 && t < 48) ((unsigned*)(a.counters + 8))[t - 40] = a.seed_ctl[t - 40];
+  if (t < 32) a.counters[t] = 0ull;
   if (t == 33) *a.niter = 0;
   if (t == 34) *a.ctl = StageCtl{0u, n, 0, 0};
   if (t == 35) *a.ovf = 0;
@@ -789,11 +781,10 @@ struct ia3_fitter {
   size_t pool_bytes;
   void *d_seeds, *d_nbr_cnt, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
       *d_counters, *d_done, *d_ctl, *d_nbr_overflow;
-  const int* d_n;      // device-resident seed count (then n is the capacity the block is sized for), else null
   bool pristine;       // the block is as fit_init_k left it: the first fit launch needs no further resets
   bool first_done;
   StageCtl host_ctl;
-  unsigned long long host_counters[4];   // copy of d_counters as of the last ia3_fit_results(_ex); [3] = seed count
+  unsigned long long host_counters[3];   // copy of d_counters as of the last ia3_fit_results(_ex)
   bool cached;         // host_stage holds [counters | n_iter | ctl | overflow | rows] of the finished fit (run_sweeps)
   std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
 };
@@ -814,7 +805,7 @@ int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
-  a.n = f->n; a.d_n = f->d_n; a.n_cap = f->n; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
+  a.n = f->n; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
@@ -867,10 +858,8 @@ static int ball_table(int radius, const signed char** d_ball, int* nball) {
   return IA3_OK;
 }
 
-// d_n != nullptr: the seed count lives on the device (d_centers_zxy holds up to n rows); n is then the capacity.
 static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const double* d_centers_zxy, int n,
-                           const ia3_fit_params* p, ia3_fitter** out, const int* d_n = nullptr,
-                           const void* seed_ctl = nullptr) {
+                           const ia3_fit_params* p, ia3_fitter** out) {
   int rc = ensure_init(); if (rc) return rc;
   if (!im || !p || !out || n < 0 || (n > 0 && !centers_zxy && !d_centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
   if (p->radius_fit < 1) return set_error(IA3_EINVAL, "radius_fit must be >= 1");
@@ -881,7 +870,7 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
     for (int i = 0; i < 3 * n; ++i)
       if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
   ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
-  f->im = im; f->prm = *p; f->n = n; f->nball = nball; f->d_n = d_n;
+  f->im = im; f->prm = *p; f->n = n; f->nball = nball;
   // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows | neighbour lists]
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n);
@@ -931,7 +920,7 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
     ia.counters = (unsigned long long*)f->d_counters; ia.niter = (int*)f->d_niter; ia.ctl = (StageCtl*)f->d_ctl;
     ia.ovf = (int*)f->d_nbr_overflow;
     ia.seeds = (double*)f->d_seeds; ia.src = centers_zxy ? nullptr : d_centers_zxy;
-    ia.d_n = d_n; ia.n = n; ia.seed_ctl = (const unsigned*)seed_ctl;
+    ia.n = n;
     size_t words = ia.zero_words > ia.row_words ? ia.zero_words : ia.row_words;
     unsigned blocks = (unsigned)((words + 255) / 256);
     if (blocks > 1024) blocks = 1024;
@@ -943,7 +932,7 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
     const double rr = 2.0 * p->radius_fit;
     ProfScope ps("nbr_build");
     hipLaunchKernelGGL(nbr_build_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)f->d_seeds, n, rr * rr,
-                       (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow, d_n);
+                       (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow);
   }
   {
     hipError_t le = hipGetLastError();
@@ -963,16 +952,8 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 
 namespace ia3k {
 void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
-void fit_host_counters(const ia3_fitter* f, long long out[4]) {
-  for (int k = 0; k < 4; ++k) out[k] = (long long)f->host_counters[k];
-}
-int fit_create_devn(const ia3_stack* im, const double* d_centers_zxy, const int* d_n, int n_cap, const ia3_fit_params* p,
-                    ia3_fitter** out, const void* seed_ctl) {
-  return fit_create_impl(im, nullptr, d_centers_zxy, n_cap, p, out, d_n, seed_ctl);
-}
-void fit_seed_ctl(const ia3_fitter* f, void* out32) {   // the 32 bytes fit_init_k parked, as of the last results call
-  if (f->host_stage.size() >= 96) memcpy(out32, f->host_stage.data() + 64, 32);
-  else memset(out32, 0xFF, 32);
+void fit_host_counters(const ia3_fitter* f, long long out[3]) {
+  for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
 }
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out) {
   return fit_create_impl(im, nullptr, d_centers_zxy, n, p, out);
@@ -988,7 +969,6 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   hipStream_t st = stream();
   if (fresh) {
     if (!f->pristine) {   // fit_init_k has armed the control record of a new fitter already
-      if (f->d_n) return set_error(IA3_EINVAL, "a fitter with a device-side seed count runs once");
       f->host_ctl = StageCtl{0u, f->n, 0, 0};
       IA3_HIP(hipMemcpyAsync(f->d_ctl, &f->host_ctl, sizeof(StageCtl), hipMemcpyHostToDevice, st));
     }
@@ -996,8 +976,8 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
     IA3_HIP(hipMemsetAsync(f->d_ctl, 0, sizeof(unsigned int), st));   // StageCtl::claim is the first word
   }
   f->pristine = false;
-  long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order); with a
-  if (blocks < 1) blocks = 1;                                // device-side count f->n is the capacity: spare blocks leave
+  long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order)
+  if (blocks < 1) blocks = 1;
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
   hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
                      (int*)f->d_done);

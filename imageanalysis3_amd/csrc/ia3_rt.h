@@ -80,7 +80,7 @@ void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& r
 }  // namespace ia3rt
 
 // ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
-namespace ia3k { void set_dft_valu(int on); void set_fft_c2c(int on); void set_sync_seeds(int on); void set_seed_dense(int on); void set_fit_nblist(int cap); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
+namespace ia3k { void set_dft_valu(int on); void set_fft_c2c(int on); void set_seed_dense(int on); void set_fit_nblist(int cap); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
 namespace ia3k {
 // separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.  axes: bit 0 = the axis-0
 // pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst); radius <= 3 runs fused (axes == 3 only).
@@ -104,28 +104,12 @@ struct SeedDev {
   const double* d_zxy = nullptr;
   const double* d_h = nullptr;
   void* hold = nullptr;     // scratch block that owns d_zxy / d_h; release with ws_put
-  // async = true (set by the caller): when the device-side finish applies nothing is read back — n stays -1, d_n points
-  // to the device-resident seed count, d_ctl to the control record the caller copies with its own results and hands to
-  // seed_async_check() after its synchronisation
-  bool async = false;
-  const int* d_n = nullptr;
-  const void* d_ctl = nullptr;
-  double levels[64] = {0};
   SeedOut host;
   ~SeedDev() { if (hold) ia3rt::ws_put(hold); }
 };
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
-int seed_async_check(const void* ctl_host, SeedDev& out);   // 0 = fine (n, th_used filled), 1 = repeat synchronously
-size_t seed_ctl_bytes();
-int seed_dev_capacity();
 // fitter from centres that are already resident (n x 3 float64)
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
-// same with the seed COUNT left on the device too (*d_n, at most n_cap rows in d_centers_zxy): nothing of the seeder's
-// result has to reach the host before the fit is queued.  Single use: ia3_fit_run, then ia3_fit_results(_ex) with
-// buffers for n_cap rows; fit_host_counters()[3] is the count.
-int fit_create_devn(const ia3_stack* im, const double* d_centers_zxy, const int* d_n, int n_cap, const ia3_fit_params* p,
-                    ia3_fitter** out, const void* seed_ctl);
-void fit_seed_ctl(const ia3_fitter* f, void* out32);   // the seeder's control record (32 bytes) that came back with the results
-// fits run / model evaluations / voxel evaluations / seed count of a fitter, as of its last ia3_fit_results(_ex)
-void fit_host_counters(const ia3_fitter* f, long long out[4]);
+// fits run / model evaluations / voxel evaluations of a fitter, as of its last ia3_fit_results(_ex)
+void fit_host_counters(const ia3_fitter* f, long long out[3]);
 }  // namespace ia3k

@@ -14,9 +14,7 @@
 using namespace ia3rt;
 
 // counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
-static thread_local long long t_last_stats[4] = {0, 0, 0, 0};
-static int g_sync_seeds = 0;   // IA3_TUNE_SYNC_SEEDS: 1 = read the seed count back before the fit is queued (first version)
-namespace ia3k { void set_sync_seeds(int on) { g_sync_seeds = on ? 1 : 0; } }
+static thread_local long long t_last_stats[3] = {0, 0, 0};
 
 static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
   int m = 0;
@@ -62,49 +60,15 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   if (n_seeds) *n_seeds = 0;
   if (n_iter) *n_iter = 0;
   *n_rows = 0;
-  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = t_last_stats[3] = 0;
-  // Seeding and the first two fit stages are queued back to back: the seed list AND its length stay on the device
-  // (the fitter is sized for the device finish's capacity and its kernels read the count themselves), so the host
-  // synchronises once per image in the common case — after stage 0 + sweep 1, when it reads the seeder's control record
-  // together with the row table.
-  {
-    ia3k::SeedDev sd;
-    sd.async = !g_sync_seeds;
-    rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
-    if (sd.on_device && sd.n < 0) {
-      const int cap = ia3k::seed_dev_capacity();
-      ia3_fitter* f = nullptr;
-      rc = ia3k::fit_create_devn(im, sd.d_zxy, sd.d_n, cap, fp, &f, sd.d_ctl); if (rc) return rc;
-      std::vector<float> ps((size_t)cap * 11);
-      char ctl[32];
-      rc = ia3_fit_run(f);
-      if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
-      int redo = 0;
-      if (!rc) {
-        ia3k::fit_seed_ctl(f, ctl);   // the seeder's control record travelled with the fit's result block
-        redo = ia3k::seed_async_check(ctl, sd);
-        if (!redo) ia3k::fit_host_counters(f, t_last_stats);
-      }
-      ia3_fit_destroy(f);
-      if (rc) return rc;
-      if (!redo) {
-        if (n_seeds) *n_seeds = sd.n;
-        return filter_rows(im, ps.data(), sd.n, out_rows, capacity, n_rows);
-      }
-      // more candidates than the device-side finish holds: once more, the synchronous way (below)
-    } else {
-      const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
-      if (n_seeds) *n_seeds = n;
-      if (n == 0) return IA3_OK;  // fitting.py:206-207
-      return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
-    }
-  }
+  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = 0;
+  // (Leaving the seed COUNT on the device as well — fitter sized for the finish capacity, kernels reading the count —
+  // was measured: no gain for one stream, since the host already queues ahead of the device, and 12 % slower with twelve
+  // images in flight because every fit launch then carries 16 k mostly empty blocks; profiles/r02b/ab_sync.log.)
   ia3k::SeedDev sd;
   rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
   const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
   if (n_seeds) *n_seeds = n;
-  if (n_iter) *n_iter = 0;
-  if (n == 0) return IA3_OK;
+  if (n == 0) return IA3_OK;  // fitting.py:206-207
   return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
 }
 

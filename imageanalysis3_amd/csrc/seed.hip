@@ -513,7 +513,7 @@ namespace {
 // and the seed list never leaves HBM between the detector and the fitter.
 constexpr unsigned FIN_CAP = 8192;
 constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
-struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; int n_final; int pad[3]; };   // n_cand / overflow mirror SeedCtl: one read-back; n_final = seeds kept
+struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; };   // the last two mirror SeedCtl: one read-back
 
 __device__ __forceinline__ unsigned fin_n(const SeedCtl* sctl) { return sctl->n_cand < FIN_CAP ? sctl->n_cand : FIN_CAP; }
 __device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h desc, then z, x, y desc (finish_seeds)
@@ -601,8 +601,6 @@ __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__
   if (i == 0) {   // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
     fcw->n_cand = sctl->n_cand;
     fcw->overflow = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
-    const unsigned alive = fc->n_alive;   // complete: fin_rank_k ran before this kernel
-    fcw->n_final = (int)((max_num > 0 && (unsigned)max_num <= alive) ? (unsigned)max_num : alive);
   }
   if (i >= n) return;
   const double th = lev.th[fc->chosen];
@@ -845,19 +843,6 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       }
       FinCtl hfc;
       fe = hipGetLastError();
-      if (fe == hipSuccess && dev->async) {
-        // nothing comes back yet: the caller queues the fit behind these kernels and reads the control record with the
-        // fit's results (seed_async_check)
-        dev->on_device = true;
-        dev->n = -1;
-        dev->d_zxy = (const double*)(fb + o_zxy);
-        dev->d_h = (const double*)(fb + o_h);
-        dev->d_n = &fc->n_final;
-        dev->d_ctl = fc;
-        dev->hold = fin;
-        for (int i = 0; i < lev.n; ++i) dev->levels[i] = lev.th[i];
-        return IA3_OK;
-      }
       if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
       if (fe == hipSuccess) fe = hipStreamSynchronize(s);
       if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe)); }
@@ -903,20 +888,6 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   if (dbg) fprintf(stderr, "dog_seed: launch gauss %.3f ms, detect+copy(sync) %.3f ms, finish %.3f ms (%zu cand)\n", t1 - t0, t2 - t1, now_ms() - t2, cand.size());
   return IA3_OK;
 }
-
-// After the stream has been synchronised: did the asynchronous seeding stay inside what the device-side finish holds?
-// ctl = host copy of the record SeedDev::d_ctl points to.  Returns 0 and the seed count / threshold level, or 1 when
-// the caller has to repeat the call synchronously (more candidates than FIN_CAP, or the lazy background path overflowed).
-int seed_async_check(const void* ctl_host, SeedDev& out) {
-  FinCtl hfc;
-  memcpy(&hfc, ctl_host, sizeof(FinCtl));
-  if ((hfc.overflow & 2u) || hfc.overflow || hfc.n_cand > FIN_CAP) return 1;
-  out.n = hfc.n_final;
-  out.th_used = out.levels[hfc.chosen];
-  return 0;
-}
-size_t seed_ctl_bytes() { return sizeof(FinCtl); }
-int seed_dev_capacity() { return (int)FIN_CAP; }
 
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out) {
   return dog_seed_impl(im, p, out.host, &out);

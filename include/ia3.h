@@ -71,9 +71,6 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_FFT_C2C: 1 = the phase correlation transforms the (real) stacks with complex-to-complex FFTs (first
  * version); 0 (default) = real-input transforms on half spectra.  Shifts agree to rounding. */
 #define IA3_TUNE_FFT_C2C 6
-/* IA3_TUNE_SYNC_SEEDS: 1 = ia3_fit_fov_dev reads the seed count back before it queues the fit (first version, two
- * more synchronisations per image); 0 (default) = the count stays on the device. */
-#define IA3_TUNE_SYNC_SEEDS 7
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
