@@ -344,3 +344,29 @@ def test_phase_correlation_real_transforms_equal_complex_transforms():
                     assert abs(e0 - e1) <= 1e-7 and abs(p0 - p1) <= 1e-7, (ref.shape, norm, up, e0, e1, p0, p1)
     finally:
         L.check(L.lib().ia3_set_tuning(6, 0))
+
+
+def test_fit_fovs_batch_entry():
+    """ia3_fit_fovs (one C call, library-owned threads and streams): host and resident jobs in one batch, an image without
+    seeds, the capacity retry of the wrapper, per-job counters — tables equal to fit_fov_image call by call."""
+    from conftest import build_case
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    im = build_case("c1_f32")
+    flat = np.full(im.shape, 400, dtype=np.float32)
+    ref = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    sp, keep = L.make_seed_params(600.0, max_num_seeds=None)
+    fp = L.make_fit_params()
+    with L.DeviceStack.upload(im) as st:
+        jobs = [im, st, flat, st, im, np.ascontiguousarray(im[::-1])]
+        for depth, cap in ((1, 16384), (3, 16384), (6, 8)):        # cap 8 < rows: IA3_ECAPACITY, then retried
+            tabs, info = L.fit_fovs(jobs, sp, fp, in_flight=depth, capacity=cap)
+            assert len(tabs) == len(jobs)
+            for k in (0, 1, 3, 4):
+                assert np.array_equal(tabs[k], ref), (depth, k)
+                assert info[k]["n_seeds"] == len(ref) and info[k]["fits"] >= len(ref) and info[k]["voxel_evals"] > info[k]["nfev"] > 0
+            assert tabs[2].shape == (0, 11) and info[2]["n_seeds"] == 0 and info[2]["fits"] == 0
+            assert len(tabs[5]) == len(ref)
+    with pytest.raises(ValueError):
+        L.fit_fovs([im, im.astype(np.uint16)], sp, fp)
+    assert L.fit_fovs([], sp, fp) == ([], [])
