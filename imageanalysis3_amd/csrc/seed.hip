@@ -316,49 +316,93 @@ __global__ __launch_bounds__(256) void blockbound_k(const float* __restrict__ bm
   lb[i] = (double)m - 2e-6 * (double)a - (is_u16 ? 2.0 : 0.0);
 }
 
-// 3x3x3 local maxima of max_im that pass the edge test and the bound test -> Cand0 list, as a streaming kernel: the
-// bound test comes first — it fails for all but ~1 % of the voxels and for
-// three quarters of the 64-voxel wave rows outright, which then cost one coalesced load per voxel — and only the lanes that
-// pass look at their 26 neighbours (clamped indices = the rank filter's reflect border; served by L2).  A block walks
-// XB consecutive x rows of one plane, 256 voxels along y each.
-template <class T, int B, int XB>
-__global__ __launch_bounds__(256) void seed_cand3_stream(const T* __restrict__ mx, const double* __restrict__ lb, int nbx, int nby,
-                                                         int Z, int X, int Y, int edge, double th_test,
-                                                         Cand0* __restrict__ out, unsigned capacity,
-                                                         SeedCtl* __restrict__ ctl) {
-  const int y = blockIdx.x * 256 + threadIdx.x;
-  const int z = blockIdx.z;
-  const bool yin = y < Y;
-  const int ys = yin ? y : Y - 1;
-  const size_t plane = (size_t)X * Y;
-  const T* pz = mx + (size_t)z * plane;
-  const bool z_ok = edge <= 0 || (z >= edge && z <= Z - edge);
-  const bool y_ok = yin && (edge <= 0 || (y >= edge && y <= Y - edge));
-  const int x_begin = blockIdx.y * XB, x_end = x_begin + XB < X ? x_begin + XB : X;
-  for (int x = x_begin; x < x_end; ++x) {
-    const T v = pz[(size_t)x * Y + ys];
-    const double bound = lb[((size_t)z * nbx + x / B) * nby + ys / B];
-    bool hit = z_ok && y_ok && (edge <= 0 || (x >= edge && x <= X - edge)) && ((double)v - bound >= th_test);
-    if (!__any(hit)) continue;                       // wave-uniform: most rows end here
-    if (hit) {
-      const int z0 = max(z - 1, 0), z1 = min(z + 1, Z - 1), x0 = max(x - 1, 0), x1 = min(x + 1, X - 1),
-                y0 = max(y - 1, 0), y1 = min(y + 1, Y - 1);
-      for (int zz = z0; zz <= z1 && hit; ++zz)
-        for (int xx = x0; xx <= x1 && hit; ++xx) {
-          const T* row = mx + (size_t)zz * plane + (size_t)xx * Y;
-          for (int yy = y0; yy <= y1; ++yy) hit = hit && !(row[yy] > v);   // local maximum: no neighbour is larger
-        }
+// 3x3x3 local maxima of max_im that pass the edge test and the bound test -> Cand0 list.  Same tiling as
+// seed_detect3_tiled (16 x 64 tile + halo in LDS, double-buffered, rolling three-plane pipeline along z), one stack.
+template <class T, int ZC, int B>
+__global__ __launch_bounds__(256) void seed_cand3_tiled(const T* __restrict__ mx, const double* __restrict__ lb, int nbx, int nby,
+                                                        int Z, int X, int Y, int edge, double th_test,
+                                                        Cand0* __restrict__ out, unsigned capacity,
+                                                        SeedCtl* __restrict__ ctl) {
+  constexpr int TX = 16, TY = 64, HX = TX + 2, HY = TY + 2, NE = (HX * HY + 255) / 256;
+  static_assert(B % TX == 0, "a tile must lie inside one block row");
+  __shared__ T tmax[2][HX][HY + 2];
+  const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
+  const int tile = xcd_tile(blockIdx.x, nty * ntx);
+  if (tile < 0) return;
+  const int x0 = (tile / nty) * TX, y0 = (tile % nty) * TY;
+  const int z0 = blockIdx.z * ZC, z1 = z0 + ZC < Z ? z0 + ZC : Z;
+  const int ty = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  size_t goff[NE]; int lr[NE], lc[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int r = e / HY, c = e % HY;
+    lr[i] = e < HX * HY ? r : -1; lc[i] = c;
+    const int gx = min(max(x0 + r - 1, 0), X - 1), gy = min(max(y0 + c - 1, 0), Y - 1);
+    goff[i] = (size_t)gx * Y + gy;
+  }
+  T ra[NE];
+  auto fetch = [&](int q) {
+    const int zq = q < 0 ? 0 : (q >= Z ? Z - 1 : q);
+    const size_t pz = (size_t)zq * X * Y;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (lr[i] >= 0) ra[i] = mx[pz + goff[i]];
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (lr[i] >= 0) tmax[buf][lr[i]][lc[i]] = ra[i];
+  };
+  T pM[4][3], cM[4][2];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { pM[v][0] = pM[v][1] = pM[v][2] = 0; cM[v][0] = cM[v][1] = 0; }
+  const int yb = min(y0 + ty, Y - 1) / B;
+  const size_t lrow = (size_t)(x0 / B) * nby + yb;
+  fetch(z0 - 1);
+  stash(0);
+  __syncthreads();
+  for (int q = z0 - 1, buf = 0; q <= z1; ++q, buf ^= 1) {
+    if (q < z1) fetch(q + 1);
+    {
+      const int c = ty + 1;
+      T hM[6], ce[4];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        const int r = tg * 4 + rr;
+        const T a0 = tmax[buf][r][c - 1], a1 = tmax[buf][r][c], a2 = tmax[buf][r][c + 1];
+        hM[rr] = max3v(a0, a1, a2);
+        if (rr >= 1 && rr <= 4) ce[rr - 1] = a1;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const T a = max3v(hM[v], hM[v + 1], hM[v + 2]);
+        pM[v][0] = pM[v][1]; pM[v][1] = pM[v][2]; pM[v][2] = a;
+        cM[v][0] = cM[v][1]; cM[v][1] = ce[v];
+      }
     }
-    const unsigned long long ballot = __ballot(hit);
-    if (ballot) {
-      const int lane = threadIdx.x & 63;
-      unsigned basepos = 0;
-      if (lane == 0) basepos = atomicAdd(&ctl->n_cand, (unsigned)__popcll(ballot));
-      basepos = __shfl(basepos, 0);
-      if (hit) {
-        unsigned pos = basepos + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
-        if (pos < capacity) out[pos] = Cand0{z, x, y, (float)v};
-        else ctl->overflow = 1;
+    if (q < z1) stash(buf ^ 1);
+    __syncthreads();
+    const int z = q - 1;
+    if (z < z0) continue;
+    const double bound = lb[(size_t)z * nbx * nby + lrow];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int x = x0 + tg * 4 + v, y = y0 + ty;
+      const T vmax = max3v(pM[v][0], pM[v][1], pM[v][2]);
+      const T cmax = cM[v][0];
+      bool hit = x < X && y < Y && (vmax == cmax) && ((double)cmax - bound >= th_test);
+      if (edge > 0)
+        hit = hit && z >= edge && z <= Z - edge && x >= edge && x <= X - edge && y >= edge && y <= Y - edge;
+      const unsigned long long ballot = __ballot(hit);
+      if (ballot) {
+        const int lane = threadIdx.x & 63;
+        unsigned basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&ctl->n_cand, (unsigned)__popcll(ballot));
+        basepos = __shfl(basepos, 0);
+        if (hit) {
+          unsigned pos = basepos + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
+          if (pos < capacity) out[pos] = Cand0{z, x, y, (float)cmax};
+          else ctl->overflow = 1;
+        }
       }
     }
   }
@@ -378,7 +422,7 @@ struct TapsD { double w[64]; };   // w[j] = tap at offset j (symmetric), j <= R
 //   loads); then lane k < 27 of wave 0 runs the axis-2 pass at (row k / 3, y' = clamp(y + k % 3 - 1)) over its row in
 //   LDS.  Both passes: acc = in[0] * w0; for j = R..1: acc = acc + (in[-j] + in[+j]) * w[j]  (this file is compiled
 //   with -ffp-contract=off), as NI_Correlate1D and the dense kernels do.
-template <class T, int RT>   // RT > 0: radius known at compile time (all 2 RT + 1 loads of a row position in flight at once)
+template <class T>
 __global__ __launch_bounds__(576) void bg_sparse_k(const T* __restrict__ zp, int Z, int X, int Y, TapsD taps, int R, int mode,
                                                    const Cand0* __restrict__ c0, const SeedCtl* __restrict__ ctl0,
                                                    unsigned cap0, double th_low, Cand* __restrict__ out, unsigned capacity,
@@ -388,7 +432,6 @@ __global__ __launch_bounds__(576) void bg_sparse_k(const T* __restrict__ zp, int
   __shared__ float mval[32];
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned n0 = ctl0->n_cand < cap0 ? ctl0->n_cand : cap0;
-  if constexpr (RT > 0) R = RT;
   const int ni = 2 * R + 3;
   for (unsigned c = blockIdx.x; c < n0; c += gridDim.x) {   // block-uniform
     const Cand0 k = c0[c];
@@ -397,27 +440,12 @@ __global__ __launch_bounds__(576) void bg_sparse_k(const T* __restrict__ zp, int
       const T* pl = zp + (size_t)zz * X * Y;
       for (int i = lane; i < ni; i += 64) {
         const int yy = reflect_idx(k.y - 1 - R + i, Y, mode);
-        double acc;
-        if constexpr (RT > 0) {
-          // the pass is a chain of dependent additions, its loads are not: fetch the whole column of taps first
-          T va[RT], vb[RT];
-          const T vc = pl[(size_t)xx * Y + yy];
-#pragma unroll
-          for (int j = 1; j <= RT; ++j) {
-            va[j - 1] = pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
-            vb[j - 1] = pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
-          }
-          acc = (double)vc * taps.w[0];
-#pragma unroll
-          for (int j = RT; j >= 1; --j) acc = acc + ((double)va[j - 1] + (double)vb[j - 1]) * taps.w[j];
-        } else {
-          acc = (double)pl[(size_t)xx * Y + yy] * taps.w[0];
+        double acc = (double)pl[(size_t)xx * Y + yy] * taps.w[0];
 #pragma unroll 8
-          for (int j = R; j >= 1; --j) {
-            const double a = (double)pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
-            const double b = (double)pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
-            acc = acc + (a + b) * taps.w[j];
-          }
+        for (int j = R; j >= 1; --j) {
+          const double a = (double)pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
+          const double b = (double)pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
+          acc = acc + (a + b) * taps.w[j];
         }
         trow[r][i] = quant<T>(acc);
       }
@@ -679,26 +707,23 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
   }
   {
     ProfScope ps("seed_detect");
+    constexpr int ZT = 64;
+    const unsigned tiles = (unsigned)((Y + 63) / 64) * (unsigned)((X + 15) / 16);
+    dim3 gt(8 * ((tiles + 7) / 8), 1, (unsigned)((Z + ZT - 1) / ZT));
     const double th_test = th_low - fabs(th_low) * 1e-6 - 1e-300;   // the exact test is made in float32: keep the bound test looser
-    constexpr int XB = 8;
-    dim3 gs((unsigned)((Y + 255) / 256), (unsigned)((X + XB - 1) / XB), (unsigned)Z);
     if (B == 32)
-      hipLaunchKernelGGL((seed_cand3_stream<T, 32, XB>), gs, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
+      hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 32>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
                          th_test, c0, LAZY_CAP, ctl0);
     else
-      hipLaunchKernelGGL((seed_cand3_stream<T, 64, XB>), gs, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
+      hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 64>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
                          th_test, c0, LAZY_CAP, ctl0);
   }
   {
     ProfScope ps("seed_sparse_bg");
     TapsD t;
     for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
-    if (R == 30)
-      hipLaunchKernelGGL((bg_sparse_k<T, 30>), dim3(4096), dim3(576), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
-                         (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
-    else
-      hipLaunchKernelGGL((bg_sparse_k<T, 0>), dim3(4096), dim3(576), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
-                         (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
+    hipLaunchKernelGGL((bg_sparse_k<T>), dim3(4096), dim3(576), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
+                       (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
   }
 }
 
