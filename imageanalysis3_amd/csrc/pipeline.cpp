@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <unistd.h>
 
 using namespace ia3rt;
@@ -101,9 +102,10 @@ void pool_run(int workers, const std::function<void()>& fn) {
     if (!g_pool || g_pool->pid != getpid()) { g_pool = new Pool(); g_pool->pid = getpid(); }
     p = g_pool;
   }
-  std::mutex done_mu;
-  std::condition_variable done_cv;
-  int left = workers;
+  // completion state outlives this frame until the last worker has let go of it (shared ownership)
+  struct Sync { std::mutex mu; std::condition_variable cv; int left; };
+  auto sync = std::make_shared<Sync>();
+  sync->left = workers;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     for (; p->threads < workers; ++p->threads)
@@ -120,15 +122,15 @@ void pool_run(int workers, const std::function<void()>& fn) {
         }
       }).detach();
     for (int t = 0; t < workers; ++t)
-      p->q.push_back([&] {
-        fn();
-        std::lock_guard<std::mutex> lk(done_mu);
-        if (--left == 0) done_cv.notify_all();
+      p->q.push_back([&fn, sync] {
+        fn();   // fn lives in the caller's frame, which waits below until every worker has returned from it
+        std::lock_guard<std::mutex> lk(sync->mu);
+        if (--sync->left == 0) sync->cv.notify_all();
       });
   }
   p->cv.notify_all();
-  std::unique_lock<std::mutex> lk(done_mu);
-  done_cv.wait(lk, [&] { return left == 0; });
+  std::unique_lock<std::mutex> lk(sync->mu);
+  sync->cv.wait(lk, [&] { return sync->left == 0; });
 }
 }  // namespace
 
