@@ -48,7 +48,10 @@ IA3_HD constexpr int tri(int i, int j) {  // packed upper-triangle index, i <= j
 #if defined(__HIP_DEVICE_COMPILE__)
 #define IA3_LM_PAR 1
 #define IA3_LM_SYNC() __builtin_amdgcn_wave_barrier()
-__device__ __forceinline__ int lm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// lane index inside a group of LW lanes (64: one fit per wave; 32: the paired solver of fit.hip, one fit per half-wave)
+template <int LW> __device__ __forceinline__ int lm_lane() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & (LW - 1);
+}
 #else
 #define IA3_LM_PAR 0
 #endif
@@ -147,12 +150,13 @@ IA3_HD double lm_norm(const double* v) {
 }
 
 // t1[j] = diag[j] * ((diag[j] * x[j]) / dxnorm);  t2[j] = diag[j] * x[j] is passed in for the serial form
+template <int LW = 64>
 IA3_HD void lm_scaled(const double* diag, const double* x, const double* t2, double dxnorm, double* t1, double* sc) {
 #if IA3_LM_PAR
   IA3_UNROLL
   for (int j = 0; j < NP; ++j) sc[NP + j] = x[j];          // wave-uniform values: every lane stores the same
   IA3_LM_SYNC();
-  const int ln = lm_lane();
+  const int ln = lm_lane<LW>();
   if (ln < NP) { const double d = diag[ln]; sc[ln] = d * ((d * sc[NP + ln]) / dxnorm); }
   IA3_LM_SYNC();
   IA3_UNROLL
@@ -168,6 +172,7 @@ IA3_HD void lm_scaled(const double* diag, const double* x, const double* t2, dou
 
 // lmpar on the normal equations: find par with | |D x| - delta | <= 0.1 delta, x = (A+par D²)⁻¹ g
 // sc: 2*NP doubles of scratch (LDS on the device)
+template <int LW = 64>
 IA3_HD void lm_par(const double* A, const double* g, const double* diag, double delta, double& par, double* x,
                    double* sc) {
   Chol c;
@@ -183,14 +188,14 @@ IA3_HD void lm_par(const double* A, const double* g, const double* diag, double 
   if (fp <= 0.1 * delta) { par = 0.0; return; }
   double parl = 0.0;
   if (c.skip == 0) {
-    lm_scaled(diag, x, t2, dxnorm, t1, sc);
+    lm_scaled<LW>(diag, x, t2, dxnorm, t1, sc);
     lm_fwd(c, t1, t1);
     double temp = lm_norm(t1);
     parl = ((fp / delta) / temp) / temp;
   }
 #if IA3_LM_PAR
   {
-    const int ln = lm_lane();
+    const int ln = lm_lane<LW>();
     if (ln < NP) sc[ln] = g[ln] / diag[ln];
     IA3_LM_SYNC();
     IA3_UNROLL
@@ -219,7 +224,7 @@ IA3_HD void lm_par(const double* A, const double* g, const double* diag, double 
     double temp = fp;
     fp = dxnorm - delta;
     if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-    lm_scaled(diag, x, t2, dxnorm, t1, sc);
+    lm_scaled<LW>(diag, x, t2, dxnorm, t1, sc);
     lm_fwd(c, t1, t1);
     temp = lm_norm(t1);
     double parc = ((fp / delta) / temp) / temp;
@@ -244,7 +249,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
   for (;;) {  // outer loop: A, g hold JᵀJ, Jᵀf at x
 #if IA3_LM_PAR
     {
-      const int ln = lm_lane();
+      const int ln = lm_lane<64>();
       if (ln < NP) w.cn[ln] = sqrt(Ac[tri(ln, ln)]);
       IA3_LM_SYNC();
     }
@@ -267,7 +272,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
     if (fnorm != 0.0) {
 #if IA3_LM_PAR
       {
-        const int ln = lm_lane();
+        const int ln = lm_lane<64>();
         if (ln < NP) { const double cnl = w.cn[ln]; if (cnl != 0.0) w.sc[ln] = fabs((gc[ln] / fnorm) / cnl); }
         IA3_LM_SYNC();
       }
@@ -290,7 +295,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
     if (gnorm <= gtol) { r.info = 4; break; }
 #if IA3_LM_PAR
     {
-      const int ln = lm_lane();
+      const int ln = lm_lane<64>();
       if (ln < NP) { const double dl = w.diag[ln], cl = w.cn[ln]; w.diag[ln] = dl > cl ? dl : cl; }
       IA3_LM_SYNC();
     }
@@ -315,7 +320,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       double jp2 = 0.0;
 #if IA3_LM_PAR
       {
-        const int ln = lm_lane();
+        const int ln = lm_lane<64>();
         if (ln < NP) {   // row ln of A times p, columns in ascending order as in the serial form
           double s = 0.0;
           IA3_UNROLL

@@ -71,6 +71,10 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_FFT_C2C: 1 = the phase correlation transforms the (real) stacks with complex-to-complex FFTs (first
  * version); 0 (default) = real-input transforms on half spectra.  Shifts agree to rounding. */
 #define IA3_TUNE_FFT_C2C 6
+/* IA3_TUNE_FIT_PAIRS: 1 (default) = the fit kernel works on two seeds per wavefront (evaluations one after the other on
+ * all lanes, the 10 x 10 trust-region algebra of both at once, one per half-wave); 0 = one seed per wavefront (first
+ * version).  Tables are identical bit for bit. */
+#define IA3_TUNE_FIT_PAIRS 7
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
