@@ -55,6 +55,7 @@ struct FitArgs {
   const void* im; int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
   int n;                    // number of seeds
+  int fuse;                 // a seed without neighbours: first fit and sweep 1 by the same wave (see fit_stages_k)
   int nb_cap;               // lists longer than this are not used (MAXNB; lowered by IA3_TUNE_FIT_NBLIST in tests)
   double nb_r2;             // (2r)²: seeds closer than this interact
   const int* nbr_cnt;       // n: number of neighbours of seed i (NOT clamped: > MAXNB = list overflow, see each_neighbour)
@@ -528,18 +529,6 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, Ball& ball
   return (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
 }
 
-__device__ __forceinline__ void do_first(const FitArgs& fa, LMWork& w, int i) {
-  const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
-  Ball ball;
-  double vals[SLOTS];
-  const int n = gather_first(fa, i, ball, vals);
-  float p[11];
-  int nfev = 0;
-  const bool ok = n >= NP;  // :382-383
-  if (ok) nfev = wave_gaussfit(fa, w, ball, vals, fa.dtype == IA3_F32 ? 0 : 1, c0, fa.delta_first, n, p);
-  store_result(fa, i, p, w, fa.delta_first, ok, n, nfev);
-}
-
 // ---- stage k >= 1 = one seed's refit in sweep k of repeatfit (:651-680) ---------------------------------
 // the full ball, data = image minus the current reconstructions of the overlapping seeds; returns the voxel count
 __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, Ball& ball, double* vals) {
@@ -590,23 +579,47 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, Ball& bal
   return (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
 }
 
-// returns "converged"
-__device__ __forceinline__ bool do_repeat(const FitArgs& fa, LMWork& w, int i) {
+// ---- one work-list position ------------------------------------------------------------------------------------------
+// mode 0: first fit (stage 0).  mode 1: refit in sweep k >= 1; returns "converged" (:677-680).
+// mode 2: a seed WITHOUT neighbours, stage 0 and sweep 1 by one wave.  No other seed's ball overlaps this one, so its
+//   Voronoi cell is the whole ball and the residual image it refits in sweep 1 is the original image: both fits see the
+//   SAME voxels and values (they differ in delta_center and in the arithmetic of the start point, Fitting_v4.py:175-182 on
+//   float32 / integer data vs on the float64 residual).  The wave gathers the ball once, fits twice and hands over once;
+//   the work-list position of the seed's sweep 1 finds done[i] >= 2 and leaves.  Same operations on the same operands
+//   as the two separate positions; returns "converged".
+// The fit itself has ONE call site (the kernel is instruction-cache bound enough as it is).
+__device__ __forceinline__ bool run_position(const FitArgs& fa, LMWork& w, int i, int mode) {
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   Ball ball;
   double vals[SLOTS];
-  const int n = gather_repeat(fa, i, ball, vals);
-  const int success_old = LDH(&fa.state[i].success);
-  const float co0 = LDH(&fa.ps[(size_t)i * 11 + 1]), co1 = LDH(&fa.ps[(size_t)i * 11 + 2]),
-              co2 = LDH(&fa.ps[(size_t)i * 11 + 3]);
+  const int n = mode == 1 ? gather_repeat(fa, i, ball, vals) : gather_first(fa, i, ball, vals);
+  int success_old = 0;
+  float co0 = 0.f, co1 = 0.f, co2 = 0.f;
+  if (mode == 1) {
+    success_old = LDH(&fa.state[i].success);
+    co0 = LDH(&fa.ps[(size_t)i * 11 + 1]); co1 = LDH(&fa.ps[(size_t)i * 11 + 2]); co2 = LDH(&fa.ps[(size_t)i * 11 + 3]);
+  }
   float p[11];
-  int nfev = 0;
-  const bool ok = n >= NP;
-  if (ok) nfev = wave_gaussfit(fa, w, ball, vals, 2, c0, fa.delta_repeat, n, p);
-  store_result(fa, i, p, w, fa.delta_repeat, ok, n, nfev);
+  const bool ok = n >= NP;  // :382-383 (mode 2: for both fits, same voxels)
+  int nfev = 0, nfev_first = 0;
+  const int npass = mode == 2 ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool refit = mode == 1 || pass == 1;
+    if (pass == 1) { success_old = ok ? 1 : 0; co0 = p[1]; co1 = p[2]; co2 = p[3]; nfev_first = nfev; }
+    // a refit sees the float64 residual (kind 2) and casts it to float32 (:172); the first fit the stack's own dtype
+    if (ok) nfev = wave_gaussfit(fa, w, ball, vals, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
+                                 refit ? fa.delta_repeat : fa.delta_first, n, p);
+  }
+  if (mode == 2 && ok && (threadIdx.x & 63) == 0) {   // the first fit's share of the bookkeeping store_result does per fit
+    atomicAdd(&fa.counters[0], 1ull);
+    atomicAdd(&fa.counters[1], (unsigned long long)nfev_first);
+    atomicAdd(&fa.counters[2], (unsigned long long)nfev_first * (unsigned long long)n);
+  }
+  store_result(fa, i, p, w, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
   // convergence (:677-680): float32 centre differences, compared in float64
   bool cv = true;
-  if (ok && success_old) {
+  if (mode != 0 && ok && success_old) {
     const float d0 = co0 - p[1], d1 = co1 - p[2], d2 = co2 - p[3];
     const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
     cv = (double)dist < fa.dist_th2;
@@ -672,10 +685,23 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
   const int k = stage0 + (int)(pos / (unsigned)n);
   const int i = (int)(pos % (unsigned)n);   // seed order inside a stage: lower-index neighbours come first
   if (k == 0) {
-    do_first(fa, w, i);
-    publish(done, i, 1);
+    // sweep 1 is part of this launch and nothing overlaps this seed: both of its fits from this wave (run_position)
+    const bool fused = fa.fuse && stage1 >= 2 && fa.nbr_cnt[i] == 0;
+    const bool cv = run_position(fa, w, i, fused ? 2 : 0);
+    if (fused) {
+      if (lane == 0) {
+        st_sc1(&fa.state[i].conv, cv ? 1 : 0);
+        atomicMax(fa.n_iter, 1);
+        if (cv) atomicSub(&ctl->n_unconv, 1);
+      }
+      publish(done, i, 2);
+    } else {
+      publish(done, i, 1);
+    }
     return;
   }
+  // sweep k of this seed already made by the wave of an earlier position (the fused first fit above)
+  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return;
   // nothing left to refit anywhere: every remaining position is a skip.  The claimed position is still
   // published (as "all stages done") so that a block which passed this check earlier and waits on it can go on.
   if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
@@ -689,7 +715,7 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
   each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
   if (!alive) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const bool cv = do_repeat(fa, w, i);
+  const bool cv = run_position(fa, w, i, 1);
   if (lane == 0) {
     st_sc1(&fa.state[i].conv, cv ? 1 : 0);
     atomicMax(fa.n_iter, k);
@@ -698,340 +724,6 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
   publish(done, i, k + 1);
 }
 
-
-// ==== two fits per wave ==========================================================================================
-// A fit's wave spends more than half of its instructions on the 10 x 10 trust-region algebra, which every lane executes
-// identically (control flow has to stay uniform), and the kernel is held to one wave per SIMD by its registers.  Here a
-// wave works on TWO seeds: the evaluations — residuals, Jacobian rows, J^T J, the only part that is parallel over voxels —
-// run one fit after the other on all 64 lanes exactly as before, the algebra of both fits runs at the same time, lanes
-// 0-31 on the first fit's work area and lanes 32-63 on the second's.  Each fit performs the operations of the single-fit
-// solver on the same operands in the same order (results are bit-identical, tests compare the two kernels); the
-// divergent branches of lmpar / lmder simply execute under the half-wave masks, and a fit that has finished idles in its
-// half while its partner (a straggler, say) goes on with full-width evaluations.
-enum { PH_E0 = 0, PH_ET = 1, PH_HEAD = 2, PH_PRE = 3, PH_DONE = 4 };
-
-struct PairShared {              // per wave (one wave per block)
-  LMWork w[2];
-  BallLds bl[2];
-  FitCfg cfg[2];
-  unsigned valid[2][64];         // slot masks of the two balls
-  double gsc[64];
-};
-
-// lm_solve (ia3_lm.h) for two problems, written as a state machine so that both halves reach their evaluations together.
-// `live`: this lane's half has a problem.  Returns this half's LMResult in every lane of the half.
-__device__ __forceinline__ LMResult lm_solve_pair(PairShared& sh, bool live, double ftol, double xtol, double gtol, int maxfev,
-                                                  double factor) {
-  const int lane = threadIdx.x & 63, half = lane >> 5;
-  LMWork* W = &sh.w[half];
-  LMResult r;
-  r.info = 0; r.nfev = 1; r.iter = 1; r.fnorm = 0.0;
-  double par = 0.0, delta = 0.0, xnorm = 0.0, fnorm = 0.0, gnorm = 0.0, pnorm = 0.0, jp2 = 0.0, fres = 0.0;
-  int sw = 0;                    // 0: (A, g) hold the accepted point and (A1, g1) the trial point; 1: the other way round
-  int phase = live ? PH_E0 : PH_DONE;
-  for (;;) {
-    // ---- evaluations: wave-uniform, one fit after the other on all 64 lanes ----
-#pragma unroll 1
-    for (int f = 0; f < 2; ++f) {
-      const int ph = __builtin_amdgcn_readlane(phase, 32 * f);
-      if (ph != PH_E0 && ph != PH_ET) continue;
-      const int swf = __builtin_amdgcn_readlane(sw, 32 * f);
-      LMWork& wf = sh.w[f];
-      const bool trial = ph == PH_ET;
-      const bool second = (swf != 0) != trial;            // accepted point lives in (A1, g1) iff sw; the trial point in the other pair
-      WaveEval ev;
-      ev.b = &sh.bl[f]; ev.cfgp = &sh.cfg[f]; ev.gsc = sh.gsc; ev.valid = sh.valid[f][lane];
-      const double fn = ev.eval(trial ? wf.xt : wf.x, second ? wf.A1 : wf.A, second ? wf.g1 : wf.g);
-      if (half == f) fres = fn;
-    }
-    // ---- algebra: each half on its own problem ----
-    double* Ac = sw ? W->A1 : W->A; double* gc = sw ? W->g1 : W->g;
-    if (phase == PH_E0) { fnorm = fres; phase = PH_HEAD; }
-    else if (phase == PH_ET) {
-      const double fnorm1 = fres;
-      ++r.nfev;
-      double actred = -1.0;
-      if (0.1 * fnorm1 < fnorm) { double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
-      double temp1 = sqrt(jp2) / fnorm;
-      double temp2 = (sqrt(par) * pnorm) / fnorm;
-      double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-      double dirder = -(temp1 * temp1 + temp2 * temp2);
-      double ratio = prered != 0.0 ? actred / prered : 0.0;
-      if (ratio <= 0.25) {
-        double temp;
-        if (actred >= 0.0) temp = 0.5;
-        else temp = 0.5 * dirder / (dirder + 0.5 * actred);
-        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-        double pm = pnorm / 0.1;
-        delta = temp * (delta < pm ? delta : pm);
-        par = par / temp;
-      } else if (par == 0.0 || ratio >= 0.75) {
-        delta = pnorm / 0.5;
-        par = 0.5 * par;
-      }
-      if (ratio >= 1e-4) {  // successful iteration
-        double t[NP];
-        IA3_UNROLL
-        for (int j = 0; j < NP; ++j) { W->x[j] = W->xt[j]; t[j] = W->diag[j] * W->xt[j]; }
-        sw ^= 1;
-        xnorm = lm_norm(t);
-        fnorm = fnorm1;
-        ++r.iter;
-      }
-      bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-      if (small) r.info = 1;
-      if (delta <= xtol * xnorm) r.info = 2;
-      if (small && r.info == 2) r.info = 3;
-      if (r.info == 0) {
-        if (r.nfev >= maxfev) r.info = 5;
-        if (fabs(actred) <= IA3_EPSMCH && prered <= IA3_EPSMCH && 0.5 * ratio <= 1.0) r.info = 6;
-        if (delta <= IA3_EPSMCH * xnorm) r.info = 7;
-        if (gnorm <= IA3_EPSMCH) r.info = 8;
-      }
-      phase = r.info != 0 ? PH_DONE : (ratio >= 1e-4 ? PH_HEAD : PH_PRE);
-      Ac = sw ? W->A1 : W->A; gc = sw ? W->g1 : W->g;
-    }
-    if (phase == PH_HEAD) {   // outer loop head: A, g hold J^T J, J^T f at x
-      const int ln = lane & 31;
-      if (ln < NP) W->cn[ln] = sqrt(Ac[tri(ln, ln)]);
-      __builtin_amdgcn_wave_barrier();
-      if (r.iter == 1) {
-        double t[NP];
-        IA3_UNROLL
-        for (int j = 0; j < NP; ++j) {
-          W->diag[j] = W->cn[j] == 0.0 ? 1.0 : W->cn[j];
-          t[j] = W->diag[j] * W->x[j];
-        }
-        xnorm = lm_norm(t);
-        delta = factor * xnorm;
-        if (delta == 0.0) delta = factor;
-      }
-      gnorm = 0.0;
-      if (fnorm != 0.0) {
-        if (ln < NP) { const double cnl = W->cn[ln]; if (cnl != 0.0) W->sc[ln] = fabs((gc[ln] / fnorm) / cnl); }
-        __builtin_amdgcn_wave_barrier();
-        IA3_UNROLL
-        for (int j = 0; j < NP; ++j) {
-          if (W->cn[j] != 0.0) { const double v = W->sc[j]; gnorm = gnorm > v ? gnorm : v; }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (gnorm <= gtol) { r.info = 4; phase = PH_DONE; }
-      else {
-        if (ln < NP) { const double dl = W->diag[ln], cl = W->cn[ln]; W->diag[ln] = dl > cl ? dl : cl; }
-        __builtin_amdgcn_wave_barrier();
-        phase = PH_PRE;
-      }
-    }
-    if (phase == PH_PRE) {    // inner loop up to the trial evaluation
-      double pv[NP], t[NP];
-      lm_par<32>(Ac, gc, W->diag, delta, par, pv, W->sc);
-      IA3_UNROLL
-      for (int j = 0; j < NP; ++j) {
-        pv[j] = -pv[j];
-        W->p[j] = pv[j];
-        W->xt[j] = W->x[j] + pv[j];
-        t[j] = W->diag[j] * pv[j];
-      }
-      pnorm = lm_norm(t);
-      if (r.iter == 1) delta = delta < pnorm ? delta : pnorm;
-      jp2 = 0.0;
-      {
-        const int ln = lane & 31;
-        if (ln < NP) {   // row ln of A times p, columns in ascending order as in the serial form
-          double s_ = 0.0;
-          IA3_UNROLL
-          for (int j = 0; j < NP; ++j) s_ += (ln <= j ? Ac[tri(ln, j)] : Ac[tri(j, ln)]) * pv[j];
-          W->sc[ln] = s_;
-        }
-        __builtin_amdgcn_wave_barrier();
-        IA3_UNROLL
-        for (int i = 0; i < NP; ++i) jp2 += pv[i] * W->sc[i];
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (jp2 < 0.0) jp2 = 0.0;
-      phase = PH_ET;
-    }
-    if (__ballot(phase != PH_DONE) == 0ull) break;
-  }
-  r.fnorm = fnorm;
-  return r;
-}
-
-// what one half of a paired wave is working on
-struct PairTask {
-  int kind;          // 0 nothing, 1 first fit, 2 refit
-  int k, i;          // stage, seed
-  int n;             // voxels
-  bool ok;           // n >= NP: a fit is made
-  double delta;
-  int success_old;   // refit: state before this sweep
-  float co[3];       // refit: centre before this sweep
-};
-
-// gather + start point of task t into slot f of the shared block (wave-wide)
-__device__ __forceinline__ void pair_prepare(const FitArgs& fa, PairShared& sh, int f, PairTask& t) {
-  const int lane = threadIdx.x & 63;
-  Ball ball;
-  double vals[SLOTS];
-  int kind;
-  if (t.kind == 1) {
-    t.n = gather_first(fa, t.i, ball, vals);
-    t.delta = fa.delta_first;
-    kind = fa.dtype == IA3_F32 ? 0 : 1;
-  } else {
-    t.n = gather_repeat(fa, t.i, ball, vals);
-    t.delta = fa.delta_repeat;
-    kind = 2;
-    t.success_old = LDH(&fa.state[t.i].success);
-    t.co[0] = LDH(&fa.ps[(size_t)t.i * 11 + 1]); t.co[1] = LDH(&fa.ps[(size_t)t.i * 11 + 2]); t.co[2] = LDH(&fa.ps[(size_t)t.i * 11 + 3]);
-  }
-  t.ok = t.n >= NP;   // Fitting_v4.py:382-383
-  sh.valid[f][lane] = t.ok ? ball.valid : 0u;
-  if (!t.ok) return;
-  BallLds& bl = sh.bl[f];
-#pragma unroll
-  for (int sl = 0; sl < SLOTS; ++sl) {
-    bl.dat[sl][lane] = ball.dat[sl]; bl.cz[sl][lane] = ball.cz[sl]; bl.cx[sl][lane] = ball.cx[sl]; bl.cy[sl][lane] = ball.cy[sl];
-  }
-  FitCfg& cfg = sh.cfg[f];   // wave-uniform: every lane writes the same values
-  cfg.min_ws = fa.min_ws; cfg.max_ws = fa.max_ws; cfg.delta = t.delta; cfg.init_w = fa.init_w;
-  cfg.c0[0] = fa.seeds[3 * t.i]; cfg.c0[1] = fa.seeds[3 * t.i + 1]; cfg.c0[2] = fa.seeds[3 * t.i + 2];
-  cfg.variant = fa.variant; cfg.iw[0] = fa.iw[0]; cfg.iw[1] = fa.iw[1]; cfg.iw[2] = fa.iw[2];
-  __builtin_amdgcn_wave_barrier();
-  double lo10[10], hi10[10];
-  wave_extremes(vals, ball.valid, lo10, hi10);
-  init_guess(lo10, hi10, kind, cfg, sh.w[f].x);
-  __builtin_amdgcn_wave_barrier();
-}
-
-// natural parameters, eps, hand-off of slot f's result; returns "converged" for refits
-__device__ __forceinline__ bool pair_finish(const FitArgs& fa, PairShared& sh, int f, const PairTask& t, int nfev) {
-  const int lane = threadIdx.x & 63;
-  float p[11];
-  if (t.ok) {
-    const FitCfg& cfg = sh.cfg[f];
-    to_natural(sh.w[f].x, cfg, p);
-    Geom gm;
-    make_geom(sh.w[f].x, cfg, gm);
-    const BallLds& bl = sh.bl[f];
-    const unsigned valid = sh.valid[f][lane];
-    double s_ = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl)
-      if (valid & (1u << sl))
-        s_ += fabs((gm.ebk_f + model_f0(gm, (double)bl.cz[sl][lane], (double)bl.cx[sl][lane], (double)bl.cy[sl][lane])) -
-                   (double)bl.dat[sl][lane]);
-    p[10] = (float)(wave_sum(s_) / (double)t.n);
-  }
-  store_result(fa, t.i, p, sh.w[f], t.delta, t.ok, t.n, t.ok ? nfev : 0);
-  bool cv = true;   // :677-680: float32 centre differences, compared in float64
-  if (t.kind == 2 && t.ok && t.success_old) {
-    const float d0 = t.co[0] - p[1], d1 = t.co[1] - p[2], d2 = t.co[2] - p[3];
-    const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
-    cv = (double)dist < fa.dist_th2;
-  }
-  return cv;
-}
-
-// non-blocking form of wait_done
-__device__ __forceinline__ bool is_done(const int* done, int j, int need) {
-  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= need;
-}
-
-// Admission of a refit (stage k >= 1, seed i), the rules of fit_stages_k: 1 = run it, 0 = nothing to do (published),
-// -1 = abort, 2 = its inputs are not there yet (only with block == false).
-__device__ __forceinline__ int pair_admit(const FitArgs& fa, int k, int i, StageCtl* ctl, int* done, bool block) {
-  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
-    publish(done, i, 1 << 20);
-    return 0;
-  }
-  if (block) { if (!wait_done(done, i, k, ctl)) return -1; }
-  else if (!is_done(done, i, k)) return 2;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return 0; }   // converged: skipped (:652)
-  int res = 1;
-  each_neighbour(fa, i, [&](int j) {
-    const int need = j < i ? k + 1 : k;
-    if (block) { if (!wait_done(done, j, need, ctl)) res = -1; }
-    else if (!is_done(done, j, need)) res = 2;
-    return res == 1;
-  });
-  if (res == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return res;
-}
-
-// One wave per PAIR of work-list positions (tickets 2t, 2t+1; the list and its dependency rules are those of
-// fit_stages_k).  The first position is admitted with blocking waits as before.  The second is paired with it only if its
-// inputs are complete at that moment — it may depend on the first (plateau twins are neighbours in the list AND in space),
-// and waiting for anything else would hold the first one back; otherwise it runs in a second round on its own.
-__global__ __launch_bounds__(64) void fit_pairs_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl, int* done) {
-  __shared__ PairShared sh;
-  const int lane = threadIdx.x & 63;
-  const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
-  unsigned pos0 = 0;
-  if (lane == 0) pos0 = atomicAdd(&ctl->claim, 2u);
-  pos0 = (unsigned)__builtin_amdgcn_readfirstlane((int)pos0);
-  if (pos0 >= total) return;
-  PairTask t[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const unsigned pos = pos0 + (unsigned)f;
-    t[f].kind = 0; t[f].k = 0; t[f].i = 0; t[f].n = 0; t[f].ok = false; t[f].delta = 0.0; t[f].success_old = 0;
-    t[f].co[0] = t[f].co[1] = t[f].co[2] = 0.f;
-    if (pos < total) {
-      t[f].k = stage0 + (int)(pos / (unsigned)n);
-      t[f].i = (int)(pos % (unsigned)n);
-      t[f].kind = t[f].k == 0 ? 1 : 2;
-    }
-  }
-  for (int round = 0; round < 2; ++round) {
-    bool run[2] = {false, false};
-    // admission: the first pending task blocks for its inputs, a second one joins only if it is ready now
-    bool first = true;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      if (t[f].kind == 0) continue;
-      int a = 1;
-      if (t[f].kind == 2) a = pair_admit(fa, t[f].k, t[f].i, ctl, done, first);
-      if (a < 0) return;
-      if (a == 0) { t[f].kind = 0; continue; }
-      if (a == 1) { run[f] = true; first = false; }
-      // a == 2: stays for the next round (then as the first task: blocking)
-      if (first && a == 2) first = true;
-    }
-    if (!run[0] && !run[1]) { if (t[0].kind == 0 && t[1].kind == 0) break; else continue; }
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      if (run[f]) pair_prepare(fa, sh, f, t[f]);
-      else sh.valid[f][lane] = 0u;
-    }
-    const int half = lane >> 5;
-    const bool live = half == 0 ? (run[0] && t[0].ok) : (run[1] && t[1].ok);
-    LMResult r;
-    r.nfev = 0;
-    if ((run[0] && t[0].ok) || (run[1] && t[1].ok))
-      r = lm_solve_pair(sh, live, fa.ftol, fa.xtol, fa.gtol, fa.maxfev, fa.factor);
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      if (!run[f]) continue;
-      const int nfev = __builtin_amdgcn_readlane(r.nfev, 32 * f);
-      const bool cv = pair_finish(fa, sh, f, t[f], nfev);
-      if (t[f].kind == 2) {
-        if (lane == 0) {
-          st_sc1(&fa.state[t[f].i].conv, cv ? 1 : 0);
-          atomicMax(fa.n_iter, t[f].k);
-          if (cv) atomicSub(&ctl->n_unconv, 1);
-        }
-        publish(done, t[f].i, t[f].k + 1);
-      } else {
-        publish(done, t[f].i, 1);
-      }
-      t[f].kind = 0;
-    }
-    if (t[0].kind == 0 && t[1].kind == 0) break;
-  }
-}
 
 // ---- standalone GaussianFit(im, X, center).fit() on explicit voxel lists (Fitting_v4.py:165-396) --
 struct VoxArgs {
@@ -1149,12 +841,12 @@ int build_ball(int r, std::vector<signed char>& ball) {
 }
 
 int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
-int g_fit_pairs = 1;    // IA3_TUNE_FIT_PAIRS: 1 = two fits per wave (fit_pairs_k), 0 = one (fit_stages_k)
+int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets its first fit and sweep 1 from one wave
 
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
-  a.n = f->n; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
+  a.n = f->n; a.fuse = g_fit_fuse; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
@@ -1301,7 +993,7 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 
 namespace ia3k {
 void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
-void set_fit_pairs(int on) { g_fit_pairs = on ? 1 : 0; }
+void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
 void fit_host_counters(const ia3_fitter* f, long long out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
 }
@@ -1329,12 +1021,8 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order)
   if (blocks < 1) blocks = 1;
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
-  if (g_fit_pairs)   // one block per pair of positions
-    hipLaunchKernelGGL(fit_pairs_k, dim3((unsigned)((blocks + 1) / 2)), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
-                       (int*)f->d_done);
-  else
-    hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
-                       (int*)f->d_done);
+  hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
+                     (int*)f->d_done);
   IA3_KCHECK();
   return IA3_OK;
 }

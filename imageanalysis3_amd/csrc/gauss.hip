@@ -643,7 +643,7 @@ int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_SEED_DENSE) { ia3k::set_seed_dense(value); return 0; }
   if (key == IA3_TUNE_FIT_NBLIST) { ia3k::set_fit_nblist(value); return 0; }
   if (key == IA3_TUNE_FFT_C2C) { ia3k::set_fft_c2c(value); return 0; }
-  if (key == IA3_TUNE_FIT_PAIRS) { ia3k::set_fit_pairs(value); return 0; }
+  if (key == IA3_TUNE_FIT_FUSE) { ia3k::set_fit_fuse(value); return 0; }
   return set_error(IA3_EINVAL, "unknown tuning key");
 }
 

@@ -71,10 +71,10 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_FFT_C2C: 1 = the phase correlation transforms the (real) stacks with complex-to-complex FFTs (first
  * version); 0 (default) = real-input transforms on half spectra.  Shifts agree to rounding. */
 #define IA3_TUNE_FFT_C2C 6
-/* IA3_TUNE_FIT_PAIRS: 1 (default) = the fit kernel works on two seeds per wavefront (evaluations one after the other on
- * all lanes, the 10 x 10 trust-region algebra of both at once, one per half-wave); 0 = one seed per wavefront (first
- * version).  Tables are identical bit for bit. */
-#define IA3_TUNE_FIT_PAIRS 7
+/* IA3_TUNE_FIT_FUSE: 1 (default) = in ia3_fit_run a seed whose ball overlaps no other seed's gets its first fit and
+ * sweep 1 from ONE wavefront (same voxels, gathered once; one hand-over); 0 = two work-list positions as for every other
+ * seed.  Tables are identical bit for bit. */
+#define IA3_TUNE_FIT_FUSE 7
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

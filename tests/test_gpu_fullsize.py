@@ -372,46 +372,33 @@ def test_fit_fovs_batch_entry():
     assert L.fit_fovs([], sp, fp) == ([], [])
 
 
-def test_paired_fit_kernel_equals_single_fit_kernel():
-    """Two seeds per wavefront (fit_pairs_k: evaluations in turn, trust-region algebra of both at once on the two
-    half-waves) against one seed per wavefront (fit_stages_k): first-fit rows, final rows, sweep counts, voxel counts
-    and evaluation counts identical bit for bit — isolated and clustered fields (ordered refits across overlapping
-    balls), uint16 plateau twins (neighbours in the list and in space), odd seed counts, a single seed, the legacy
-    model variant."""
+def test_fused_first_fit_and_sweep1_equal_separate_positions():
+    """ia3_fit_run gives a seed without neighbours its first fit and sweep 1 from one wavefront (one gather, one
+    hand-over; fit.hip run_position mode 2).  Against the same call with the fusion off, and against the class API
+    (firstfit() and repeatfit() as separate launches, which never fuses): tables, seed / sweep counts and the fit /
+    evaluation / voxel-evaluation counters identical bit for bit — isolated fields (every seed fused), clustered ones
+    (mixed), uint16 plateau twins, an edge case with clipped balls."""
     from conftest import build_case
     from imageanalysis3_amd import synth, _lib as L
-    from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
-    from imageanalysis3_amd.spot_tools.fitting import get_seeds
-    import ctypes as C
-    cases = []
-    for name in ("c1_f32", "c1_u16", "hot_u16", "clu_f32", "edge_f32"):
-        im = build_case(name)
-        cases.append((name, im, get_seeds(im, th_seed=600.0)))
-    im, c, h = synth.make_fov((50, 512, 512), 400, 3, layout="clustered", n_territories=16)
-    cases.append(("clustered_333", im, get_seeds(im, th_seed=600.0)))
-    im, c, h = synth.make_fov((50, 640, 640), 480, 40, dtype=np.uint16)
-    cases.append(("u16_twins", im, get_seeds(im, th_seed=600.0)))
-    s = cases[0][2]
-    cases.append(("odd", cases[0][1], s[:len(s) - 1 + len(s) % 2]))
-    cases.append(("single", cases[0][1], s[:1]))
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    cases = [(name, build_case(name)) for name in ("c1_f32", "c1_u16", "hot_u16", "clu_f32", "edge_f32", "m_f32")]
+    cases.append(("clustered_333", synth.make_fov((50, 512, 512), 400, 3, layout="clustered", n_territories=16)[0]))
+    cases.append(("u16_twins", synth.make_fov((50, 640, 640), 480, 40, dtype=np.uint16)[0]))
+    sp, keep = L.make_seed_params(600.0, max_num_seeds=None)
+    fp = L.make_fit_params()
     res = {}
     try:
         for mode in (0, 1):
-            L.check(L.lib().ia3_set_tuning(7, mode))      # IA3_TUNE_FIT_PAIRS
-            for name, im, seeds in cases:
-                f = iter_fit_seed_points(im, seeds[:, :3].T)
-                f.firstfit()
-                first, nvox = np.array(f.ps), np.array(f.nvox)
-                nfev = np.empty(len(seeds), np.int32)
-                L.check(L.lib().ia3_fit_nfev(f._fitter, L.ptr(nfev)))      # evaluations of the first fits
-                f.repeatfit()
-                res[(mode, name)] = (first, nvox, np.array(f.ps), f.n_iter, nfev)
+            L.check(L.lib().ia3_set_tuning(7, mode))      # IA3_TUNE_FIT_FUSE
+            for name, im in cases:
+                tabs, info = L.fit_fovs([im], sp, fp, in_flight=1)
+                res[(mode, name)] = (tabs[0], info[0])
     finally:
         L.check(L.lib().ia3_set_tuning(7, 1))
-    for name, im, seeds in cases:
-        a, b = res[(0, name)], res[(1, name)]
-        assert a[3] == b[3], (name, a[3], b[3])
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[4], b[4]), name
-        assert np.array_equal(a[0], b[0], equal_nan=True), name
-        assert np.array_equal(a[2], b[2], equal_nan=True), name
-    assert res[(1, "clustered_333")][3] >= 4 and res[(1, "u16_twins")][3] >= 2
+    for name, im in cases:
+        (ta, ia), (tb, ib) = res[(0, name)], res[(1, name)]
+        assert ia == ib, (name, ia, ib)
+        assert np.array_equal(ta, tb), name
+        tc = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+        assert tc.shape == tb.shape and np.array_equal(tc, tb), name
+    assert res[(1, "clustered_333")][1]["n_iter"] >= 4 and res[(1, "u16_twins")][1]["n_iter"] >= 2
