@@ -611,11 +611,7 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, LMWork& w, int i
     if (ok) nfev = wave_gaussfit(fa, w, ball, vals, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
                                  refit ? fa.delta_repeat : fa.delta_first, n, p);
   }
-  if (mode == 2 && ok && (threadIdx.x & 63) == 0) {   // the first fit's share of the bookkeeping store_result does per fit
-    atomicAdd(&fa.counters[0], 1ull);
-    atomicAdd(&fa.counters[1], (unsigned long long)nfev_first);
-    atomicAdd(&fa.counters[2], (unsigned long long)nfev_first * (unsigned long long)n);
-  }
+  if (mode == 2 && ok && (threadIdx.x & 63) == 0) atomicAdd(&fa.counters[0], 1ull);   // two fits; store_result counts one
   store_result(fa, i, p, w, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
   // convergence (:677-680): float32 centre differences, compared in float64
   bool cv = true;
