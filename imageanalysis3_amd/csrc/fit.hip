@@ -669,15 +669,15 @@ __device__ __forceinline__ void publish(int* done, int i, int value) {
 // One block (= one wave) per work-list position.  The position is a TICKET drawn when the block starts running,
 // not blockIdx: tickets are handed out in the order blocks actually start, so everything a block may wait for is
 // held by a block that is already running (or done) whatever order the dispatcher picks.
-__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
-                                                   int* done) {
-  __shared__ LMWork w;
+// done[i] := max(done[i], value) without the release: for a seed whose data no wave of this kernel reads any more
+__device__ __forceinline__ void publish_quiet(int* done, int i, int value) {
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_max(&done[i], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one work-list position; false = abort (a dependency wait exceeded its bound)
+__device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int n, int stage0, int stage1, StageCtl* ctl,
+                                               int* done, unsigned pos) {
   const int lane = threadIdx.x & 63;
-  const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
-  unsigned pos = 0;
-  if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
-  pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
-  if (pos >= total) return;
   const int k = stage0 + (int)(pos / (unsigned)n);
   const int i = (int)(pos % (unsigned)n);   // seed order inside a stage: lower-index neighbours come first
   if (k == 0) {
@@ -690,26 +690,29 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
         atomicMax(fa.n_iter, 1);
         if (cv) atomicSub(&ctl->n_unconv, 1);
       }
-      publish(done, i, 2);
+      // converged and without neighbours: no wave of this kernel will read this seed's rows or state again (its later
+      // positions leave at the done[] test below), so the hand-over needs no release; the end of the kernel publishes it
+      if (cv) publish_quiet(done, i, 1 << 20);
+      else publish(done, i, 2);
     } else {
       publish(done, i, 1);
     }
-    return;
+    return true;
   }
   // sweep k of this seed already made by the wave of an earlier position (the fused first fit above)
-  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return;
+  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
   // nothing left to refit anywhere: every remaining position is a skip.  The claimed position is still
   // published (as "all stages done") so that a block which passed this check earlier and waits on it can go on.
   if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
     publish(done, i, 1 << 20);
-    return;
+    return true;
   }
-  if (!wait_done(done, i, k, ctl)) return;
+  if (!wait_done(done, i, k, ctl)) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return; }   // converged: skipped (:652)
+  if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return true; }   // converged: skipped (:652)
   bool alive = true;
   each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
-  if (!alive) return;
+  if (!alive) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const bool cv = run_position(fa, w, i, 1);
   if (lane == 0) {
@@ -718,8 +721,28 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
     if (cv) atomicSub(&ctl->n_unconv, 1);
   }
   publish(done, i, k + 1);
+  return true;
 }
 
+// One wave per block, at most one block per SIMD of the device (the kernel's registers allow no more): every wave draws
+// work-list positions until the list is empty.  A position is a TICKET drawn when its wave is ready for it, not a
+// block index: tickets are handed out in the order waves actually get to them, so everything a wave may wait for is
+// held by a wave that is running (or done) whatever order the dispatcher picks — no co-residency assumption.  (One block
+// per position, the first form, spent 0.14 ms per 10 000 positions on block launches alone.)
+__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
+                                                   int* done) {
+  __shared__ LMWork w;
+  const int lane = threadIdx.x & 63;
+  const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
+  for (;;) {
+    unsigned pos = 0;
+    if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
+    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+    if (pos >= total) return;
+    if (!stage_position(fa, w, n, stage0, stage1, ctl, done, pos)) return;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 
 // ---- standalone GaussianFit(im, X, center).fit() on explicit voxel lists (Fitting_v4.py:165-396) --
 struct VoxArgs {
@@ -1014,7 +1037,9 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
     IA3_HIP(hipMemsetAsync(f->d_ctl, 0, sizeof(unsigned int), st));   // StageCtl::claim is the first word
   }
   f->pristine = false;
-  long long blocks = (long long)(stage1 - stage0) * f->n;   // one block per work-list position (ticket order)
+  long long blocks = (long long)(stage1 - stage0) * f->n;   // work-list positions; waves draw them as tickets
+  const long long simds = 4LL * num_cus();
+  if (blocks > simds) blocks = simds;
   if (blocks < 1) blocks = 1;
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
   hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
