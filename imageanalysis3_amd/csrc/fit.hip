@@ -708,6 +708,8 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int
     return true;
   }
   if (!wait_done(done, i, k, ctl)) return false;
+  // ... or made meanwhile: the wave that holds this seed's first fit may have been running until now
+  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return true; }   // converged: skipped (:652)
   bool alive = true;

@@ -10,7 +10,7 @@ sp, keep = L.make_seed_params(600.0, max_num_seeds=None); fp = L.make_fit_params
 st = L.DeviceStack.upload(im)
 rows = np.empty((16384, 11), np.float32); nr, ns, ni = C.c_int(0), C.c_int(0), C.c_int(0)
 for rep in range(2):
-    for mode in (0,):
+    for mode in (0, 1):
         L.check(lib.ia3_set_tuning(7, mode))
         for _ in range(2):
             L.check(lib.ia3_fit_fov_dev(st._h, C.byref(sp), C.byref(fp), L.ptr(rows), len(rows), C.byref(nr), C.byref(ns), C.byref(ni)))
