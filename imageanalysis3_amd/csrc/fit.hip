@@ -351,9 +351,11 @@ __device__ __forceinline__ void wave_extremes(const double* v, unsigned valid, d
 }
 
 // One GaussianFit(...).fit() on the ball held by the wave (n >= 10 checked by the caller).
-// vals: float64 data before the float32 cast (used for the start point only, :175-182).
-__device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const Ball& ball, const double* vals,
-                                             int kind, const double* c0, double delta, int n, float* p_out) {
+// lo10 / hi10: the ten smallest / largest voxel values of the float64 data before the float32 cast (start point only,
+// :175-182).  centre_only: the caller needs nothing but the fitted centre p_out[1..3] (the first of two fits of a seed
+// without neighbours): natural parameters and eps are left out.
+__device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const Ball& ball, const double* lo10, const double* hi10,
+                                             int kind, const double* c0, double delta, int n, float* p_out, bool centre_only) {
   __shared__ BallLds bl;   // one wave per block
   {
     const int ln = threadIdx.x & 63;
@@ -374,10 +376,14 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const
   ev.cfgp = &cfg_sh;
   ev.gsc = geom_sc;
   ev.valid = ball.valid;
-  double lo10[10], hi10[10];
-  wave_extremes(vals, ball.valid, lo10, hi10);
   init_guess(lo10, hi10, kind, cfg, w.x);
   LMResult r = lm_solve(ev, w, fa.ftol, fa.xtol, fa.gtol, fa.maxfev, fa.factor);
+  if (centre_only) {
+    double c[3];
+    centers_of(w.x, cfg, c);   // what to_natural puts into p[1..3]
+    p_out[1] = (float)c[0]; p_out[2] = (float)c[1]; p_out[3] = (float)c[2];
+    return r.nfev;
+  }
   to_natural(w.x, cfg, p_out);
   Geom gm;
   make_geom(w.x, cfg, gm);
@@ -603,13 +609,15 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, LMWork& w, int i
   const bool ok = n >= NP;  // :382-383 (mode 2: for both fits, same voxels)
   int nfev = 0, nfev_first = 0;
   const int npass = mode == 2 ? 2 : 1;
+  double lo10[10], hi10[10];   // mode 2: the same ten smallest / largest values start both fits
+  if (ok) wave_extremes(vals, ball.valid, lo10, hi10);
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     const bool refit = mode == 1 || pass == 1;
     if (pass == 1) { success_old = ok ? 1 : 0; co0 = p[1]; co1 = p[2]; co2 = p[3]; nfev_first = nfev; }
     // a refit sees the float64 residual (kind 2) and casts it to float32 (:172); the first fit the stack's own dtype
-    if (ok) nfev = wave_gaussfit(fa, w, ball, vals, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
-                                 refit ? fa.delta_repeat : fa.delta_first, n, p);
+    if (ok) nfev = wave_gaussfit(fa, w, ball, lo10, hi10, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
+                                 refit ? fa.delta_repeat : fa.delta_first, n, p, mode == 2 && pass == 0);
   }
   if (mode == 2 && ok && (threadIdx.x & 63) == 0) atomicAdd(&fa.counters[0], 1ull);   // two fits; store_result counts one
   store_result(fa, i, p, w, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
@@ -792,7 +800,11 @@ __global__ __launch_bounds__(64) void fit_voxels_k(VoxArgs va, int n_fits, doubl
   for (int k = 0; k < 11; ++k) p[k] = NAN;
   int nfev = 0;
   const bool ok = n >= NP;
-  if (ok) nfev = wave_gaussfit(fa, w, ball, vals, va.kind[i], c0, va.cfg[4 * i], n, p);
+  if (ok) {
+    double lo10[10], hi10[10];
+    wave_extremes(vals, ball.valid, lo10, hi10);
+    nfev = wave_gaussfit(fa, w, ball, lo10, hi10, va.kind[i], c0, va.cfg[4 * i], n, p, false);
+  }
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 11; ++k) va.ps[(size_t)i * 11 + k] = p[k];
