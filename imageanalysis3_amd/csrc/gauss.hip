@@ -389,15 +389,25 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
 #pragma unroll
     for (int k = 0; k < SL; ++k) win[k][j] = (WT)in[pz + off[k]];
   }
+  // The plane a step adds to the window is fetched one step ahead (in the stack dtype: half the registers of the
+  // window's float64), so its HBM latency runs under the previous plane's three passes instead of in front of this one's.
+  T nxt[SL];
+  {
+    const size_t pz = (size_t)mz[z_begin + W - 1] * plane;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) nxt[k] = in[pz + off[k]];
+  }
   for (int zz = z_begin; zz < z_end; zz += U) {
     auto step = [&](auto pc) -> bool {
       constexpr int ph = decltype(pc)::value;          // ring phase: logical slot j -> physical (ph + j) % W
       const int z = zz + ph;
       if (z >= z_end) return false;                    // block-uniform
       {
-        const size_t pz = (size_t)mz[z + W - 1] * plane;
 #pragma unroll
-        for (int k = 0; k < SL; ++k) win[k][(ph + W - 1) % W] = (WT)in[pz + off[k]];
+        for (int k = 0; k < SL; ++k) win[k][(ph + W - 1) % W] = (WT)nxt[k];
+        const size_t pz = (size_t)mz[z + W] * plane;   // (the border map reaches Z + 2R: valid for the last plane too)
+#pragma unroll
+        for (int k = 0; k < SL; ++k) nxt[k] = in[pz + off[k]];
       }
       // axis 0 on the halo tile
 #pragma unroll
