@@ -364,8 +364,9 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
   using WT = std::conditional_t<WIDE, double, T>;          // window element
   using LT = float;                                        // LDS element (the quantised intermediate is exact in a float)
   constexpr int U = WIDE ? W : 1;                          // z steps per expanded loop body
-  __shared__ LT A[EX][EY + 1];
-  __shared__ LT B[TX][EY + 1];
+  constexpr int PADY = WIDE ? 2 : 1;                       // WIDE: rows of 72 floats, 16-byte aligned for the axis-2 pieces
+  __shared__ __attribute__((aligned(16))) LT A[EX][EY + PADY];
+  __shared__ __attribute__((aligned(16))) LT B[TX][EY + PADY];
   const int tid = threadIdx.x;
   const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
   const int tile_id = xcd_tile(blockIdx.x, nty * ntx);   // grid.x = 8 * ceil(tiles / 8)
@@ -427,6 +428,49 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
         }
       }
       __syncthreads();
+      if constexpr (WIDE) {
+        // Axes 1 and 2 with register windows as well: a thread converts each LDS value once and uses it for up to 2R+1
+        // outputs (7 conversions and 7 LDS reads per output before — the kernel issued 69 VALU instructions per voxel
+        // for 30 of arithmetic, and VALU issue is what it shares with the long pass on the other stream).
+        // axis 1: runs of RUN1 outputs along x at one yy; lanes along yy (conflict-free rows)
+        constexpr int RUN1 = 8, NR1 = TX / RUN1;
+        static_assert(TX % RUN1 == 0 && NR1 * EY <= NT, "axis-1 runs must fit one round of the block");
+        if (tid < NR1 * EY) {
+          const int yy = tid % EY, xr = (tid / EY) * RUN1;
+          double v[RUN1 + 2 * R];
+#pragma unroll
+          for (int j = 0; j < RUN1 + 2 * R; ++j) v[j] = (double)A[xr + j][yy];
+#pragma unroll
+          for (int o = 0; o < RUN1; ++o) {
+            double acc = v[o + R] * taps.w[0];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc = acc + (v[o + R - j] + v[o + R + j]) * taps.w[j];
+            B[xr + o][yy] = (LT)cvt<T>(acc);
+          }
+        }
+        __syncthreads();
+        // axis 2: runs of RUN2 outputs along y at one x, fetched as 16-byte pieces of the row (rows are 16-byte aligned)
+        constexpr int RUN2 = 4, NR2 = TY / RUN2;
+        static_assert(TX * NR2 == NT && (RUN2 + 2 * R + 3) / 4 * 4 <= EY + PADY - (TY - RUN2), "axis-2 runs: one per thread, reads inside the row");
+        {
+          const int x = tid / NR2, yr = (tid % NR2) * RUN2;
+          float f[(RUN2 + 2 * R + 3) / 4 * 4];
+#pragma unroll
+          for (int q = 0; q < (RUN2 + 2 * R + 3) / 4; ++q) *reinterpret_cast<float4*>(&f[4 * q]) = *reinterpret_cast<const float4*>(&B[x][yr + 4 * q]);
+          double v[RUN2 + 2 * R];
+#pragma unroll
+          for (int j = 0; j < RUN2 + 2 * R; ++j) v[j] = (double)f[j];
+          T* po = out + (size_t)z * plane + (size_t)(x0 + x) * Y + (y0 + yr);
+#pragma unroll
+          for (int o = 0; o < RUN2; ++o) {
+            double acc = v[o + R] * taps.w[0];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc = acc + (v[o + R - j] + v[o + R + j]) * taps.w[j];
+            if (x0 + x < X && y0 + yr + o < Y) po[o] = cvt<T>(acc);
+          }
+        }
+        return true;
+      }
       // axis 1: outputs (x, yy) for x in [0,TX), yy in [0,EY)
 #pragma unroll
       for (int k = 0; k < S1; ++k) {
