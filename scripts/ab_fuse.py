@@ -1,4 +1,4 @@
-"""A/B of IA3_TUNE_FIT_PAIRS on one box: float32 FOV from one stream, per-kernel HIP-event times (developer probe)."""
+"""A/B of IA3_TUNE_FIT_FUSE (7) on one box: float32 FOV from one stream, per-kernel HIP-event times (developer probe)."""
 import sys, os, time, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,5 +20,5 @@ for rep in range(2):
             L.check(lib.ia3_fit_fov_dev(st._h, C.byref(sp), C.byref(fp), L.ptr(rows), len(rows), C.byref(nr), C.byref(ns), C.byref(ni)))
         d = (time.perf_counter() - t0) / 10
         prof = L.profile_collect(); L.profile_enable(False)
-        print("pairs=%d: %.3f ms/FOV, %d rows, fit kernels: %s" % (mode, d * 1e3, nr.value,
+        print("fuse=%d: %.3f ms/FOV, %d rows, fit kernels: %s" % (mode, d * 1e3, nr.value,
               {k: round(v[1] / v[0], 3) for k, v in prof.items() if k.startswith("fit")}), flush=True)
