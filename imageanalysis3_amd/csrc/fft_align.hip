@@ -38,54 +38,65 @@ int next_fast_len(int n) {  // smallest 2^a 3^b 5^c 7^d >= n
   } while (0)
 
 // rocFFT plans cost tens of milliseconds to build (kernel selection, twiddle tables, work buffer); drift alignment
-// runs the same few transforms for every crop of every image, so plans are kept: a small cache per host thread keyed
-// by (type, dims), least recently used entry evicted.  Work buffers stay attached to the cached plans, and a plan
-// with its work buffer must not run on two streams at once — hence one cache per thread (= per library stream), not
-// one per process: several threads aligning different images use different plans.
-struct PlanEntry { int type, n0, n1, n2; hipfftHandle h; unsigned long long used; };
-constexpr size_t MAX_PLANS = 8;
-struct PlanCache {
+// runs the same few transforms for every crop of every image, so plans are kept: ONE pool for the process, keyed by
+// (type, dims).  A plan with its work buffer must not run on two streams at once, so a thread LEASES a plan for the
+// duration of a call (PlanLease, released after the call's final synchronisation) and another thread that needs the same
+// transform meanwhile builds a second one.  Plans are never destroyed when a thread ends — round 1 kept a cache per thread
+// and released it from the thread's destructor, and a plan destroyed there while other threads were creating plans or
+// launching crashed inside the runtime (std::map erase under rocfft_plan_destroy; scripts/stress_threads.py) — only the
+// least recently used idle plan goes when the pool is full, under the pool's lock.  What is left at process exit is left
+// to process teardown (the HIP runtime may already be gone by then).
+struct PlanEntry { int type, n0, n1, n2; hipfftHandle h; unsigned long long used; bool busy; };
+constexpr size_t MAX_PLANS = 48;
+struct PlanPool {
   std::vector<PlanEntry> plans;
   pid_t pid = 0;
   unsigned long long clock = 0;
-  ~PlanCache() {
-    // worker threads release their plans when they end; the main thread's cache is left to process teardown
-    // (the HIP runtime may already be gone when its thread-locals are destroyed)
-    if (pid == getpid() && (pid_t)syscall(SYS_gettid) != getpid())
-      for (auto& e : plans) hipfftDestroy(e.h);
+  std::mutex mu;   // guards the table AND serialises plan construction / destruction
+};
+static PlanPool& plan_pool() { static PlanPool* p = new PlanPool(); return *p; }   // never destructed
+
+struct PlanLease {
+  hipfftHandle h = 0;
+  bool held = false;
+  PlanLease() = default;
+  PlanLease(const PlanLease&) = delete;
+  PlanLease& operator=(const PlanLease&) = delete;
+  ~PlanLease() { release(); }
+  void release() {
+    if (!held) return;
+    PlanPool& c = plan_pool();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.pid == getpid())
+      for (auto& e : c.plans) if (e.h == h && e.busy) { e.busy = false; break; }
+    held = false;
   }
 };
-static thread_local PlanCache t_cache;
-static std::mutex g_plan_mu;   // plan construction is serialised
 
-static int get_plan(int type, int n0, int n1, int n2, hipStream_t st, hipfftHandle* out) {
-  PlanCache& c = t_cache;
+static int get_plan(int type, int n0, int n1, int n2, hipStream_t st, PlanLease& out) {
+  PlanPool& c = plan_pool();
+  std::lock_guard<std::mutex> lk(c.mu);
   if (c.pid != getpid()) { c.plans.clear(); c.pid = getpid(); }   // handles do not survive fork()
   for (auto& e : c.plans)
-    if (e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) {
-      e.used = ++c.clock;
+    if (!e.busy && e.type == type && e.n0 == n0 && e.n1 == n1 && e.n2 == n2) {
       if (hipfftSetStream(e.h, st) != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfftSetStream failed");
-      *out = e.h;
+      e.used = ++c.clock; e.busy = true;
+      out.h = e.h; out.held = true;
       return IA3_OK;
     }
-  if (c.plans.size() >= MAX_PLANS) {
-    size_t victim = 0;
-    for (size_t i = 1; i < c.plans.size(); ++i) if (c.plans[i].used < c.plans[victim].used) victim = i;
-    (void)hipStreamSynchronize(st);
-    hipfftDestroy(c.plans[victim].h);
-    c.plans.erase(c.plans.begin() + victim);
+  if (c.plans.size() >= MAX_PLANS) {   // make room: the least recently used idle plan (its last call has synchronised)
+    int victim = -1;
+    for (size_t i = 0; i < c.plans.size(); ++i)
+      if (!c.plans[i].busy && (victim < 0 || c.plans[i].used < c.plans[victim].used)) victim = (int)i;
+    if (victim >= 0) { hipfftDestroy(c.plans[victim].h); c.plans.erase(c.plans.begin() + victim); }
   }
   hipfftHandle h;
-  hipfftResult r;
-  {
-    std::lock_guard<std::mutex> lk(g_plan_mu);
-    r = n2 > 0 ? hipfftPlan3d(&h, n0, n1, n2, (hipfftType)type) : hipfftPlan2d(&h, n0, n1, (hipfftType)type);
-  }
+  hipfftResult r = n2 > 0 ? hipfftPlan3d(&h, n0, n1, n2, (hipfftType)type) : hipfftPlan2d(&h, n0, n1, (hipfftType)type);
   if (r != HIPFFT_SUCCESS) return set_error(IA3_EHIP, "hipfft plan (%d x %d x %d) failed: error %d", n0, n1, n2, (int)r);
   r = hipfftSetStream(h, st);
   if (r != HIPFFT_SUCCESS) { hipfftDestroy(h); return set_error(IA3_EHIP, "hipfftSetStream failed: error %d", (int)r); }
-  c.plans.push_back(PlanEntry{type, n0, n1, n2, h, ++c.clock});
-  *out = h;
+  c.plans.push_back(PlanEntry{type, n0, n1, n2, h, ++c.clock, true});
+  out.h = h; out.held = true;
   return IA3_OK;
 }
 
@@ -193,13 +204,13 @@ int fftalign2d_dev(const double* im1, int s1x, int s1y, const double* im2, int s
   dim3 g((Fy + 255) / 256, Fx);
   hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im1, s1x, s1y, (const double*)stats.as<double>(), 0, a.as<double>(), Fx, Fy);
   hipLaunchKernelGGL(pad_norm_k, g, dim3(256), 0, st, im2, s2x, s2y, (const double*)(stats.as<double>() + 2), 1, b.as<double>(), Fx, Fy);
-  hipfftHandle fwd, inv;
-  { int prc = get_plan(HIPFFT_D2Z, Fx, Fy, 0, st, &fwd); if (prc) return prc; }
-  { int prc = get_plan(HIPFFT_Z2D, Fx, Fy, 0, st, &inv); if (prc) return prc; }
-  IA3_FFT(hipfftExecD2Z(fwd, a.as<double>(), fa.as<cplx>()));
-  IA3_FFT(hipfftExecD2Z(fwd, b.as<double>(), fb.as<cplx>()));
+  PlanLease fwd, inv;   // held until this call has synchronised (end of scope)
+  { int prc = get_plan(HIPFFT_D2Z, Fx, Fy, 0, st, fwd); if (prc) return prc; }
+  { int prc = get_plan(HIPFFT_Z2D, Fx, Fy, 0, st, inv); if (prc) return prc; }
+  IA3_FFT(hipfftExecD2Z(fwd.h, a.as<double>(), fa.as<cplx>()));
+  IA3_FFT(hipfftExecD2Z(fwd.h, b.as<double>(), fb.as<cplx>()));
   hipLaunchKernelGGL(cmul_k, dim3((unsigned)((ncplx + 255) / 256)), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), ncplx);
-  IA3_FFT(hipfftExecZ2D(inv, fa.as<cplx>(), a.as<double>()));
+  IA3_FFT(hipfftExecZ2D(inv.h, fa.as<cplx>(), a.as<double>()));
   // window (alignment_tools.py:301-308)
   const double c0 = center[0] + cx / 2.0, c1 = center[1] + cy / 2.0;
   auto clampi = [](double v, int hi) { v = v < 0 ? 0 : v; v = v > hi ? hi : v; return (int)v; };
@@ -611,14 +622,14 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
   cplx ccmax;
   double hs[2];
   if (half) {
-    hipfftHandle fwd, inv;
-    { int prc = get_plan(HIPFFT_D2Z, Z, X, Y, st, &fwd); if (prc) return prc; }
-    { int prc = get_plan(HIPFFT_Z2D, Z, X, Y, st, &inv); if (prc) return prc; }
+    PlanLease fwd, inv;   // released at the end of this block: real_argmax below synchronises the stream first
+    { int prc = get_plan(HIPFFT_D2Z, Z, X, Y, st, fwd); if (prc) return prc; }
+    { int prc = get_plan(HIPFFT_Z2D, Z, X, Y, st, inv); if (prc) return prc; }
     for (int which = 0; which < 2; ++which) {
       const ia3_stack* s = which ? mov : ref;
       if (s->dtype == IA3_F32) hipLaunchKernelGGL((to_real_k<float>), dim3(nb), dim3(256), 0, st, (const float*)s->d, rbuf.as<double>(), n);
       else hipLaunchKernelGGL((to_real_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)s->d, rbuf.as<double>(), n);
-      IA3_FFT(hipfftExecD2Z(fwd, rbuf.as<double>(), which ? fb.as<cplx>() : fa.as<cplx>()));
+      IA3_FFT(hipfftExecD2Z(fwd.h, rbuf.as<double>(), which ? fb.as<cplx>() : fa.as<cplx>()));
     }
     // fa := prod, fb := conj(prod), power sums of both spectra — one pass
     hipLaunchKernelGGL(half_power_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, fa.as<cplx>(), fb.as<cplx>(), nh, Yh, Y, normalization,
@@ -626,7 +637,7 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
     hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)(parts.as<double>() + ABS2_BLOCKS), sums.as<double>() + 1);
     // rbuf := ifftn(prod), real (unnormalised by hipFFT; the transform may overwrite fa)
-    IA3_FFT(hipfftExecZ2D(inv, fa.as<cplx>(), rbuf.as<double>()));
+    IA3_FFT(hipfftExecZ2D(inv.h, fa.as<cplx>(), rbuf.as<double>()));
     IA3_KCHECK();
     rc = real_argmax(rbuf.as<double>(), n, &idx, &v2); if (rc) return rc;
     double cc;
@@ -642,17 +653,17 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
       hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)ref->d, fa.as<cplx>(), n);
       hipLaunchKernelGGL((to_cplx_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)mov->d, fb.as<cplx>(), n);
     }
-    hipfftHandle plan;
-    { int prc = get_plan(HIPFFT_Z2Z, Z, X, Y, st, &plan); if (prc) return prc; }
-    IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
-    IA3_FFT(hipfftExecZ2Z(plan, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
+    PlanLease plan;
+    { int prc = get_plan(HIPFFT_Z2Z, Z, X, Y, st, plan); if (prc) return prc; }
+    IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fa.as<cplx>(), HIPFFT_FORWARD));
+    IA3_FFT(hipfftExecZ2Z(plan.h, fb.as<cplx>(), fb.as<cplx>(), HIPFFT_FORWARD));
     hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fa.as<cplx>(), n, parts.as<double>());
     hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>());
     hipLaunchKernelGGL(abs2_part_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)fb.as<cplx>(), n, parts.as<double>());
     hipLaunchKernelGGL(abs2_sum_k, dim3(1), dim3(1024), 0, st, (const double*)parts.as<double>(), sums.as<double>() + 1);
     hipLaunchKernelGGL(cross_power_k, dim3(nb), dim3(256), 0, st, fa.as<cplx>(), (const cplx*)fb.as<cplx>(), n, normalization);
     // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
-    IA3_FFT(hipfftExecZ2Z(plan, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
+    IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
     IA3_KCHECK();
     rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;
     IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
