@@ -5,17 +5,18 @@
 //              the ORIGINAL image -> all fits independent -> one wave per seed.
 //   repeatfit: sweeps over unconverged seeds in seed order on the full ball; data = image minus the
 //              current reconstructions of the other seeds (in-place Gauss–Seidel in the reference,
-//              :658-675).  Only seeds whose balls can overlap interact, so the seeds are split into
-//              connected components of the overlap graph; a wave walks one component in seed order,
-//              sweep after sweep, and components run in parallel.  The residual image `im_add` (a
-//              float64 copy of the whole stack in the reference, 1.7 GB per FOV) is never
-//              materialised: data(v) = im(v) - Σ_{j≠i} rec_j(v) is rebuilt from the neighbours'
+//              :658-675).  Only seeds whose balls can overlap interact: the work list (stages x seeds)
+//              is walked by persistent waves that draw positions as tickets and wait for the fits a
+//              position depends on (fit_stages_k), which reproduces the sequential order exactly; a
+//              seed that overlaps no other gets its first fit and sweep 1 from one wave.  The residual
+//              image `im_add` (a float64 copy of the whole stack in the reference, 1.7 GB per FOV) is
+//              never materialised: data(v) = im(v) - Σ_{j≠i} rec_j(v) is rebuilt from the neighbours'
 //              parameter vectors, which is the same quantity up to f64 rounding order.
 //
 // Wave layout: the ball has <= 512 voxels (radius 5: 512) = 8 slots per lane.  Per LM evaluation a
 // lane computes residual + float32-rounded Jacobian row for its slots (float64, as NumPy does for
-// the reference under numpy>=2) and accumulates its share of JᵀJ (55) and Jᵀr (10); a 6-step
-// butterfly sums across the wave.  The 10x10 trust-region algebra (ia3_lm.h) runs redundantly on
+// the reference under numpy>=2) and accumulates its share of JᵀJ (55) and Jᵀr (10); permlane swaps
+// and DPP rotations sum across the wave.  The 10x10 trust-region algebra (ia3_lm.h) runs redundantly on
 // all lanes on a per-wave LDS work area, so control flow stays wave-uniform.
 //
 // Roofline: ~0.2 kflop per voxel per evaluation, 2 KB gathered per fit -> f64-VALU-bound, not HBM

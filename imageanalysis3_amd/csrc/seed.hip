@@ -4,16 +4,17 @@
 //   mask   = (maxfilt_s(max_im) == max_im) & (minfilt_s(min_im) != min_im)      fitting.py:95,102
 //   diff   = float32(max_im) - float32(min_im)                                  fitting.py:106
 //   keep   diff >= th_i, d <= c <= size-d on every axis                         fitting.py:113-125,156-165
-// One pass produces the candidate list at the LOWEST dynamic threshold level, so the
-// dynamic-threshold loop (pick the first level with enough seeds) needs no second sweep.
-// Candidates are sparse (~1e-5 of the voxels): a wave ballots its hits, one lane reserves
-// space with a single atomic and the hits are written by prefix rank (wavefront ballot +
-// prefix-sum compaction).  The rest (np.where order, hot-column vote, sort by height,
-// truncation: fitting.py:131-150) runs on a few thousand records on the host.
+// The candidate list is made at the LOWEST dynamic threshold level, so the dynamic-threshold loop (pick the first level
+// with enough seeds) needs no second sweep.  Candidates are sparse (~1e-5 of the voxels): a wave ballots its hits, one lane
+// reserves space with a single atomic and the hits are written by prefix rank (wavefront ballot + prefix-sum
+// compaction).  The rest (np.where order, hot-column vote, sort by height, truncation: fitting.py:131-150) runs on the
+// device too (fin_*_k) for up to 8192 candidates, on the host beyond.
 //
-// HBM traffic: the two filtered stacks are read once (8 B/voxel for f32); the 3x3x3 windows are
-// served by a rolling three-plane register pipeline along z plus L1/L2 hits for the in-plane
-// neighbours.
+// Two forms of the detector.  Default (3x3x3 footprint, background radius 4..63): the background filter is evaluated
+// LAZILY — only its axis-0 pass on the whole stack, a block-minimum bound of min_im, candidates = local maxima of max_im
+// that can still reach the lowest level, exact axis-1 / axis-2 passes at those (see "lazy background filter" below).
+// Otherwise, and as the fallback when the lazy form's candidate list overflows: both filtered stacks are read once
+// (8 B/voxel for f32) by an LDS-tiled kernel with a rolling three-plane register pipeline along z.
 #include "ia3_rt.h"
 #include <algorithm>
 #include <math.h>
