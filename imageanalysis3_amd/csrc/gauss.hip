@@ -20,10 +20,12 @@
 //     axis-2 pass is the strided kernel over that transposed plane, storing transposed again.
 #include "ia3_rt.h"
 #include <type_traits>
+#include <cstring>
+#include <mutex>
 
 namespace {
 
-__device__ __forceinline__ int border_idx(int q, int n, int mode) {
+__host__ __device__ __forceinline__ int border_idx(int q, int n, int mode) {
   if (mode == IA3_MODE_NEAREST) return q < 0 ? 0 : (q >= n ? n - 1 : q);
   if (q >= 0 && q < n) return q;
   int p = 2 * n;
@@ -207,6 +209,116 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
       return true;
     };
     static_for_until<0, U>(chunk);
+  }
+}
+
+// ---- axis 0 of a long filter on a short stack: the whole column in registers, border folded into the weights ----
+// With Z <= 64 planes and R = 30 most taps of an output land on the reflected (or clamped) border, i.e. on a plane
+// the sum already holds: out[z] = sum_p W[z][p] * in[p] with W[z][p] = the taps that map to plane p added up
+// (host, f64), p in [max(0, z-R), min(Z-1, z+R)].  That is 31..Z fused multiply-adds per output instead of R pair
+// additions + R+1 multiply-adds (Z = 50: 42 on average against 66 with the 6-wide chunks), every input is read
+// once, and the rows of z and Z-1-z share their weights (W[Z-1-z][Z-1-p] = W[z][p]).  The order of operations is
+// not NI_Correlate1D's, so this is a certified path like the fused one above: for non-negative data and taps both
+// sums are within (3R+1) resp. (Z+2) * 2^-53 * S of the exact sum S, so the float32 / uint16 value can only differ
+// when the folded sum lies within 3R+Z+3 f64 ulps of a quantisation boundary.  Those outputs, and every output of
+// a thread that saw a sign bit, are recomputed with the reference sequence from global memory.  wf = the folded
+// rows 0 .. (Z-1)/2 packed one after the other (uniform, compile-time offsets -> scalar loads).
+template <int Z, int R> constexpr int fold_lo(int z) { return z - R > 0 ? z - R : 0; }
+template <int Z, int R> constexpr int fold_hi(int z) { return z + R < Z - 1 ? z + R : Z - 1; }
+template <int Z, int R> constexpr int fold_off(int z) {
+  int o = 0;
+  for (int i = 0; i < z; ++i) o += fold_hi<Z, R>(i) - fold_lo<Z, R>(i) + 1;
+  return o;
+}
+
+// flat position i of the packed weight stream -> its row
+template <int Z, int R> constexpr int fold_row(int i) {
+  int z = 0;
+  while (i >= fold_off<Z, R>(z + 1)) ++z;
+  return z;
+}
+
+template <class T, int Z, int R>
+__global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
+                                                          const double* __restrict__ wf, Taps taps, int mode, int cert) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= plane) return;
+  double v[Z];
+  unsigned sbits = 0;
+  const T* ip = in + p;
+#pragma unroll
+  for (int z = 0; z < Z; ++z) {
+    const T t = *ip;
+    ip += plane;
+    sbits |= sign_of<T>(t);
+    v[z] = (double)t;
+  }
+  // rows complete in the order 0, Z-1, 1, Z-2, ...: two walking pointers instead of Z plane offsets in SGPRs
+  T* olo = out + p;
+  T* ohi = out + (size_t)(Z - 1) * plane + p;
+  unsigned long long redo = 0;   // outputs that need NI_Correlate1D's own sequence
+  if (cert < 0 || (int)sbits < 0) {
+    redo = Z == 64 ? ~0ull : (1ull << Z) - 1;
+  } else {
+    // the weight stream is read in pieces of CH doubles (scalar loads), the next piece in flight while this one is
+    // used; the scheduling barrier keeps the compiler from hoisting every load to the top (and spilling SGPRs)
+    constexpr int N = fold_off<Z, R>((Z + 1) / 2), CH = 8, NC = (N + CH - 1) / CH;
+    double a = 0.0, b = 0.0;
+    double cur[CH], nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) nxt[i] = wf[i];   // the table is padded to a multiple of CH
+    auto piece = [&](auto cc) -> bool {
+      constexpr int c = decltype(cc)::value;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+      if constexpr (c + 1 < NC) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) nxt[i] = wf[(c + 1) * CH + i];
+      }
+      auto tap = [&](auto ic) -> bool {
+        constexpr int i = c * CH + decltype(ic)::value;
+        if constexpr (i < N) {
+          constexpr int z = fold_row<Z, R>(i), zz = Z - 1 - z, lo = fold_lo<Z, R>(z), k = i - fold_off<Z, R>(z);
+          constexpr bool last = i + 1 == fold_off<Z, R>(z + 1);
+          const double w = cur[i - c * CH];
+          if constexpr (k == 0) {
+            a = v[lo] * w;
+            if constexpr (zz != z) b = v[Z - 1 - lo] * w;
+          } else {
+            a = __builtin_fma(v[lo + k], w, a);
+            if constexpr (zz != z) b = __builtin_fma(v[Z - 1 - lo - k], w, b);
+          }
+          if constexpr (last) {
+            if (uncertain<T>(a, cert)) redo |= 1ull << z;
+            *olo = cvt<T>(a);
+            olo += plane;
+            if constexpr (zz != z) {
+              if (uncertain<T>(b, cert)) redo |= 1ull << zz;
+              *ohi = cvt<T>(b);
+              ohi -= plane;
+            }
+          }
+        }
+        return true;
+      };
+      static_for_until<0, CH>(tap);
+      __builtin_amdgcn_sched_barrier(0);
+      return true;
+    };
+    static_for_until<0, NC>(piece);
+  }
+  // NI_Correlate1D's own sequence, inputs re-read (a few outputs per 10^7 on non-negative data)
+  while (redo) {
+    const int z = __builtin_ctzll(redo);
+    redo &= redo - 1;
+    double acc = ld<T>(in, (size_t)z * plane + p) * taps.w[0];
+#pragma unroll 1
+    for (int j = R; j >= 1; --j) {
+      const double x0 = ld<T>(in, (size_t)border_idx(z - j, Z, mode) * plane + p);
+      const double x1 = ld<T>(in, (size_t)border_idx(z + j, Z, mode) * plane + p);
+      acc = acc + (x0 + x1) * taps.w[j];
+    }
+    out[(size_t)z * plane + p] = cvt<T>(acc);
   }
 }
 
@@ -507,6 +619,48 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
 int g_cert = -2;   // -2: default guard (4R+8 ulps), -1: fused path off, >= 0: guard distance in ulps (tests)
 inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
 
+// folded weight rows of gauss_axis0_folded, cached on the device per (Z, R, mode, taps)
+struct FoldKey { int Z, R, mode; std::vector<double> w; };
+struct FoldEntry { FoldKey k; double* d = nullptr; };
+std::mutex g_fold_mu;
+std::vector<FoldEntry> g_fold;
+int g_fold_on = 1;
+
+template <int Z, int R>
+const double* folded_rows(const Taps& t, int mode, hipStream_t s) {
+  std::lock_guard<std::mutex> g(g_fold_mu);
+  for (auto& e : g_fold)
+    if (e.k.Z == Z && e.k.R == R && e.k.mode == mode && std::memcmp(e.k.w.data(), t.w, (R + 1) * sizeof(double)) == 0) return e.d;
+  std::vector<double> rows;
+  for (int z = 0; z < (Z + 1) / 2; ++z) {
+    const int lo = fold_lo<Z, R>(z), hi = fold_hi<Z, R>(z);
+    for (int p = lo; p <= hi; ++p) {
+      double acc = 0.0;
+      for (int j = -R; j <= R; ++j)
+        if (border_idx(z + j, Z, mode) == p) acc += t.w[j < 0 ? -j : j];
+      rows.push_back(acc);
+    }
+  }
+  rows.resize((rows.size() + 15) / 16 * 16, 0.0);
+  FoldEntry e;
+  e.k = FoldKey{Z, R, mode, std::vector<double>(t.w, t.w + R + 1)};
+  if (hipMalloc((void**)&e.d, rows.size() * sizeof(double)) != hipSuccess) return nullptr;
+  // a blocking copy, once per filter: the table must be in place before any stream uses the cached pointer
+  if (hipMemcpy(e.d, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.d); return nullptr; }
+  (void)s;
+  if (g_fold.size() >= 16) { g_fold.erase(g_fold.begin()); }   // the evicted table stays allocated: launches may be in flight
+  g_fold.push_back(e);
+  return e.d;
+}
+
+template <class T, int Z, int R>
+int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipStream_t s, int cert) {
+  const double* wf = folded_rows<Z, R>(t, mode, s);
+  if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
+  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert);
+  return 0;
+}
+
 // axes: bit 0 = the axis-0 pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst)
 template <class T, int R, int KS, int KC, int KZ = KS>
 int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst, T* tmp, hipStream_t s, int axes) {
@@ -535,6 +689,10 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     (void)tmp;
     return 0;
   }
+  // the certified paths assume non-negative taps (caller-supplied weights may not be): reference sequence otherwise
+  bool taps_nonneg = true;
+  for (int j = 0; j <= R; ++j) taps_nonneg &= t.w[j] >= 0.0;
+  const int cert = taps_nonneg ? cert_for(R) : -1;
   // border maps for the three axes: positions -R .. len + R + 2K (sliding-window prefetch overshoots by < 2K)
   const int cz = Z + 2 * R + 3 * KZ, cx = X + 2 * R + 3 * KS, cy = Y + 2 * R + 256 * 9;
   ia3rt::Scratch maps((size_t)(cz + cx + cy) * sizeof(int));
@@ -558,9 +716,26 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
   // axis 0: src -> dst
   if (axes & 1) {
     ia3rt::ProfScope ps(nz.c_str());
-    const int seg = seg_for_k(Z, (long long)plane, KZ);
-    dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
-    hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg, cert_for(R));
+    bool done = false;
+    if constexpr (R >= 16) {
+      if (g_fold_on && cert >= 0) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel)
+        const int fc = g_cert == -2 ? 3 * R + Z + 16 : cert;
+        int rc = -1;
+        switch (Z) {
+          case 30: rc = run_folded<T, 30, R>(src, plane, t, mode, dst, s, fc); break;
+          case 40: rc = run_folded<T, 40, R>(src, plane, t, mode, dst, s, fc); break;
+          case 50: rc = run_folded<T, 50, R>(src, plane, t, mode, dst, s, fc); break;
+          default: break;
+        }
+        if (rc > 0) return rc;
+        done = rc == 0;
+      }
+    }
+    if (!done) {
+      const int seg = seg_for_k(Z, (long long)plane, KZ);
+      dim3 g((unsigned)((plane + 255) / 256), 1, (unsigned)((Z + seg - 1) / seg));
+      hipLaunchKernelGGL((gauss_strided<T, R, KZ>), g, dim3(256), 0, s, src, dst, (int)plane, plane, Z, (size_t)0, t, (const int*)mz, seg, cert);
+    }
   }
   if (!(axes & 2)) return 0;
   if constexpr (R >= 16) {
@@ -570,13 +745,13 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
       ia3rt::ProfScope ps(nx.c_str());
       const int seg = seg_for(X, (long long)Y * Z);
       dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
-      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert_for(R));
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert);
     }
     {  // axis 2: tmp[z][y][x] -> dst[z][x][y]: lanes along x, filter along y with stride X, transposed store
       ia3rt::ProfScope ps(ny.c_str());
       const int seg = seg_for(Y, (long long)X * Z);
       dim3 g((unsigned)((X + 255) / 256), (unsigned)Z, (unsigned)((Y + seg - 1) / seg));
-      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)tmp, dst, X, (size_t)X, Y, plane, t, (const int*)my, seg, cert_for(R));
+      hipLaunchKernelGGL((gauss_strided<T, R, KS, true>), g, dim3(256), 0, s, (const T*)tmp, dst, X, (size_t)X, Y, plane, t, (const int*)my, seg, cert);
     }
     return 0;
   }
@@ -586,7 +761,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     ia3rt::ProfScope ps(nx.c_str());
     const int seg = seg_for(X, (long long)Y * Z);
     dim3 g((unsigned)((Y + 255) / 256), (unsigned)Z, (unsigned)((X + seg - 1) / seg));
-    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert_for(R));
+    hipLaunchKernelGGL((gauss_strided<T, R, KS>), g, dim3(256), 0, s, (const T*)dst, tmp, Y, (size_t)Y, X, plane, t, (const int*)mx, seg, cert);
   }
   // axis 2: tmp -> dst
   {
@@ -692,6 +867,7 @@ int ia3_set_tuning(int key, int value) {
     g_cert = value;
     return 0;
   }
+  if (key == IA3_TUNE_GAUSS_FOLD) { g_fold_on = value != 0; return 0; }
   if (key == IA3_TUNE_DFT_VALU) { ia3k::set_dft_valu(value); return 0; }
   if (key == IA3_TUNE_UPLOAD_THREADS) return ia3rt::set_upload_threads(value);
   if (key == IA3_TUNE_SEED_DENSE) { ia3k::set_seed_dense(value); return 0; }

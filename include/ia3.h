@@ -75,6 +75,10 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * sweep 1 from ONE wavefront (same voxels, gathered once; one hand-over); 0 = two work-list positions as for every other
  * seed.  Tables are identical bit for bit. */
 #define IA3_TUNE_FIT_FUSE 7
+/* IA3_TUNE_GAUSS_FOLD: 1 (default) = the axis-0 pass of a long filter (radius >= 16) over a stack of 30, 40 or 50
+ * planes holds the column in registers and folds the border into the weights (certified like the fused path, same
+ * fallback); 0 = the sliding-window pass for every depth.  Results are identical bit for bit. */
+#define IA3_TUNE_GAUSS_FOLD 8
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

@@ -857,6 +857,49 @@ def test_gaussian_long_filter_certified_fused_path_bit_exact():
         _set_gauss_cert(-2)
 
 
+def test_gaussian_axis0_folded_column_pass_bit_exact():
+    """Stacks of 30 / 40 / 50 planes run the axis-0 pass of a long filter with the whole column in registers and the
+    border folded into the weights (IA3_TUNE_GAUSS_FOLD, a different summation order, certified like the fused path).
+    Same bits as SciPy for both border modes, with the default guard, with every output sent through the reference
+    sequence, with the guard forced wide open and with the folded form off, on inputs that sit on quantisation
+    boundaries (see the test above)."""
+    import ctypes as C
+    from scipy import ndimage as ndi
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.correction_tools.filter import gaussian_filter
+    rng = np.random.RandomState(12)
+    try:
+        for Z in (30, 40, 50):
+            shape = (Z, 96, 192)
+            blocks = np.zeros(shape, np.uint16)
+            for i in range(2):
+                for j in range(3):
+                    blocks[:, i * 48:(i + 1) * 48, j * 64:(j + 1) * 64] = rng.randint(1, 65535)
+            blocks[Z // 2:, :, 100:] //= 3                      # a step along the filtered axis as well
+            pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
+            pos[:, :32, :32] = 0
+            pos[:, 32:64, :32] = 400.0
+            mixed = rng.normal(0, 300.0, size=shape).astype(np.float32)
+            negz = pos.copy(); negz[3:6, 40:60, 100:130] = -0.0
+            u16 = np.clip(rng.gamma(2.0, 300.0, size=shape), 0, 65535).astype(np.uint16)
+            cases = {"blocks_u16": blocks, "pos_f32": pos, "mixed_f32": mixed, "negzero_f32": negz, "gamma_u16": u16}
+            for name, im in cases.items():
+                for mode in ("reflect", "nearest"):
+                    ref = ndi.gaussian_filter(im, 7.5, mode=mode, truncate=4.0)
+                    for fold, cert in ((1, -2), (1, -1), (1, 1 << 28), (0, -2)):
+                        L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(fold)))
+                        _set_gauss_cert(cert)
+                        got = gaussian_filter(im, 7.5, mode=mode, truncate=4.0)
+                        if im.dtype == np.float32:
+                            same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+                        else:
+                            same = np.array_equal(got, ref)
+                        assert same, (Z, name, mode, fold, cert, int((got != ref).sum()))
+    finally:
+        _set_gauss_cert(-2)
+        L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
+
+
 # ---------------------------------------------------------------------------------------------
 # production entry: movie -> corrected images + drift + spots in the FOV save file
 # ---------------------------------------------------------------------------------------------
