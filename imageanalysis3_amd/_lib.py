@@ -21,7 +21,7 @@ EXPORTS = [
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",
     "ia3_remove_hot_pixels", "ia3_z_shift_correction", "ia3_illumination_correct", "ia3_bleedthrough_correct",
-    "ia3_dog_seed", "ia3_dog_seed_dev", "ia3_seed_in_distance",
+    "ia3_dog_seed", "ia3_dog_seed_dev", "ia3_dog_filters_dev", "ia3_seed_in_distance",
     "ia3_find_background", "ia3_find_background_dev", "ia3_local_background_dev",
     "ia3_stack_deinterleave", "ia3_buffer_upload", "ia3_buffer_free", "ia3_remove_hot_pixels_dev",
     "ia3_z_shift_correction_dev", "ia3_illumination_correct_dev", "ia3_bleedthrough_correct_dev",

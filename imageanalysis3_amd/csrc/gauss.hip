@@ -238,9 +238,13 @@ template <int Z, int R> constexpr int fold_row(int i) {
   return z;
 }
 
-template <class T, int Z, int R>
+// RF > 0: the same launch also runs the axis-0 pass of a SHORT filter (radius RF, 'reflect' border) over the column
+// it holds and writes it to fout — the DoG seed detector filters one stack with a short and a long kernel, and the
+// two first passes share every load (NI_Correlate1D's sequence, unfused: the short pass is not a certified path).
+template <class T, int Z, int R, int RF = 0>
 __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
-                                                          const double* __restrict__ wf, Taps taps, int mode, int cert) {
+                                                          const double* __restrict__ wf, Taps taps, int mode, int cert,
+                                                          T* __restrict__ fout, Taps ftaps) {
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= plane) return;
   double v[Z];
@@ -252,6 +256,24 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
     ip += plane;
     sbits |= sign_of<T>(t);
     v[z] = (double)t;
+  }
+  if constexpr (RF > 0) {
+    static_assert(Z > RF, "single reflection");
+    T* fo = fout + p;
+    auto frow = [&](auto zc) -> bool {
+      constexpr int z = decltype(zc)::value;
+      double acc = v[z] * ftaps.w[0];
+#pragma unroll
+      for (int j = RF; j >= 1; --j) {
+        const int lo = z - j < 0 ? -(z - j) - 1 : z - j, hi = z + j >= Z ? 2 * Z - 1 - (z + j) : z + j;   // compile-time
+        acc = acc + (v[lo] + v[hi]) * ftaps.w[j];
+      }
+      *fo = cvt<T>(acc);
+      fo += plane;
+      return true;
+    };
+    static_for_until<0, Z>(frow);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // rows complete in the order 0, Z-1, 1, Z-2, ...: two walking pointers instead of Z plane offsets in SGPRs
   T* olo = out + p;
@@ -615,6 +637,91 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
   }
 }
 
+// ---- axes 1 and 2 of a short filter, plane by plane (the axis-0 pass was done by gauss_axis0_folded<.., RF>) --------
+// One 256-thread block walks an x segment of one plane in steps of TXB rows over a y tile of TY <= 248 columns.
+// Axis 1: thread t owns column y0 - R + t, loads TXB + 2R values of it (coalesced along y), converts each once and
+// writes TXB outputs to LDS; axis 2: runs of four outputs along y from 16-byte LDS pieces, stored as one 16-byte piece.
+// No z window, no halo planes: 60 registers, six blocks per CU.
+template <class T, int R>
+__global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, T* __restrict__ out, int X, int Y, Taps taps,
+                                                     const int* __restrict__ mx, const int* __restrict__ my, int TY, int xseg) {
+  constexpr int TXB = 16, RUN2 = 4, PITCH = 264, NV = (RUN2 + 2 * R + 3) / 4 * 4;
+  __shared__ __attribute__((aligned(16))) float B[TXB][PITCH];
+  const int t = threadIdx.x;
+  const int y0 = blockIdx.x * TY, EY = TY + 2 * R;
+  const int xbeg = blockIdx.y * xseg, xend = xbeg + xseg < X ? xbeg + xseg : X;
+  const size_t pz = (size_t)blockIdx.z * X * Y;
+  const T* ip = in + pz;
+  T* op = out + pz;
+  const int gy = t < EY ? my[y0 + t] : 0;
+  const int nr2 = TY / RUN2;                       // runs per row
+  int rx[4], ry[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int id = t + 256 * r;
+    rx[r] = id < TXB * nr2 ? id / nr2 : -1;
+    ry[r] = (id % nr2) * RUN2;
+  }
+  const bool vec = (Y % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  // the column window slides by TXB rows per step; the TXB rows a step adds are fetched one step ahead (in the stack
+  // dtype), so their latency runs under the previous step's two passes
+  double v[TXB + 2 * R];
+  T nxt[TXB];
+  if (t < EY) {
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) v[TXB + j] = (double)ip[(size_t)mx[xbeg + j] * Y + gy];
+#pragma unroll
+    for (int j = 0; j < TXB; ++j) nxt[j] = ip[(size_t)mx[xbeg + 2 * R + j] * Y + gy];
+  }
+  for (int xs = xbeg; xs < xend; xs += TXB) {
+    if (t < EY) {
+#pragma unroll
+      for (int j = 0; j < 2 * R; ++j) v[j] = v[TXB + j];
+#pragma unroll
+      for (int j = 0; j < TXB; ++j) v[2 * R + j] = (double)nxt[j];
+      if (xs + TXB < xend) {
+#pragma unroll
+        for (int j = 0; j < TXB; ++j) nxt[j] = ip[(size_t)mx[xs + TXB + 2 * R + j] * Y + gy];
+      }
+#pragma unroll
+      for (int o = 0; o < TXB; ++o) {
+        double acc = v[o + R] * taps.w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j) acc = acc + (v[o + R - j] + v[o + R + j]) * taps.w[j];
+        B[o][t] = (float)cvt<T>(acc);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = rx[r];
+      if (x >= 0 && xs + x < xend) {
+        float f[NV];
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) *reinterpret_cast<float4*>(&f[4 * q]) = *reinterpret_cast<const float4*>(&B[x][ry[r] + 4 * q]);
+        alignas(16) T res[RUN2];
+#pragma unroll
+        for (int o = 0; o < RUN2; ++o) {
+          double acc = (double)f[o + R] * taps.w[0];
+#pragma unroll
+          for (int j = R; j >= 1; --j) acc = acc + ((double)f[o + R - j] + (double)f[o + R + j]) * taps.w[j];
+          res[o] = cvt<T>(acc);
+        }
+        const int y = y0 + ry[r];
+        T* po = op + (size_t)(xs + x) * Y + y;
+        if (vec && y + RUN2 <= Y) {
+          if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(po) = *reinterpret_cast<const float4*>(res);
+          else *reinterpret_cast<uint2*>(po) = *reinterpret_cast<const uint2*>(res);
+        } else {
+#pragma unroll
+          for (int o = 0; o < RUN2; ++o) if (y + o < Y) po[o] = res[o];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // KZ / KS / KC: outputs per chunk of the axis-0 pass, of the other strided passes, of the LDS-transposed pass
 int g_cert = -2;   // -2: default guard (4R+8 ulps), -1: fused path off, >= 0: guard distance in ulps (tests)
 inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
@@ -657,8 +764,58 @@ template <class T, int Z, int R>
 int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipStream_t s, int cert) {
   const double* wf = folded_rows<Z, R>(t, mode, s);
   if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
-  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert);
+  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert,
+                     (T*)nullptr, t);
   return 0;
+}
+
+// both first passes of the DoG pair in one launch (long: folded, -> dst; short: radius RF, reflect, -> fdst)
+template <class T, int Z, int R, int RF>
+int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Taps& ft, T* fdst, hipStream_t s, int cert) {
+  const double* wf = folded_rows<Z, R>(t, IA3_MODE_REFLECT, s);
+  if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
+  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R, RF>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t,
+                     (int)IA3_MODE_REFLECT, cert, fdst, ft);
+  return 0;
+}
+
+template <class T>
+int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt, T* dst_front, T* dst_zp, T* tmp, hipStream_t s) {
+  constexpr int RF = 3, RB = 30;
+  const size_t plane = (size_t)X * Y;
+  bool nonneg = true;
+  for (int j = 0; j <= RB; ++j) nonneg &= bt.w[j] >= 0.0;
+  const int cert = !nonneg ? -1 : (g_cert == -2 ? 3 * RB + Z + 16 : g_cert);
+  int rc;
+  {
+    ia3rt::ProfScope ps("gauss_axis0_pair");
+    switch (Z) {
+      case 30: rc = run_folded_pair<T, 30, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
+      case 40: rc = run_folded_pair<T, 40, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
+      case 50: rc = run_folded_pair<T, 50, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
+      default: return 1;
+    }
+  }
+  if (rc) return rc;
+  // axes 1 and 2 of the short filter: tmp -> dst_front, on the auxiliary stream (the caller goes on with dst_zp)
+  const int ntile = (Y + 247) / 248;
+  const int TY = ((Y + ntile - 1) / ntile + 3) / 4 * 4;
+  const int xseg = 128;
+  const int cx = X + 2 * RF + 32, cy = ntile * TY + 2 * RF;
+  ia3rt::AuxScope aux;
+  hipStream_t sa = ia3rt::stream();
+  ia3rt::Scratch maps((size_t)(cx + cy) * sizeof(int));
+  if (!maps.p) return IA3_ENOMEM;
+  int* mx = maps.as<int>();
+  int* my = mx + cx;
+  hipLaunchKernelGGL(border_map_k, dim3((cx + 255) / 256), dim3(256), 0, sa, mx, cx, RF, X, (int)IA3_MODE_REFLECT);
+  hipLaunchKernelGGL(border_map_k, dim3((cy + 255) / 256), dim3(256), 0, sa, my, cy, RF, Y, (int)IA3_MODE_REFLECT);
+  {
+    ia3rt::ProfScope ps("gauss_xy_R3");
+    dim3 g((unsigned)ntile, (unsigned)((X + xseg - 1) / xseg), (unsigned)Z);
+    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, (const int*)mx, (const int*)my, TY, xseg);
+  }
+  return aux.ok ? 0 : -1;   // -1: no auxiliary stream, everything ran on the main one (nothing to join)
 }
 
 // axes: bit 0 = the axis-0 pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst)
@@ -838,6 +995,29 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
   if (dtype == IA3_F32) rc = gaussian3d_t<float>((const float*)src, Z, X, Y, w, radius, mode, (float*)dst, (float*)tmp, axes);
   else rc = gaussian3d_t<uint16_t>((const uint16_t*)src, Z, X, Y, w, radius, mode, (uint16_t*)dst, (uint16_t*)tmp, axes);
   if (rc) return rc;
+  IA3_KCHECK();
+  return IA3_OK;
+}
+
+// The DoG pair of get_seeds on one stack: the short filter (wf, radius rf) completely -> dst_front, and the axis-0 pass
+// of the long filter (wb, radius rb) -> dst_zp, both 'reflect'.  The two axis-0 passes share one launch and every load;
+// the short filter's other two axes are queued on the auxiliary stream.  Returns 0 with *forked = 1 when the caller
+// has to aux_join() before reading dst_front, 1 when this shape / these radii are not covered (nothing was queued).
+int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
+                   void* dst_front, void* dst_zp, void* tmp, int* forked) {
+  *forked = 0;
+  if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)X * Y > 0x7fffffffULL || Y < 8 || X < 4) return 1;
+  for (int j = 1; j <= rf; ++j) if (wf[rf + j] != wf[rf - j]) return 1;
+  for (int j = 1; j <= rb; ++j) if (wb[rb + j] != wb[rb - j]) return 1;
+  Taps ft, bt;
+  for (int j = 0; j < 64; ++j) { ft.w[j] = j <= rf ? wf[rf + j] : 0.0; bt.w[j] = j <= rb ? wb[rb + j] : 0.0; }
+  hipStream_t s = ia3rt::stream();
+  int rc;
+  if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s);
+  else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s);
+  if (rc == 1) return 1;
+  if (rc > 0) return rc;
+  *forked = rc == 0;
   IA3_KCHECK();
   return IA3_OK;
 }

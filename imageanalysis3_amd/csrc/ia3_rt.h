@@ -88,6 +88,9 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
                void* dst, void* tmp, int axes = 3);
 // out = im - low ; out[low > im] = 0   (correction_tools/filter.py:17-18)
 int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out);
+// DoG pair of the seed detector: short filter -> dst_front (complete), axis-0 pass of the long filter -> dst_zp (gauss.hip)
+int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
+                   void* dst_front, void* dst_zp, void* tmp, int* forked);
 // get_seeds on a resident stack (seed.hip)
 struct SeedOut {
   std::vector<double> zxyh;  // n x 4 [z,x,y,h], brightest first

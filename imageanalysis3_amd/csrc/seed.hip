@@ -278,7 +278,21 @@ __global__ __launch_bounds__(256) void blockmin_k(const T* __restrict__ zp, int 
   float m = INFINITY, a = 0.f;
   if (y < Y) {   // V > 1 only when Y % V == 0: a lane's V voxels are all inside
     const T* p = zp + ((size_t)z * X + x0) * Y + y;
-    for (int x = x0; x < x1; ++x, p += Y) {
+    constexpr int U = 8;   // rows in flight per thread (the reduction is latency-bound otherwise)
+    int x = x0;
+    for (; x + U <= x1; x += U, p += (size_t)U * Y) {
+      alignas(16) T v[U][V];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (V * sizeof(T) == 16) *reinterpret_cast<uint4*>(v[u]) = *reinterpret_cast<const uint4*>(p + (size_t)u * Y);
+        else v[u][0] = p[(size_t)u * Y];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float f = (float)v[u][k]; m = fminf(m, f); a = fmaxf(a, fabsf(f)); }
+    }
+    for (; x < x1; ++x, p += Y) {
       alignas(16) T v[V];
       if constexpr (V * sizeof(T) == 16) *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p);
       else v[0] = *p;
@@ -768,19 +782,33 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   if (!bnd.p || !c0buf.p) return IA3_ENOMEM;
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
   // background (long, f64-VALU-bound) one; the detector waits for both.
-  bool forked = false;
+  bool forked = false, paired = false;
   if (p.gfilt_size > 0) {
     if (p.w_front) { w.assign(p.w_front, p.w_front + 2 * p.r_front + 1); R = p.r_front; }
     else gaussian_taps(p.gfilt_size, 4.0, w, R);
-    {
-      AuxScope aux;
-      forked = aux.ok;
-      rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp2.p);
+    if (lazy) {
+      // short stacks: both axis-0 passes from one launch (the column is loaded once), then the short filter's other two
+      // axes on the auxiliary stream next to the block minima of the long filter's axis-0 result
+      int fk = 0;
+      rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk);
+      if (rc == 0) { paired = true; forked = fk != 0; }
+      else if (rc != 1) { if (fk) aux_join(); return rc; }
     }
-    if (rc) { if (forked) aux_join(); return rc; }
+    if (!paired) {
+      {
+        AuxScope aux;
+        forked = aux.ok;
+        rc = gaussian3d(im->d, im->dtype, Z, X, Y, w.data(), R, IA3_MODE_REFLECT, a.p, tmp2.p);
+      }
+      if (rc) { if (forked) aux_join(); return rc; }
+    }
     maxim = a.p;
   }
-  if (p.background_gfilt_size > 0) {
+  if (paired) {
+    minim = b.p;
+    if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+    else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+  } else if (p.background_gfilt_size > 0) {
     rc = gaussian3d(im->d, im->dtype, Z, X, Y, wb.data(), Rb, IA3_MODE_REFLECT, b.p, tmp.p, lazy ? 1 : 3);
     if (rc) { if (forked) aux_join(); return rc; }
     minim = b.p;
@@ -1109,6 +1137,27 @@ int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p, double* out_
   if (n && !out_zxyh) return set_error(IA3_EINVAL, "null output");
   if (n) memcpy(out_zxyh, o.zxyh.data(), o.zxyh.size() * sizeof(double));
   return IA3_OK;
+}
+
+int ia3_dog_filters_dev(const ia3_stack* im, double sigma_front, double sigma_back, ia3_stack* front, ia3_stack* back_axis0) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!im || !front || !back_axis0) return set_error(IA3_EINVAL, "null stack");
+  for (const ia3_stack* o : {front, back_axis0})
+    if (o->dtype != im->dtype || o->Z != im->Z || o->X != im->X || o->Y != im->Y) return set_error(IA3_EINVAL, "stacks differ in shape or dtype");
+  if (front->d == im->d || back_axis0->d == im->d || front->d == back_axis0->d) return set_error(IA3_EINVAL, "outputs must not alias");
+  if (!(sigma_front > 0) || !(sigma_back > 0)) return set_error(IA3_EINVAL, "sigma must be > 0");
+  std::vector<double> wf, wb; int rf, rb;
+  gaussian_taps(sigma_front, 4.0, wf, rf);
+  gaussian_taps(sigma_back, 4.0, wb, rb);
+  Scratch tmp(im->bytes);
+  if (!tmp.p) return IA3_ENOMEM;
+  int forked = 0;
+  rc = ia3k::gauss_dog_pair(im->d, im->dtype, im->Z, im->X, im->Y, wf.data(), rf, wb.data(), rb, front->d, back_axis0->d, tmp.p, &forked);
+  if (rc == 0) return forked ? aux_join() : IA3_OK;
+  if (rc != 1) { if (forked) aux_join(); return rc; }
+  rc = ia3k::gaussian3d(im->d, im->dtype, im->Z, im->X, im->Y, wf.data(), rf, IA3_MODE_REFLECT, front->d, tmp.p);
+  if (rc) return rc;
+  return ia3k::gaussian3d(im->d, im->dtype, im->Z, im->X, im->Y, wb.data(), rb, IA3_MODE_REFLECT, back_axis0->d, tmp.p, 1);
 }
 
 int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_params* p,

@@ -161,6 +161,14 @@ int ia3_dog_seed(const void* im, int dtype, int Z, int X, int Y, const ia3_seed_
 int ia3_dog_seed_dev(const ia3_stack* im, const ia3_seed_params* p,
                      double* out_zxyh, int capacity, int* n_out, double* th_used);
 
+/* The two filtered stacks get_seeds compares (spot_tools/fitting.py:83-96), as the seed detector computes them: `front`
+ * = scipy.ndimage.gaussian_filter(im, sigma_front) complete, `back_axis0` = the FIRST pass of
+ * gaussian_filter(im, sigma_back), i.e. scipy.ndimage.gaussian_filter1d(im, sigma_back, axis=0) — the detector runs the
+ * other two passes of the background filter only around candidate maxima.  Both 'reflect', truncate 4, bit-identical
+ * to SciPy.  On stacks of 30 / 40 / 50 planes with the default sigmas (0.75, 7.5) the two axis-0 passes share one
+ * launch; every other case runs the separate filters.  Outputs must not alias the input or each other. */
+int ia3_dog_filters_dev(const ia3_stack* im, double sigma_front, double sigma_back, ia3_stack* front, ia3_stack* back_axis0);
+
 /* ---- the pre-correction chain of io_tools/load.py:323-384 on stacks that stay resident ---------------------------
  * ia3_remove_hot_pixels_dev works in place; float_arith != 0 on a uint16 stack = the chain's
  * corrections.Remove_Hot_Pixels(im.astype(np.float32), dtype=np.uint16) (float32 votes and means, one truncation at

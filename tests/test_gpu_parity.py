@@ -900,6 +900,41 @@ def test_gaussian_axis0_folded_column_pass_bit_exact():
         L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
 
 
+def test_dog_filter_pair_shared_axis0_launch_bit_exact():
+    """ia3_dog_filters_dev: the seed detector's two filtered stacks.  On 30 / 40 / 50 planes the two axis-0 passes come
+    from one launch (column in registers) and the short filter's other axes from the plane-wise kernel; other depths
+    run the separate filters.  front == scipy gaussian_filter(im, 0.75), back == gaussian_filter1d(im, 7.5, axis=0),
+    bit for bit, on ragged plane sizes, with the guard at its default, off and wide open."""
+    import ctypes as C
+    from scipy import ndimage as ndi
+    from imageanalysis3_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(13)
+    try:
+        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120)):
+            shape = (Z, X, Y)
+            pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
+            pos[:, :20, :20] = 0
+            mixed = rng.normal(0, 300.0, size=shape).astype(np.float32)
+            u16 = np.clip(rng.gamma(2.0, 300.0, size=shape), 0, 65535).astype(np.uint16)
+            steps = np.zeros(shape, np.uint16)
+            steps[:, X // 2:, :] = 40000; steps[Z // 3:, :, Y // 2:] += 7777
+            for name, im in (("pos_f32", pos), ("mixed_f32", mixed), ("gamma_u16", u16), ("steps_u16", steps)):
+                ref_f = ndi.gaussian_filter(im, 0.75, mode="reflect", truncate=4.0)
+                ref_b = ndi.gaussian_filter1d(im, 7.5, axis=0, mode="reflect", truncate=4.0)
+                for cert in (-2, -1, 1 << 28):
+                    _set_gauss_cert(cert)
+                    with L.DeviceStack.upload(im) as st, L.DeviceStack.empty(shape, im.dtype) as f, \
+                            L.DeviceStack.empty(shape, im.dtype) as b:
+                        L.check(lib.ia3_dog_filters_dev(st._h, C.c_double(0.75), C.c_double(7.5), f._h, b._h))
+                        got_f, got_b = f.download(), b.download()
+                    v = np.uint32 if im.dtype == np.float32 else np.uint16
+                    assert np.array_equal(got_f.view(v), ref_f.view(v)), (shape, name, cert, "front", int((got_f != ref_f).sum()))
+                    assert np.array_equal(got_b.view(v), ref_b.view(v)), (shape, name, cert, "back", int((got_b != ref_b).sum()))
+    finally:
+        _set_gauss_cert(-2)
+
+
 # ---------------------------------------------------------------------------------------------
 # production entry: movie -> corrected images + drift + spots in the FOV save file
 # ---------------------------------------------------------------------------------------------
