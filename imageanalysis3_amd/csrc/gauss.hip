@@ -769,6 +769,25 @@ int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipS
   return 0;
 }
 
+// border map (position i - R -> source index) kept on the device per (count, R, len, mode): the plane-wise kernel is
+// launched right behind the column kernel, a map-building launch in between would sit on the critical path
+const int* cached_border_map(int count, int R, int len, int mode) {
+  struct Key { int count, R, len, mode; const int* d; };
+  static std::mutex mu;
+  static std::vector<Key> maps;
+  std::lock_guard<std::mutex> g(mu);
+  for (const Key& k : maps)
+    if (k.count == count && k.R == R && k.len == len && k.mode == mode) return k.d;
+  std::vector<int> h(count);
+  for (int i = 0; i < count; ++i) h[i] = border_idx(i - R, len, mode);
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)count * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  if (maps.size() >= 64) maps.erase(maps.begin());   // (the evicted map stays allocated: launches may be in flight)
+  maps.push_back(Key{count, R, len, mode, d});
+  return d;
+}
+
 // both first passes of the DoG pair in one launch (long: folded, -> dst; short: radius RF, reflect, -> fdst)
 template <class T, int Z, int R, int RF>
 int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Taps& ft, T* fdst, hipStream_t s, int cert) {
@@ -802,18 +821,15 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   const int TY = ((Y + ntile - 1) / ntile + 3) / 4 * 4;
   const int xseg = 128;
   const int cx = X + 2 * RF + 32, cy = ntile * TY + 2 * RF;
+  const int* mx = cached_border_map(cx, RF, X, IA3_MODE_REFLECT);
+  const int* my = cached_border_map(cy, RF, Y, IA3_MODE_REFLECT);
+  if (!mx || !my) return ia3rt::set_error(IA3_ENOMEM, "border maps");
   ia3rt::AuxScope aux;
   hipStream_t sa = ia3rt::stream();
-  ia3rt::Scratch maps((size_t)(cx + cy) * sizeof(int));
-  if (!maps.p) return IA3_ENOMEM;
-  int* mx = maps.as<int>();
-  int* my = mx + cx;
-  hipLaunchKernelGGL(border_map_k, dim3((cx + 255) / 256), dim3(256), 0, sa, mx, cx, RF, X, (int)IA3_MODE_REFLECT);
-  hipLaunchKernelGGL(border_map_k, dim3((cy + 255) / 256), dim3(256), 0, sa, my, cy, RF, Y, (int)IA3_MODE_REFLECT);
   {
     ia3rt::ProfScope ps("gauss_xy_R3");
     dim3 g((unsigned)ntile, (unsigned)((X + xseg - 1) / xseg), (unsigned)Z);
-    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, (const int*)mx, (const int*)my, TY, xseg);
+    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg);
   }
   return aux.ok ? 0 : -1;   // -1: no auxiliary stream, everything ran on the main one (nothing to join)
 }

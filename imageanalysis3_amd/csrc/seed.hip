@@ -780,6 +780,24 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   Scratch bnd(lazy ? (nblk + (nblk & 1)) * 2 * sizeof(float) + nblk * sizeof(double) : 256);
   Scratch c0buf(lazy ? (size_t)LAZY_CAP * sizeof(Cand0) : 256);
   if (!bnd.p || !c0buf.p) return IA3_ENOMEM;
+  // candidate buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity] and the workspace of the device-side finish: cleared
+  // here, in front of the filters, so that no fill launch sits between the filters and the detector
+  unsigned capacity = 1u << 20;
+  constexpr size_t HDR = 2 * sizeof(SeedCtl);
+  Scratch buf0(HDR + (size_t)capacity * sizeof(Cand));
+  if (!buf0.p) return IA3_ENOMEM;
+  IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, s));
+  const bool dev_finish = dev && Z <= 256 && X <= 4096 && Y <= 4096;
+  const size_t o_hot = sizeof(FinCtl), o_rank = o_hot + 4 * (size_t)FIN_CAP, o_zxy = o_rank + 4 * (size_t)FIN_CAP,
+               o_h = o_zxy + 24 * (size_t)FIN_CAP, fin_bytes = o_h + 8 * (size_t)FIN_CAP;
+  void* fin = nullptr;
+  if (dev_finish) {
+    fin = ws_get(fin_bytes);
+    if (!fin) return IA3_ENOMEM;
+    hipError_t fe = hipMemsetAsync(fin, 0, o_zxy, s);
+    if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(fe)); }
+  }
+  struct FinGuard { void*& p; ~FinGuard() { if (p) ws_put(p); } } fin_guard{fin};   // handed to the caller on success (fin = nullptr)
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
   // background (long, f64-VALU-bound) one; the detector waits for both.
   bool forked = false, paired = false;
@@ -821,19 +839,18 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   const double t1 = now_ms();
   // device buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity]; the header and the first FIRST candidates come back
   // in ONE copy (the common case: a few thousand seeds), the rest only if there are more
-  unsigned capacity = 1u << 20;
   constexpr unsigned FIRST = 8192;
-  constexpr size_t HDR = 2 * sizeof(SeedCtl);
   std::vector<Cand> cand;
   std::vector<char> hbuf(HDR + (size_t)FIRST * sizeof(Cand));
   SeedCtl hctl, hlazy;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    Scratch buf(HDR + (size_t)capacity * sizeof(Cand));
-    if (!buf.p) return IA3_ENOMEM;
-    SeedCtl* dctl = (SeedCtl*)buf.p;
+    Scratch buf(attempt == 0 ? 0 : HDR + (size_t)capacity * sizeof(Cand));
+    void* bp = attempt == 0 ? buf0.p : buf.p;
+    if (!bp) return IA3_ENOMEM;
+    SeedCtl* dctl = (SeedCtl*)bp;
     SeedCtl* dlazy = dctl + 1;
-    Cand* dcand = (Cand*)((char*)buf.p + HDR);
-    IA3_HIP(hipMemsetAsync(dctl, 0, HDR, s));
+    Cand* dcand = (Cand*)((char*)bp + HDR);
+    if (attempt > 0) IA3_HIP(hipMemsetAsync(dctl, 0, HDR, s));
     if (lazy) {
       if (im->dtype == IA3_F32)
         launch_lazy<float>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1);
@@ -847,15 +864,10 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
         launch_detect<uint16_t>(p.filt_size, maxim, minim, Z, X, Y, p.min_edge_distance, th_low, dcand, capacity, dctl, s);
     }
     IA3_KCHECK();
-    if (dev && attempt == 0 && Z <= 256 && X <= 4096 && Y <= 4096) {
+    if (dev_finish && attempt == 0) {
       // finish on the device; the host only learns how many seeds there are
-      const size_t o_hot = sizeof(FinCtl), o_rank = o_hot + 4 * (size_t)FIN_CAP, o_zxy = o_rank + 4 * (size_t)FIN_CAP,
-                   o_h = o_zxy + 24 * (size_t)FIN_CAP, fin_bytes = o_h + 8 * (size_t)FIN_CAP;
-      void* fin = ws_get(fin_bytes);
-      if (!fin) return IA3_ENOMEM;
       char* fb = (char*)fin;
-      hipError_t fe = hipMemsetAsync(fin, 0, o_zxy, s);
-      if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(fe)); }
+      hipError_t fe;
       FinCtl* fc = (FinCtl*)fb;
       unsigned* hot = (unsigned*)(fb + o_hot);
       unsigned* rank = (unsigned*)(fb + o_rank);
@@ -874,11 +886,9 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       fe = hipGetLastError();
       if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
       if (fe == hipSuccess) fe = hipStreamSynchronize(s);
-      if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe)); }
-      if (hfc.overflow & 2u) {   // more first-stage candidates than the lazy path is sized for: dense filter instead
-        ws_put(fin);
+      if (fe != hipSuccess) return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe));
+      if (hfc.overflow & 2u)     // more first-stage candidates than the lazy path is sized for: dense filter instead
         return dog_seed_impl(im, p, out, dev, true);
-      }
       hctl.n_cand = hfc.n_cand; hctl.overflow = hfc.overflow;
       if (hctl.n_cand <= FIN_CAP && !hctl.overflow) {
         int n = (int)hfc.n_alive;
@@ -889,12 +899,14 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
         dev->d_zxy = (const double*)(fb + o_zxy);
         dev->d_h = (const double*)(fb + o_h);
         dev->hold = fin;
+        fin = nullptr;   // now the caller's
         if (dbg) fprintf(stderr, "dog_seed: device finish, %u candidates -> %d seeds\n", hctl.n_cand, n);
         return IA3_OK;
       }
       ws_put(fin);   // too many candidates: the host path below takes over (the detector's output is still in buf)
+      fin = nullptr;
     }
-    IA3_HIP(hipMemcpyAsync(hbuf.data(), buf.p, hbuf.size(), hipMemcpyDeviceToHost, s));
+    IA3_HIP(hipMemcpyAsync(hbuf.data(), bp, hbuf.size(), hipMemcpyDeviceToHost, s));
     IA3_HIP(hipStreamSynchronize(s));
     memcpy(&hctl, hbuf.data(), sizeof(SeedCtl));
     memcpy(&hlazy, hbuf.data() + sizeof(SeedCtl), sizeof(SeedCtl));
