@@ -644,9 +644,11 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
 // No z window, no halo planes: 60 registers, six blocks per CU.
 template <class T, int R>
 __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, T* __restrict__ out, int X, int Y, Taps taps,
-                                                     const int* __restrict__ mx, const int* __restrict__ my, int TY, int xseg) {
+                                                     const int* __restrict__ mx, const int* __restrict__ my, int TY, int xseg,
+                                                     float* __restrict__ tmax) {
   constexpr int TXB = 16, RUN2 = 4, PITCH = 264, NV = (RUN2 + 2 * R + 3) / 4 * 4;
   __shared__ __attribute__((aligned(16))) float B[TXB][PITCH];
+  __shared__ unsigned smx[4];   // per 64-column group of the tile: largest output of the step, as an order-preserving key
   const int t = threadIdx.x;
   const int y0 = blockIdx.x * TY, EY = TY + 2 * R;
   const int xbeg = blockIdx.y * xseg, xend = xbeg + xseg < X ? xbeg + xseg : X;
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
     rx[r] = id < TXB * nr2 ? id / nr2 : -1;
     ry[r] = (id % nr2) * RUN2;
   }
+  if (t < 4) smx[t] = 0u;   // (the first barrier of the loop orders this before the first atomic)
   const bool vec = (Y % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   // the column window slides by TXB rows per step; the TXB rows a step adds are fetched one step ahead (in the stack
   // dtype), so their latency runs under the previous step's two passes
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int x = rx[r];
+      float smax = -INFINITY;   // largest of this run's outputs
       if (x >= 0 && xs + x < xend) {
         float f[NV];
 #pragma unroll
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
 #pragma unroll
           for (int j = R; j >= 1; --j) acc = acc + ((double)f[o + R - j] + (double)f[o + R + j]) * taps.w[j];
           res[o] = cvt<T>(acc);
+          smax = fmaxf(smax, (float)res[o]);
         }
         const int y = y0 + ry[r];
         T* po = op + (size_t)(xs + x) * Y + y;
@@ -717,8 +722,26 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
           for (int o = 0; o < RUN2; ++o) if (y + o < Y) po[o] = res[o];
         }
       }
+      if (tmax) {
+        // TY is a multiple of 64 here: 16 consecutive runs (an aligned group of 16 lanes) are one row of one 64-column
+        // group, i.e. of one detector tile; the group's maximum goes to its LDS slot
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
+        if ((t & 15) == 0 && smax > -INFINITY) {
+          const unsigned u = __float_as_uint(smax);
+          atomicMax(&smx[ry[r] >> 6], (u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        }
+      }
     }
     __syncthreads();
+    if (tmax && t < (TY >> 6)) {   // [plane][step of TXB rows][64-column group]; the next step's atomics come behind its first barrier
+      const int col = (y0 >> 6) + t, ncol = (Y + 63) >> 6;
+      const unsigned k = smx[t];
+      smx[t] = 0u;
+      if (col < ncol)
+        tmax[((size_t)blockIdx.z * ((X + TXB - 1) / TXB) + xs / TXB) * ncol + col] =
+            k == 0u ? -INFINITY : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+    }
   }
 }
 
@@ -799,7 +822,8 @@ int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Tap
 }
 
 template <class T>
-int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt, T* dst_front, T* dst_zp, T* tmp, hipStream_t s) {
+int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt, T* dst_front, T* dst_zp, T* tmp, hipStream_t s,
+               float* tmax) {
   constexpr int RF = 3, RB = 30;
   const size_t plane = (size_t)X * Y;
   bool nonneg = true;
@@ -817,9 +841,9 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   }
   if (rc) return rc;
   // axes 1 and 2 of the short filter: tmp -> dst_front, on the auxiliary stream (the caller goes on with dst_zp)
-  const int ntile = (Y + 247) / 248;
-  const int TY = ((Y + ntile - 1) / ntile + 3) / 4 * 4;
-  const int xseg = 128;
+  int TY, ntile;
+  ia3k::dog_pair_tiles(X, Y, &TY, &ntile, nullptr);
+  const int xseg = 128;   // a multiple of the 16-row step: steps start on multiples of 16
   const int cx = X + 2 * RF + 32, cy = ntile * TY + 2 * RF;
   const int* mx = cached_border_map(cx, RF, X, IA3_MODE_REFLECT);
   const int* my = cached_border_map(cy, RF, Y, IA3_MODE_REFLECT);
@@ -829,7 +853,7 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   {
     ia3rt::ProfScope ps("gauss_xy_R3");
     dim3 g((unsigned)ntile, (unsigned)((X + xseg - 1) / xseg), (unsigned)Z);
-    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg);
+    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg, tmax);
   }
   return aux.ok ? 0 : -1;   // -1: no auxiliary stream, everything ran on the main one (nothing to join)
 }
@@ -1019,8 +1043,17 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
 // of the long filter (wb, radius rb) -> dst_zp, both 'reflect'.  The two axis-0 passes share one launch and every load;
 // the short filter's other two axes are queued on the auxiliary stream.  Returns 0 with *forked = 1 when the caller
 // has to aux_join() before reading dst_front, 1 when this shape / these radii are not covered (nothing was queued).
+// geometry of the plane-wise kernel: y tiles of TY columns, steps of 16 rows; *count = entries per plane of the table of
+// step maxima (one per 16 rows x 64 columns = per tile of the candidate detector)
+void dog_pair_tiles(int X, int Y, int* ty, int* ntile, size_t* count) {
+  const int ncol = (Y + 63) / 64;              // 64-column groups = the detector's tile columns
+  *ty = 64 * (ncol < 3 ? ncol : 3);            // a y tile holds whole groups: 192 columns (198 of 256 threads on axis 1)
+  *ntile = (Y + *ty - 1) / *ty;
+  if (count) *count = (size_t)((X + 15) / 16) * (size_t)ncol;
+}
+
 int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
-                   void* dst_front, void* dst_zp, void* tmp, int* forked) {
+                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax) {
   *forked = 0;
   if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)X * Y > 0x7fffffffULL || Y < 8 || X < 4) return 1;
   for (int j = 1; j <= rf; ++j) if (wf[rf + j] != wf[rf - j]) return 1;
@@ -1029,8 +1062,8 @@ int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double
   for (int j = 0; j < 64; ++j) { ft.w[j] = j <= rf ? wf[rf + j] : 0.0; bt.w[j] = j <= rb ? wb[rb + j] : 0.0; }
   hipStream_t s = ia3rt::stream();
   int rc;
-  if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s);
-  else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s);
+  if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s, tmax);
+  else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s, tmax);
   if (rc == 1) return 1;
   if (rc > 0) return rc;
   *forked = rc == 0;

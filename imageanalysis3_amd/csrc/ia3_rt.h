@@ -89,8 +89,10 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
 // out = im - low ; out[low > im] = 0   (correction_tools/filter.py:17-18)
 int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out);
 // DoG pair of the seed detector: short filter -> dst_front (complete), axis-0 pass of the long filter -> dst_zp (gauss.hip)
+// tmax (optional): per plane, 16-row step and y tile (dog_pair_tiles) the largest value of dst_front, for the detector
 int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
-                   void* dst_front, void* dst_zp, void* tmp, int* forked);
+                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax = nullptr);
+void dog_pair_tiles(int X, int Y, int* ty, int* ntile, size_t* count);
 // get_seeds on a resident stack (seed.hip)
 struct SeedOut {
   std::vector<double> zxyh;  // n x 4 [z,x,y,h], brightest first

@@ -337,10 +337,13 @@ template <class T, int ZC, int B>
 __global__ __launch_bounds__(256) void seed_cand3_tiled(const T* __restrict__ mx, const double* __restrict__ lb, int nbx, int nby,
                                                         int Z, int X, int Y, int edge, double th_test,
                                                         Cand0* __restrict__ out, unsigned capacity,
-                                                        SeedCtl* __restrict__ ctl) {
+                                                        SeedCtl* __restrict__ ctl,
+                                                        const float* __restrict__ smax, int sm_ty, int sm_ntile) {
   constexpr int TX = 16, TY = 64, HX = TX + 2, HY = TY + 2, NE = (HX * HY + 255) / 256;
   static_assert(B % TX == 0, "a tile must lie inside one block row");
+  static_assert(ZC <= 254, "plane flags");
   __shared__ T tmax[2][HX][HY + 2];
+  __shared__ unsigned char act_s[ZC + 2];   // act_s[1 + z - z0]: plane z of this tile can hold a candidate
   const int nty = (Y + TY - 1) / TY, ntx = (X + TX - 1) / TX;
   const int tile = xcd_tile(blockIdx.x, nty * ntx);
   if (tile < 0) return;
@@ -372,12 +375,36 @@ __global__ __launch_bounds__(256) void seed_cand3_tiled(const T* __restrict__ mx
   for (int v = 0; v < 4; ++v) { pM[v][0] = pM[v][1] = pM[v][2] = 0; cM[v][0] = cM[v][1] = 0; }
   const int yb = min(y0 + ty, Y - 1) / B;
   const size_t lrow = (size_t)(x0 / B) * nby + yb;
-  fetch(z0 - 1);
-  stash(0);
+  // Plane flags.  smax (optional, written by the plane-wise filter kernel): largest max_im value per plane and 16 x 64 tile
+  // (this kernel's tiles); a plane of this tile whose maximum stays below `lowest level + smallest bound` cannot hold a
+  // candidate (float subtraction is monotone, so the test below never drops a voxel the per-voxel test would pass).  Planes
+  // that are neither flagged nor next to a flagged plane are not fetched at all.
+  if (threadIdx.x < ZC + 2) {
+    const int z = z0 - 1 + (int)threadIdx.x;
+    unsigned char a = 0;
+    if (z >= z0 && z < z1) {
+      a = 1;
+      if (smax) {
+        const int ylast = min(y0 + TY - 1, Y - 1);
+        const float m = smax[((size_t)z * ((X + 15) / 16) + x0 / 16) * ((Y + 63) / 64) + y0 / 64];   // this tile's own entry
+        double lo = INFINITY;
+        for (int by = y0 / B; by <= ylast / B; ++by) lo = fmin(lo, lb[(size_t)z * nbx * nby + (size_t)(x0 / B) * nby + by]);
+        a = ((double)m - lo >= th_test) ? 1 : 0;
+      }
+    }
+    act_s[threadIdx.x] = a;
+  }
+  __syncthreads();
+  auto act = [&](int z) -> bool { return act_s[1 + z - z0] != 0; };                       // z in [z0 - 1, z1]
+  auto need = [&](int q) -> bool {                                                          // q in [z0 - 1, z1]
+    return (q > z0 - 1 && act(q - 1)) || act(q) || (q < z1 && act(q + 1));
+  };
+  if (need(z0 - 1)) { fetch(z0 - 1); stash(0); }
   __syncthreads();
   for (int q = z0 - 1, buf = 0; q <= z1; ++q, buf ^= 1) {
-    if (q < z1) fetch(q + 1);
-    {
+    const bool nq = need(q), nn = q < z1 && need(q + 1);   // block-uniform
+    if (nn) fetch(q + 1);
+    if (nq) {
       const int c = ty + 1;
       T hM[6], ce[4];
 #pragma unroll
@@ -394,10 +421,10 @@ __global__ __launch_bounds__(256) void seed_cand3_tiled(const T* __restrict__ mx
         cM[v][0] = cM[v][1]; cM[v][1] = ce[v];
       }
     }
-    if (q < z1) stash(buf ^ 1);
-    __syncthreads();
+    if (nn) stash(buf ^ 1);
+    if (nq || nn) __syncthreads();   // this plane's reads before the plane after next is stashed over them; the next plane's stash
     const int z = q - 1;
-    if (z < z0) continue;
+    if (z < z0 || !act(z)) continue;
     const double bound = lb[(size_t)z * nbx * nby + lrow];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -699,7 +726,7 @@ constexpr unsigned LAZY_CAP = 1u << 17;   // first-stage candidates of the lazy 
 template <class T>
 static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, const double* w, int R, int edge,
                         double th_low, void* bnd, Cand0* c0, SeedCtl* ctl0, Cand* out, unsigned capacity, SeedCtl* ctl,
-                        hipStream_t s, int stage) {
+                        hipStream_t s, int stage, const float* smax = nullptr, int sm_ty = 0, int sm_ntile = 0) {
   const int B = R <= 32 ? 32 : 64;
   const int nbx = (X + B - 1) / B, nby = (Y + B - 1) / B;
   const size_t nb = (size_t)Z * nbx * nby;
@@ -728,10 +755,10 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
     const double th_test = th_low - fabs(th_low) * 1e-6 - 1e-300;   // the exact test is made in float32: keep the bound test looser
     if (B == 32)
       hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 32>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
-                         th_test, c0, LAZY_CAP, ctl0);
+                         th_test, c0, LAZY_CAP, ctl0, smax, sm_ty, sm_ntile);
     else
       hipLaunchKernelGGL((seed_cand3_tiled<T, ZT, 64>), gt, dim3(256), 0, s, (const T*)mx, (const double*)lb, nbx, nby, Z, X, Y, edge,
-                         th_test, c0, LAZY_CAP, ctl0);
+                         th_test, c0, LAZY_CAP, ctl0, smax, sm_ty, sm_ntile);
   }
   {
     ProfScope ps("seed_sparse_bg");
@@ -800,6 +827,11 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   struct FinGuard { void*& p; ~FinGuard() { if (p) ws_put(p); } } fin_guard{fin};   // handed to the caller on success (fin = nullptr)
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
   // background (long, f64-VALU-bound) one; the detector waits for both.
+  int sm_ty = 0, sm_ntile = 0;
+  size_t sm_count = 0;
+  dog_pair_tiles(X, Y, &sm_ty, &sm_ntile, &sm_count);
+  Scratch smaxbuf(lazy ? sm_count * (size_t)Z * sizeof(float) : 256);   // step maxima of max_im (plane-wise filter -> detector)
+  if (!smaxbuf.p) return IA3_ENOMEM;
   bool forked = false, paired = false;
   if (p.gfilt_size > 0) {
     if (p.w_front) { w.assign(p.w_front, p.w_front + 2 * p.r_front + 1); R = p.r_front; }
@@ -808,7 +840,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       // short stacks: both axis-0 passes from one launch (the column is loaded once), then the short filter's other two
       // axes on the auxiliary stream next to the block minima of the long filter's axis-0 result
       int fk = 0;
-      rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk);
+      rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk, smaxbuf.as<float>());
       if (rc == 0) { paired = true; forked = fk != 0; }
       else if (rc != 1) { if (fk) aux_join(); return rc; }
     }
@@ -853,9 +885,11 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     if (attempt > 0) IA3_HIP(hipMemsetAsync(dctl, 0, HDR, s));
     if (lazy) {
       if (im->dtype == IA3_F32)
-        launch_lazy<float>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1);
+        launch_lazy<float>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1,
+                           paired ? smaxbuf.as<float>() : nullptr, sm_ty, sm_ntile);
       else
-        launch_lazy<uint16_t>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1);
+        launch_lazy<uint16_t>(maxim, b.p, Z, X, Y, wb.data(), Rb, p.min_edge_distance, th_low, bnd.p, c0buf.as<Cand0>(), dlazy, dcand, capacity, dctl, s, 1,
+                              paired ? smaxbuf.as<float>() : nullptr, sm_ty, sm_ntile);
     } else {
       ProfScope ps("seed_detect");
       if (im->dtype == IA3_F32)
