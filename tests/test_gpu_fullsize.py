@@ -308,6 +308,26 @@ def test_lazy_background_filter_equals_dense_filter():
     cases.append(("zeros_f32", zeros, dict(th_seed=100.0)))
     noise = rng.normal(400, 60, size=(30, 512, 512)).astype(np.float32)
     cases.append(("overflow_noise", noise, dict(th_seed=5.0, use_dynamic_th=False, remove_hot_pixel=False)))
+    # production depths (30 / 40 / 50 planes): the lazy path takes both axis-0 passes from the column kernel, the short filter's
+    # other axes from the plane-wise kernel, and the detector skips planes by that kernel's tile maxima (IA3_TUNE_GAUSS_FOLD = 0:
+    # lazy path with the separate filters and a detector that scans every plane)
+    import ctypes as C
+    from imageanalysis3_amd import _lib as L
+    for shape, dt in (((50, 75, 200), np.float32), ((40, 130, 70), np.uint16), ((30, 33, 257), np.float32),
+                      ((50, 17, 65), np.uint16), ((50, 200, 450), np.float32), ((40, 64, 192), np.uint16)):
+        im, c, h = synth.make_fov(shape, 14, 23, dtype=dt, margin=(2, 6, 6), layout="uniform")
+        cases.append(("deep%s" % (shape,), im, dict(th_seed=300.0)))
+    steps50 = (np.arange(50 * 96 * 200).reshape(50, 96, 200) // 517 % 7 * 500 + 300).astype(np.uint16)
+    steps50[20:23, 40:43, 150:153] += 2000
+    cases.append(("deep_plateaus_u16", steps50, dict(th_seed=200.0)))
+    mixed50 = rng.normal(0, 50, size=(50, 90, 210)).astype(np.float32)
+    mixed50[8:11, 30:33, 60:63] += 900
+    mixed50[30:33, 70:73, 190:193] += 700
+    mixed50[5, 70, 20] = -4000.0
+    cases.append(("deep_mixed_sign_f32", mixed50, dict(th_seed=150.0)))
+    zeros40 = np.zeros((40, 64, 130), np.float32)
+    zeros40[6:9, 20:23, 100:103] = 800
+    cases.append(("deep_zeros_f32", zeros40, dict(th_seed=100.0)))
     try:
         for name, im, kw in cases:
             _seed_dense(True)
@@ -315,10 +335,16 @@ def test_lazy_background_filter_equals_dense_filter():
             _seed_dense(False)
             lazy = get_seeds(im, return_h=True, **kw)
             assert dense.shape == lazy.shape and np.array_equal(dense, lazy), (name, dense.shape, lazy.shape)
-            if name != "zeros_f32":
+            if im.shape[0] in (30, 40, 50):
+                L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(0)))
+                lazy0 = get_seeds(im, return_h=True, **kw)
+                L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
+                assert dense.shape == lazy0.shape and np.array_equal(dense, lazy0), (name, "separate filters", dense.shape, lazy0.shape)
+            if not name.endswith("zeros_f32"):
                 assert len(dense) > 0, name
     finally:
         _seed_dense(False)
+        L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
 
 
 def test_phase_correlation_real_transforms_equal_complex_transforms():
