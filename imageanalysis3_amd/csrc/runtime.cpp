@@ -207,14 +207,23 @@ static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 
 static std::mutex g_prof_mu;
+static std::vector<hipEvent_t> g_evpool;   // collected events are reused: creating two per scope cost more than recording them
+static hipEvent_t prof_event_locked() {
+  if (!g_evpool.empty()) { hipEvent_t e = g_evpool.back(); g_evpool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 ProfScope::ProfScope(const char* name) : slot(-1) {
   if (!g_prof || !stream()) return;
   ProfRec r;
   r.name = name;
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.st = stream();
-  (void)hipEventRecord(r.a, r.st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  r.a = prof_event_locked();
+  r.b = prof_event_locked();
+  if (!r.a || !r.b) { if (r.a) g_evpool.push_back(r.a); if (r.b) g_evpool.push_back(r.b); return; }
+  (void)hipEventRecord(r.a, r.st);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
 }
@@ -294,7 +303,7 @@ int ia3_profile_collect(char* buf, int len) {
   for (auto& r : g_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    g_evpool.push_back(r.a); g_evpool.push_back(r.b);
     bool found = false;
     for (auto& a : agg) if (strcmp(a.name, r.name) == 0) { a.n++; a.ms += ms; found = true; break; }
     if (!found) agg.push_back({r.name, 1, (double)ms});
