@@ -650,8 +650,12 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
   __shared__ __attribute__((aligned(16))) float B[TXB][PITCH];
   __shared__ unsigned smx[4];   // per 64-column group of the tile: largest output of the step, as an order-preserving key
   const int t = threadIdx.x;
-  const int y0 = blockIdx.x * TY, EY = TY + 2 * R;
-  const int xbeg = blockIdx.y * xseg, xend = xbeg + xseg < X ? xbeg + xseg : X;
+  // (y tile, x segment) pairs of a plane are dealt to the XCDs in runs, so that tiles sharing halo lines share an L2
+  const int nty = (Y + TY - 1) / TY;
+  const int tile = xcd_tile(blockIdx.x, nty * ((X + xseg - 1) / xseg));
+  if (tile < 0) return;   // whole block
+  const int y0 = (tile % nty) * TY, EY = TY + 2 * R;
+  const int xbeg = (tile / nty) * xseg, xend = xbeg + xseg < X ? xbeg + xseg : X;
   const size_t pz = (size_t)blockIdx.z * X * Y;
   const T* ip = in + pz;
   T* op = out + pz;
@@ -852,7 +856,8 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   hipStream_t sa = ia3rt::stream();
   {
     ia3rt::ProfScope ps("gauss_xy_R3");
-    dim3 g((unsigned)ntile, (unsigned)((X + xseg - 1) / xseg), (unsigned)Z);
+    const unsigned tiles = (unsigned)ntile * (unsigned)((X + xseg - 1) / xseg);
+    dim3 g(8 * ((tiles + 7) / 8), 1, (unsigned)Z);   // tiles, XCD-grouped inside the kernel
     hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg, tmax);
   }
   return aux.ok ? 0 : -1;   // -1: no auxiliary stream, everything ran on the main one (nothing to join)
