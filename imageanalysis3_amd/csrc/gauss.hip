@@ -54,8 +54,9 @@ struct Taps { double w[64]; };
 template <class T> __device__ __forceinline__ bool uncertain(double s, int cert);
 template <> __device__ __forceinline__ bool uncertain<float>(double s, int cert) {
   const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
-  const int d = (int)(lo & 0x1FFFFFFFu) - 0x10000000;
-  const bool near_mid = (d < 0 ? -d : d) <= cert;
+  // |(lo & 0x1FFFFFFF) - 0x10000000| <= cert as one unsigned range test (cert < 2^28 + ..., see cert_for and the tests' 1 << 28)
+  const unsigned c = (unsigned)cert < 0x10000000u ? (unsigned)cert : 0x10000000u;
+  const bool near_mid = ((lo & 0x1FFFFFFFu) - (0x10000000u - c)) <= 2u * c;
   // exponent outside [2^-100, inf): zero is exact on both paths, anything else (tiny, inf, nan) is recomputed
   const bool odd_exp = (hi - 0x39B00000u) >= (0x7FF00000u - 0x39B00000u) && (hi | lo) != 0u;
   return near_mid || odd_exp;
@@ -241,25 +242,45 @@ template <int Z, int R> constexpr int fold_row(int i) {
 // RF > 0: the same launch also runs the axis-0 pass of a SHORT filter (radius RF, 'reflect' border) over the column
 // it holds and writes it to fout — the DoG seed detector filters one stack with a short and a long kernel, and the
 // two first passes share every load (NI_Correlate1D's sequence, unfused: the short pass is not a certified path).
+// buffer-descriptor access: vector byte offset + scalar byte offset
+template <class T> __device__ __forceinline__ T buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ float buf_ld<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <> __device__ __forceinline__ uint16_t buf_ld<uint16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+template <class T> __device__ __forceinline__ void buf_st(T v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ void buf_st<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buf_st<uint16_t>(uint16_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b16((short)v, r, voff, soff, 0);
+}
+
 template <class T, int Z, int R, int RF = 0>
 __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
                                                           const double* __restrict__ wf, Taps taps, int mode, int cert,
                                                           T* __restrict__ fout, Taps ftaps) {
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // addressing: buffer descriptors, this thread's 32-bit byte offset in the plane + the plane's byte offset as the
+  // scalar operand (the host checks Z * plane * sizeof(T) < 2^31): no vector address arithmetic per access
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
   if (p >= plane) return;
+  const unsigned voff = p * (unsigned)sizeof(T), pbytes = (unsigned)plane * (unsigned)sizeof(T);
+  const int nbytes = (int)((unsigned)Z * pbytes);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, nbytes, 0x00020000);
   double v[Z];
   unsigned sbits = 0;
-  const T* ip = in + p;
 #pragma unroll
   for (int z = 0; z < Z; ++z) {
-    const T t = *ip;
-    ip += plane;
+    const T t = buf_ld<T>(rin, voff, (unsigned)z * pbytes);
     sbits |= sign_of<T>(t);
     v[z] = (double)t;
   }
   if constexpr (RF > 0) {
     static_assert(Z > RF, "single reflection");
-    T* fo = fout + p;
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)fout, (short)0, nbytes, 0x00020000);
     auto frow = [&](auto zc) -> bool {
       constexpr int z = decltype(zc)::value;
       double acc = v[z] * ftaps.w[0];
@@ -268,20 +289,17 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
         const int lo = z - j < 0 ? -(z - j) - 1 : z - j, hi = z + j >= Z ? 2 * Z - 1 - (z + j) : z + j;   // compile-time
         acc = acc + (v[lo] + v[hi]) * ftaps.w[j];
       }
-      *fo = cvt<T>(acc);
-      fo += plane;
+      buf_st<T>(cvt<T>(acc), rf, voff, (unsigned)z * pbytes);
       return true;
     };
     static_for_until<0, Z>(frow);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // rows complete in the order 0, Z-1, 1, Z-2, ...: two walking pointers instead of Z plane offsets in SGPRs
-  T* olo = out + p;
-  T* ohi = out + (size_t)(Z - 1) * plane + p;
-  unsigned long long redo = 0;   // outputs that need NI_Correlate1D's own sequence
-  if (cert < 0 || (int)sbits < 0) {
-    redo = Z == 64 ? ~0ull : (1ull << Z) - 1;
-  } else {
+
+  unsigned long long redo = 0;   // outputs that need NI_Correlate1D's own sequence (about one thread in 3e4 has one)
+  const bool all = cert < 0 || (int)sbits < 0;
+  if (all) redo = Z == 64 ? ~0ull : (1ull << Z) - 1;
+  if (!all) {
     // the weight stream is read in pieces of CH doubles (scalar loads), the next piece in flight while this one is
     // used; the scheduling barrier keeps the compiler from hoisting every load to the top (and spilling SGPRs)
     constexpr int N = fold_off<Z, R>((Z + 1) / 2), CH = 8, NC = (N + CH - 1) / CH;
@@ -312,12 +330,10 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
           }
           if constexpr (last) {
             if (uncertain<T>(a, cert)) redo |= 1ull << z;
-            *olo = cvt<T>(a);
-            olo += plane;
+            buf_st<T>(cvt<T>(a), rout, voff, (unsigned)z * pbytes);
             if constexpr (zz != z) {
               if (uncertain<T>(b, cert)) redo |= 1ull << zz;
-              *ohi = cvt<T>(b);
-              ohi -= plane;
+              buf_st<T>(cvt<T>(b), rout, voff, (unsigned)zz * pbytes);
             }
           }
         }
@@ -330,16 +346,19 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
     static_for_until<0, NC>(piece);
   }
   // NI_Correlate1D's own sequence, inputs re-read (a few outputs per 10^7 on non-negative data)
+  // NI_Correlate1D's own sequence, inputs re-read from memory, all 2R+1 loads of an output in flight together
   while (redo) {
     const int z = __builtin_ctzll(redo);
     redo &= redo - 1;
-    double acc = ld<T>(in, (size_t)z * plane + p) * taps.w[0];
-#pragma unroll 1
-    for (int j = R; j >= 1; --j) {
-      const double x0 = ld<T>(in, (size_t)border_idx(z - j, Z, mode) * plane + p);
-      const double x1 = ld<T>(in, (size_t)border_idx(z + j, Z, mode) * plane + p);
-      acc = acc + (x0 + x1) * taps.w[j];
+    T lo[R], hi[R];
+#pragma unroll
+    for (int j = 1; j <= R; ++j) {
+      lo[j - 1] = in[(size_t)border_idx(z - j, Z, mode) * plane + p];
+      hi[j - 1] = in[(size_t)border_idx(z + j, Z, mode) * plane + p];
     }
+    double acc = ld<T>(in, (size_t)z * plane + p) * taps.w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) acc = acc + ((double)lo[j - 1] + (double)hi[j - 1]) * taps.w[j];
     out[(size_t)z * plane + p] = cvt<T>(acc);
   }
 }
@@ -920,7 +939,7 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     ia3rt::ProfScope ps(nz.c_str());
     bool done = false;
     if constexpr (R >= 16) {
-      if (g_fold_on && cert >= 0) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel)
+      if (g_fold_on && cert >= 0 && (size_t)Z * plane * sizeof(T) < 0x7fffffffULL) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel; 32-bit buffer offsets)
         const int fc = g_cert == -2 ? 3 * R + Z + 16 : cert;
         int rc = -1;
         switch (Z) {
@@ -1060,7 +1079,7 @@ void dog_pair_tiles(int X, int Y, int* ty, int* ntile, size_t* count) {
 int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
                    void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax) {
   *forked = 0;
-  if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)X * Y > 0x7fffffffULL || Y < 8 || X < 4) return 1;
+  if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)Z * X * Y * (dtype == IA3_F32 ? 4 : 2) >= 0x7fffffffULL || Y < 8 || X < 4) return 1;
   for (int j = 1; j <= rf; ++j) if (wf[rf + j] != wf[rf - j]) return 1;
   for (int j = 1; j <= rb; ++j) if (wb[rb + j] != wb[rb - j]) return 1;
   Taps ft, bt;
