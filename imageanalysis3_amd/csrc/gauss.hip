@@ -243,6 +243,8 @@ template <int Z, int R> constexpr int fold_row(int i) {
 // it holds and writes it to fout — the DoG seed detector filters one stack with a short and a long kernel, and the
 // two first passes share every load (NI_Correlate1D's sequence, unfused: the short pass is not a certified path).
 // buffer-descriptor access: vector byte offset + scalar byte offset
+typedef unsigned bv4u __attribute__((ext_vector_type(4)));
+typedef unsigned bv2u __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ T buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ float buf_ld<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -675,17 +677,23 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
   if (tile < 0) return;   // whole block
   const int y0 = (tile % nty) * TY, EY = TY + 2 * R;
   const int xbeg = (tile / nty) * xseg, xend = xbeg + xseg < X ? xbeg + xseg : X;
-  const size_t pz = (size_t)blockIdx.z * X * Y;
-  const T* ip = in + pz;
-  T* op = out + pz;
-  const int gy = t < EY ? my[y0 + t] : 0;
+  // addressing: buffer descriptors with the row's byte offset as the scalar operand and a per-thread byte offset that is
+  // fixed for the whole walk (the host checks that the stack is below 2^31 bytes): no vector address arithmetic per access
+  const unsigned ES = (unsigned)sizeof(T);
+  const unsigned pzb = (unsigned)blockIdx.z * (unsigned)X * (unsigned)Y * ES, rowb = (unsigned)Y * ES;
+  const int nbytes = (int)((unsigned)gridDim.z * (unsigned)X * (unsigned)Y * ES);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, nbytes, 0x00020000);
+  const unsigned gyb = (t < EY ? (unsigned)my[y0 + t] : 0u) * ES;
   const int nr2 = TY / RUN2;                       // runs per row
   int rx[4], ry[4];
+  unsigned so[4];                                  // byte offset of a run's first output inside the step's first row
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int id = t + 256 * r;
     rx[r] = id < TXB * nr2 ? id / nr2 : -1;
     ry[r] = (id % nr2) * RUN2;
+    so[r] = ((unsigned)(rx[r] < 0 ? 0 : rx[r]) * (unsigned)Y + (unsigned)(y0 + ry[r])) * ES;
   }
   if (t < 4) smx[t] = 0u;   // (the first barrier of the loop orders this before the first atomic)
   const bool vec = (Y % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -695,9 +703,9 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
   T nxt[TXB];
   if (t < EY) {
 #pragma unroll
-    for (int j = 0; j < 2 * R; ++j) v[TXB + j] = (double)ip[(size_t)mx[xbeg + j] * Y + gy];
+    for (int j = 0; j < 2 * R; ++j) v[TXB + j] = (double)buf_ld<T>(rin, gyb, pzb + (unsigned)mx[xbeg + j] * rowb);
 #pragma unroll
-    for (int j = 0; j < TXB; ++j) nxt[j] = ip[(size_t)mx[xbeg + 2 * R + j] * Y + gy];
+    for (int j = 0; j < TXB; ++j) nxt[j] = buf_ld<T>(rin, gyb, pzb + (unsigned)mx[xbeg + 2 * R + j] * rowb);
   }
   for (int xs = xbeg; xs < xend; xs += TXB) {
     if (t < EY) {
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
       for (int j = 0; j < TXB; ++j) v[2 * R + j] = (double)nxt[j];
       if (xs + TXB < xend) {
 #pragma unroll
-        for (int j = 0; j < TXB; ++j) nxt[j] = ip[(size_t)mx[xs + TXB + 2 * R + j] * Y + gy];
+        for (int j = 0; j < TXB; ++j) nxt[j] = buf_ld<T>(rin, gyb, pzb + (unsigned)mx[xs + TXB + 2 * R + j] * rowb);
       }
 #pragma unroll
       for (int o = 0; o < TXB; ++o) {
@@ -736,13 +744,13 @@ __global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, 
           smax = fmaxf(smax, (float)res[o]);
         }
         const int y = y0 + ry[r];
-        T* po = op + (size_t)(xs + x) * Y + y;
+        const unsigned sb = pzb + (unsigned)xs * rowb;   // the step's first row (scalar)
         if (vec && y + RUN2 <= Y) {
-          if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(po) = *reinterpret_cast<const float4*>(res);
-          else *reinterpret_cast<uint2*>(po) = *reinterpret_cast<const uint2*>(res);
+          if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const bv4u*>(res), rout, so[r], sb, 0);
+          else __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const bv2u*>(res), rout, so[r], sb, 0);
         } else {
 #pragma unroll
-          for (int o = 0; o < RUN2; ++o) if (y + o < Y) po[o] = res[o];
+          for (int o = 0; o < RUN2; ++o) if (y + o < Y) buf_st<T>(res[o], rout, so[r] + (unsigned)o * ES, sb);
         }
       }
       if (tmax) {
