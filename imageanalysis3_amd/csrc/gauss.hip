@@ -664,7 +664,7 @@ __global__ __launch_bounds__(fused_threads<R>()) void gauss3_fused(const T* __re
 // writes TXB outputs to LDS; axis 2: runs of four outputs along y from 16-byte LDS pieces, stored as one 16-byte piece.
 // No z window, no halo planes: 60 registers, six blocks per CU.
 template <class T, int R>
-__global__ __launch_bounds__(256) void gauss_xy_short(const T* __restrict__ in, T* __restrict__ out, int X, int Y, Taps taps,
+__global__ __launch_bounds__(256, 5) void gauss_xy_short(const T* __restrict__ in, T* __restrict__ out, int X, int Y, Taps taps,
                                                      const int* __restrict__ mx, const int* __restrict__ my, int TY, int xseg,
                                                      float* __restrict__ tmax) {
   constexpr int TXB = 16, RUN2 = 4, PITCH = 264, NV = (RUN2 + 2 * R + 3) / 4 * 4;
