@@ -263,7 +263,8 @@ template <> __device__ __forceinline__ void buf_st<uint16_t>(uint16_t v, __amdgp
 template <class T, int Z, int R, int RF = 0>
 __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
                                                           const double* __restrict__ wf, Taps taps, int mode, int cert,
-                                                          T* __restrict__ fout, Taps ftaps) {
+                                                          T* __restrict__ fout, Taps ftaps,
+                                                          float* __restrict__ smin, float* __restrict__ sabs, int Y) {
   // addressing: buffer descriptors, this thread's 32-bit byte offset in the plane + the plane's byte offset as the
   // scalar operand (the host checks Z * plane * sizeof(T) < 2^31): no vector address arithmetic per access
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
@@ -272,6 +273,20 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
   const int nbytes = (int)((unsigned)Z * pbytes);
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, nbytes, 0x00020000);
+  // smin / sabs (optional; the seed detector's lazy background filter): smallest value and largest magnitude of this
+  // launch's long-filter output per group of planes (NGZ groups), row and 32-column strip — the block minima the
+  // detector's bound is made from, taken from the registers instead of a pass over the stored stack.  The folded value of
+  // an output that is recomputed below may differ from the stored one by a float32 ulp / one count: the bound's slack
+  // covers it (seed.hip).
+  constexpr int NGZ = ia3k::DOG_PAIR_ZGROUPS;
+  float gmin[NGZ], gabs[NGZ];   // of the quantised outputs (uint16: magnitudes are not needed, the slack is a constant)
+#pragma unroll
+  for (int g = 0; g < NGZ; ++g) { gmin[g] = INFINITY; gabs[g] = 0.f; }
+  auto note = [&](int g, T q) {
+    const float f = (float)q;
+    gmin[g] = fminf(gmin[g], f);
+    if constexpr (sizeof(T) == 4) gabs[g] = fmaxf(gabs[g], fabsf(f));
+  };
   double v[Z];
   unsigned sbits = 0;
 #pragma unroll
@@ -332,10 +347,14 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
           }
           if constexpr (last) {
             if (uncertain<T>(a, cert)) redo |= 1ull << z;
-            buf_st<T>(cvt<T>(a), rout, voff, (unsigned)z * pbytes);
+            const T qa = cvt<T>(a);
+            buf_st<T>(qa, rout, voff, (unsigned)z * pbytes);
+            if constexpr (RF > 0) note(z * NGZ / Z, qa);
             if constexpr (zz != z) {
               if (uncertain<T>(b, cert)) redo |= 1ull << zz;
-              buf_st<T>(cvt<T>(b), rout, voff, (unsigned)zz * pbytes);
+              const T qb = cvt<T>(b);
+              buf_st<T>(qb, rout, voff, (unsigned)zz * pbytes);
+              if constexpr (RF > 0) note(zz * NGZ / Z, qb);
             }
           }
         }
@@ -361,7 +380,36 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
     double acc = ld<T>(in, (size_t)z * plane + p) * taps.w[0];
 #pragma unroll
     for (int j = R; j >= 1; --j) acc = acc + ((double)lo[j - 1] + (double)hi[j - 1]) * taps.w[j];
-    out[(size_t)z * plane + p] = cvt<T>(acc);
+    const T qr = cvt<T>(acc);
+    out[(size_t)z * plane + p] = qr;
+    if constexpr (RF > 0) {
+      const int g = z * NGZ / Z;
+#pragma unroll
+      for (int k = 0; k < NGZ; ++k)
+        if (k == g) note(k, qr);
+    }
+  }
+  if (RF > 0 && smin) {   // Y % 32 == 0 (host): 32 consecutive lanes are 32 consecutive columns of one row
+    float fmn[NGZ], fab[NGZ];
+#pragma unroll
+    for (int g = 0; g < NGZ; ++g) {
+      fmn[g] = gmin[g];
+      fab[g] = gabs[g];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) {
+        fmn[g] = fminf(fmn[g], __shfl_xor(fmn[g], o));
+        fab[g] = fmaxf(fab[g], __shfl_xor(fab[g], o));
+      }
+    }
+    if ((threadIdx.x & 31) == 0) {
+      const unsigned x = p / (unsigned)Y, yb = (p % (unsigned)Y) >> 5;
+      const size_t rows = plane / (unsigned)Y, nby = (unsigned)Y >> 5;
+#pragma unroll
+      for (int g = 0; g < NGZ; ++g) {
+        smin[((size_t)g * rows + x) * nby + yb] = fmn[g];
+        sabs[((size_t)g * rows + x) * nby + yb] = fab[g];
+      }
+    }
   }
 }
 
@@ -819,7 +867,7 @@ int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipS
   const double* wf = folded_rows<Z, R>(t, mode, s);
   if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
   hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert,
-                     (T*)nullptr, t);
+                     (T*)nullptr, t, (float*)nullptr, (float*)nullptr, 0);
   return 0;
 }
 
@@ -844,17 +892,18 @@ const int* cached_border_map(int count, int R, int len, int mode) {
 
 // both first passes of the DoG pair in one launch (long: folded, -> dst; short: radius RF, reflect, -> fdst)
 template <class T, int Z, int R, int RF>
-int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Taps& ft, T* fdst, hipStream_t s, int cert) {
+int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Taps& ft, T* fdst, hipStream_t s, int cert,
+                    float* smin, float* sabs, int Y) {
   const double* wf = folded_rows<Z, R>(t, IA3_MODE_REFLECT, s);
   if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
   hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R, RF>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t,
-                     (int)IA3_MODE_REFLECT, cert, fdst, ft);
+                     (int)IA3_MODE_REFLECT, cert, fdst, ft, smin, sabs, Y);
   return 0;
 }
 
 template <class T>
 int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt, T* dst_front, T* dst_zp, T* tmp, hipStream_t s,
-               float* tmax) {
+               float* tmax, float* smin, float* sabs) {
   constexpr int RF = 3, RB = 30;
   const size_t plane = (size_t)X * Y;
   bool nonneg = true;
@@ -864,9 +913,9 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   {
     ia3rt::ProfScope ps("gauss_axis0_pair");
     switch (Z) {
-      case 30: rc = run_folded_pair<T, 30, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
-      case 40: rc = run_folded_pair<T, 40, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
-      case 50: rc = run_folded_pair<T, 50, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert); break;
+      case 30: rc = run_folded_pair<T, 30, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
+      case 40: rc = run_folded_pair<T, 40, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
+      case 50: rc = run_folded_pair<T, 50, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
       default: return 1;
     }
   }
@@ -1084,8 +1133,13 @@ void dog_pair_tiles(int X, int Y, int* ty, int* ntile, size_t* count) {
   if (count) *count = (size_t)((X + 15) / 16) * (size_t)ncol;
 }
 
+// strip minima of the column kernel: [DOG_PAIR_ZGROUPS][X][Y / 32] floats each (smallest value, largest magnitude of the
+// long filter's axis-0 result over a group of planes, one row and 32 columns); 0 when the kernel cannot produce them
+size_t dog_pair_strips(int X, int Y) { return Y % 32 == 0 ? (size_t)DOG_PAIR_ZGROUPS * X * (Y / 32) : 0; }
+
 int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
-                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax) {
+                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax, float* smin, float* sabs) {
+  if (Y % 32 != 0) smin = sabs = nullptr;   // strips are aligned groups of 32 lanes (callers check dog_pair_strips first)
   *forked = 0;
   if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)Z * X * Y * (dtype == IA3_F32 ? 4 : 2) >= 0x7fffffffULL || Y < 8 || X < 4) return 1;
   for (int j = 1; j <= rf; ++j) if (wf[rf + j] != wf[rf - j]) return 1;
@@ -1094,8 +1148,8 @@ int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double
   for (int j = 0; j < 64; ++j) { ft.w[j] = j <= rf ? wf[rf + j] : 0.0; bt.w[j] = j <= rb ? wb[rb + j] : 0.0; }
   hipStream_t s = ia3rt::stream();
   int rc;
-  if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s, tmax);
-  else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s, tmax);
+  if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s, tmax, smin, sabs);
+  else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s, tmax, smin, sabs);
   if (rc == 1) return 1;
   if (rc > 0) return rc;
   *forked = rc == 0;
@@ -1132,6 +1186,7 @@ int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_DFT_VALU) { ia3k::set_dft_valu(value); return 0; }
   if (key == IA3_TUNE_UPLOAD_THREADS) return ia3rt::set_upload_threads(value);
   if (key == IA3_TUNE_SEED_DENSE) { ia3k::set_seed_dense(value); return 0; }
+  if (key == IA3_TUNE_SEED_STRIPS) { ia3k::set_seed_strips(value); return 0; }
   if (key == IA3_TUNE_FIT_NBLIST) { ia3k::set_fit_nblist(value); return 0; }
   if (key == IA3_TUNE_FFT_C2C) { ia3k::set_fft_c2c(value); return 0; }
   if (key == IA3_TUNE_FIT_FUSE) { ia3k::set_fit_fuse(value); return 0; }

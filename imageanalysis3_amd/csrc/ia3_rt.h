@@ -80,7 +80,8 @@ void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& r
 }  // namespace ia3rt
 
 // ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
-namespace ia3k { void set_dft_valu(int on); void set_fft_c2c(int on); void set_seed_dense(int on); void set_fit_nblist(int cap); void set_fit_fuse(int on); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
+namespace ia3k { void set_dft_valu(int on); void set_fft_c2c(int on); void set_seed_dense(int on);
+void set_seed_strips(int on); void set_fit_nblist(int cap); void set_fit_fuse(int on); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
 namespace ia3k {
 // separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.  axes: bit 0 = the axis-0
 // pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst); radius <= 3 runs fused (axes == 3 only).
@@ -90,8 +91,13 @@ int gaussian3d(const void* src, int dtype, int Z, int X, int Y, const double* w,
 int highpass_combine(const void* im, const void* low, int dtype, size_t n, void* out);
 // DoG pair of the seed detector: short filter -> dst_front (complete), axis-0 pass of the long filter -> dst_zp (gauss.hip)
 // tmax (optional): per plane, 16-row step and y tile (dog_pair_tiles) the largest value of dst_front, for the detector
+// smin / sabs (optional, dog_pair_strips(X, Y) floats each, only when that is non-zero): smallest value / largest magnitude
+// of dst_zp per group of planes (group of plane z = z * DOG_PAIR_ZGROUPS / Z), row and 32-column strip
+constexpr int DOG_PAIR_ZGROUPS = 5;
+size_t dog_pair_strips(int X, int Y);
 int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double* wf, int rf, const double* wb, int rb,
-                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax = nullptr);
+                   void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax = nullptr, float* smin = nullptr,
+                   float* sabs = nullptr);
 void dog_pair_tiles(int X, int Y, int* ty, int* ntile, size_t* count);
 // get_seeds on a resident stack (seed.hip)
 struct SeedOut {

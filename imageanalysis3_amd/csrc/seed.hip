@@ -331,6 +331,31 @@ __global__ __launch_bounds__(256) void blockbound_k(const float* __restrict__ bm
   lb[i] = (double)m - 2e-6 * (double)a - (is_u16 ? 2.0 : 0.0);
 }
 
+// The same bound from the column kernel's strip minima (gauss.hip: smallest value / largest magnitude of the axis-0 result per
+// group of planes, row and 32-column strip, taken from registers — no pass over the stored stack): minimum over the rows of
+// the 3 x 3 block neighbourhood, one value per plane group, written for every plane of the group.  Coarser along z than the
+// per-plane block minima (the axis-0 result is smooth along z by construction); the extra uint16 count covers outputs the
+// column kernel recomputes after taking their minimum (they may differ from the stored value by one count / one ulp).
+__global__ __launch_bounds__(256) void stripbound_k(const float* __restrict__ smin, const float* __restrict__ sabs, int Z, int X,
+                                                    int nbx, int nby, int ngz, int is_u16, double* __restrict__ lb) {
+  // one wave per (plane group, block): its lanes share the <= 96 rows x 3 strips of the neighbourhood
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= (size_t)ngz * nbx * nby) return;   // whole wave
+  const int lane = threadIdx.x & 63;
+  const int by = (int)(i % nby), bx = (int)((i / nby) % nbx), g = (int)(i / ((size_t)nbx * nby));
+  const int x0 = max(32 * (bx - 1), 0), x1 = min(32 * (bx + 2), X), y0 = max(by - 1, 0), ny = min(by + 1, nby - 1) - y0 + 1;
+  float m = INFINITY, a = 0.f;
+  for (int e = lane; e < (x1 - x0) * ny; e += 64) {
+    const size_t o = ((size_t)g * X + x0 + e / ny) * nby + y0 + e % ny;
+    m = fminf(m, smin[o]); a = fmaxf(a, sabs[o]);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { m = fminf(m, __shfl_xor(m, o)); a = fmaxf(a, __shfl_xor(a, o)); }
+  const double v = (double)m - 2e-6 * (double)a - (is_u16 ? 3.0 : 0.0);
+  for (int z = lane; z < Z; z += 64)
+    if (z * ngz / Z == g) lb[((size_t)z * nbx + bx) * nby + by] = v;
+}
+
 // 3x3x3 local maxima of max_im that pass the edge test and the bound test -> Cand0 list.  Same tiling as
 // seed_detect3_tiled (16 x 64 tile + halo in LDS, double-buffered, rolling three-plane pipeline along z), one stack.
 template <class T, int ZC, int B>
@@ -718,6 +743,8 @@ static void finish_seeds(std::vector<Cand>& c, const Levels& lev, const ia3_seed
 
 static double now_ms() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
+int g_strip_bound = 1;   // IA3_TUNE_SEED_STRIPS: 0 = block minima from a pass over the axis-0 result even where the column kernel supplies strips
+void set_seed_strips(int on) { g_strip_bound = on ? 1 : 0; }
 int g_seed_dense = 0;   // IA3_TUNE_SEED_DENSE: 1 = always run the dense background filter (tests compare the two paths)
 void set_seed_dense(int on) { g_seed_dense = on ? 1 : 0; }
 
@@ -832,6 +859,11 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   dog_pair_tiles(X, Y, &sm_ty, &sm_ntile, &sm_count);
   Scratch smaxbuf(lazy ? sm_count * (size_t)Z * sizeof(float) : 256);   // step maxima of max_im (plane-wise filter -> detector)
   if (!smaxbuf.p) return IA3_ENOMEM;
+  const size_t n_strip = (lazy && Bk == 32) ? dog_pair_strips(X, Y) : 0;   // strip minima of the axis-0 result (column kernel -> bound)
+  Scratch stripbuf(n_strip ? 2 * n_strip * sizeof(float) : 256);
+  if (!stripbuf.p) return IA3_ENOMEM;
+  float* smin_d = n_strip ? stripbuf.as<float>() : nullptr;
+  float* sabs_d = n_strip ? smin_d + n_strip : nullptr;
   bool forked = false, paired = false;
   if (p.gfilt_size > 0) {
     if (p.w_front) { w.assign(p.w_front, p.w_front + 2 * p.r_front + 1); R = p.r_front; }
@@ -840,7 +872,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       // short stacks: both axis-0 passes from one launch (the column is loaded once), then the short filter's other two
       // axes on the auxiliary stream next to the block minima of the long filter's axis-0 result
       int fk = 0;
-      rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk, smaxbuf.as<float>());
+      rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk, smaxbuf.as<float>(), smin_d, sabs_d);
       if (rc == 0) { paired = true; forked = fk != 0; }
       else if (rc != 1) { if (fk) aux_join(); return rc; }
     }
@@ -856,7 +888,15 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   }
   if (paired) {
     minim = b.p;
-    if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+    if (n_strip && g_strip_bound) {   // the bound from the column kernel's strip minima: no pass over the axis-0 result
+      ProfScope ps("seed_blockmin");
+      const int nbx = (X + 31) / 32, nby = Y / 32;
+      const size_t nb = (size_t)Z * nbx * nby;
+      double* lb = (double*)((float*)bnd.p + 2 * nb + (nb & 1));   // as launch_lazy lays the block out
+      const size_t nt = (size_t)DOG_PAIR_ZGROUPS * nbx * nby;
+      hipLaunchKernelGGL(stripbound_k, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, (const float*)smin_d, (const float*)sabs_d, Z, X,
+                         nbx, nby, (int)DOG_PAIR_ZGROUPS, (int)(im->dtype == IA3_U16), lb);
+    } else if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
     else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
   } else if (p.background_gfilt_size > 0) {
     rc = gaussian3d(im->d, im->dtype, Z, X, Y, wb.data(), Rb, IA3_MODE_REFLECT, b.p, tmp.p, lazy ? 1 : 3);

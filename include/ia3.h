@@ -79,6 +79,11 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * planes holds the column in registers and folds the border into the weights (certified like the fused path, same
  * fallback); 0 = the sliding-window pass for every depth.  Results are identical bit for bit. */
 #define IA3_TUNE_GAUSS_FOLD 8
+/* IA3_TUNE_SEED_STRIPS: 1 (default) = where the column kernel of IA3_TUNE_GAUSS_FOLD runs for the seed detector and the
+ * row length is a multiple of 32, the lower bound of the lazy background filter is made from minima that kernel takes from
+ * its registers (per group of planes, row and 32 columns); 0 = from a pass over the stored axis-0 result (per plane).  Only
+ * the number of first-stage candidates can differ, never a seed. */
+#define IA3_TUNE_SEED_STRIPS 9
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

@@ -328,6 +328,20 @@ def test_lazy_background_filter_equals_dense_filter():
     zeros40 = np.zeros((40, 64, 130), np.float32)
     zeros40[6:9, 20:23, 100:103] = 800
     cases.append(("deep_zeros_f32", zeros40, dict(th_seed=100.0)))
+    # row lengths that are multiples of 32: the bound comes from the column kernel's strip minima (IA3_TUNE_SEED_STRIPS)
+    for shape, dt in (((50, 70, 256), np.float32), ((30, 100, 96), np.uint16), ((40, 33, 160), np.float32)):
+        im, c, h = synth.make_fov(shape, 14, 29, dtype=dt, margin=(2, 6, 6), layout="uniform")
+        cases.append(("strips%s" % (shape,), im, dict(th_seed=300.0)))
+    steps32 = (np.arange(50 * 96 * 192).reshape(50, 96, 192) // 517 % 7 * 500 + 300).astype(np.uint16)
+    steps32[20:23, 40:43, 150:153] += 2000
+    steps32[40:, :, :96] += 150                                     # a step along z inside a plane group
+    cases.append(("strips_plateaus_u16", steps32, dict(th_seed=200.0)))
+    mixed32 = rng.normal(0, 50, size=(50, 90, 224)).astype(np.float32)
+    mixed32[8:11, 30:33, 60:63] += 900
+    mixed32[30:33, 70:73, 190:193] += 700
+    mixed32[5, 70, 20] = -4000.0
+    mixed32[25:, 40:, :] += 120.0                                   # background differs between the planes of a group
+    cases.append(("strips_mixed_sign_f32", mixed32, dict(th_seed=150.0)))
     try:
         for name, im, kw in cases:
             _seed_dense(True)
@@ -340,11 +354,16 @@ def test_lazy_background_filter_equals_dense_filter():
                 lazy0 = get_seeds(im, return_h=True, **kw)
                 L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
                 assert dense.shape == lazy0.shape and np.array_equal(dense, lazy0), (name, "separate filters", dense.shape, lazy0.shape)
+                L.check(L.lib().ia3_set_tuning(C.c_int(9), C.c_int(0)))
+                lazy1 = get_seeds(im, return_h=True, **kw)
+                L.check(L.lib().ia3_set_tuning(C.c_int(9), C.c_int(1)))
+                assert dense.shape == lazy1.shape and np.array_equal(dense, lazy1), (name, "per-plane block minima", dense.shape, lazy1.shape)
             if not name.endswith("zeros_f32"):
                 assert len(dense) > 0, name
     finally:
         _seed_dense(False)
         L.check(L.lib().ia3_set_tuning(C.c_int(8), C.c_int(1)))
+        L.check(L.lib().ia3_set_tuning(C.c_int(9), C.c_int(1)))
 
 
 def test_phase_correlation_real_transforms_equal_complex_transforms():
