@@ -9,7 +9,7 @@ def short(name):
 
 
 SCOPE = {"gauss_axis0_folded<float, 50, 30, 3>": "gauss_axis0_pair", "gauss_xy_short<float, 3>": "gauss_xy_R3",
-         "blockmin_k<float, 32, 4>": "seed_blockmin", "seed_cand3_tiled<float, 64, 32>": "seed_detect",
+         "blockmin_k<float, 32, 4>": "seed_blockmin", "stripbound_k": "seed_blockmin", "seed_cand3_tiled<float, 64, 32>": "seed_detect",
          "bg_sparse_k<float>": "seed_sparse_bg", "fit_stages_k": "fit_first"}
 
 
@@ -19,7 +19,7 @@ def main(folder):
                       "fetch_x1024 / write_x1024 = counter x 1024 B.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes "
                       "of 16-B-per-lane streaming reads and WRITE_SIZE is exact for 16-B-per-lane stores (guide_read = 2 x fetch_x1024, "
                       "guide_write = write_x1024), other patterns to be calibrated on a known byte count.  Calibration on this pool: "
-                      "seed_blockmin reads exactly one stack (419.43 MB) once with 16-B loads and reports fetch_x1024 = 419.5 MB; the "
+                      "blockmin_k (profiles/r02d, the per-plane block minima that stripbound_k replaces on the bench shape) reads exactly one stack (419.43 MB) once with 16-B loads and reports fetch_x1024 = 419.5 MB; the "
                       "column kernel stores exactly two stacks (838.86 MB) and reports write_x1024 = 1677.7 MB, the plane-wise kernel "
                       "stores one stack with 16-B stores and reports 842 MB.  Calibrated: read = fetch_x1024, write = write_x1024 / 2" % folder,
            "_shape": [50, 2048, 2048], "_read_factor": 1.0, "_write_factor": 0.5}
