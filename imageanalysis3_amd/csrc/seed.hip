@@ -834,13 +834,13 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   Scratch bnd(lazy ? (nblk + (nblk & 1)) * 2 * sizeof(float) + nblk * sizeof(double) : 256);
   Scratch c0buf(lazy ? (size_t)LAZY_CAP * sizeof(Cand0) : 256);
   if (!bnd.p || !c0buf.p) return IA3_ENOMEM;
-  // candidate buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity] and the workspace of the device-side finish: cleared
-  // here, in front of the filters, so that no fill launch sits between the filters and the detector
+  // candidate buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity] and the workspace of the device-side finish; they are
+  // cleared on the main stream right behind the first filter launch (clear_buffers below), where the fills run under the
+  // other filter kernels: neither in front of the first kernel of the FOV nor between the filters and the detector
   unsigned capacity = 1u << 20;
   constexpr size_t HDR = 2 * sizeof(SeedCtl);
   Scratch buf0(HDR + (size_t)capacity * sizeof(Cand));
   if (!buf0.p) return IA3_ENOMEM;
-  IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, s));
   const bool dev_finish = dev && Z <= 256 && X <= 4096 && Y <= 4096;
   const size_t o_hot = sizeof(FinCtl), o_rank = o_hot + 4 * (size_t)FIN_CAP, o_zxy = o_rank + 4 * (size_t)FIN_CAP,
                o_h = o_zxy + 24 * (size_t)FIN_CAP, fin_bytes = o_h + 8 * (size_t)FIN_CAP;
@@ -848,10 +848,16 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   if (dev_finish) {
     fin = ws_get(fin_bytes);
     if (!fin) return IA3_ENOMEM;
-    hipError_t fe = hipMemsetAsync(fin, 0, o_zxy, s);
-    if (fe != hipSuccess) { ws_put(fin); return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(fe)); }
   }
   struct FinGuard { void*& p; ~FinGuard() { if (p) ws_put(p); } } fin_guard{fin};   // handed to the caller on success (fin = nullptr)
+  bool cleared = false;
+  auto clear_buffers = [&]() -> int {
+    if (cleared) return IA3_OK;
+    cleared = true;
+    IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, s));
+    if (fin) IA3_HIP(hipMemsetAsync(fin, 0, o_zxy, s));
+    return IA3_OK;
+  };
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
   // background (long, f64-VALU-bound) one; the detector waits for both.
   int sm_ty = 0, sm_ntile = 0;
@@ -875,6 +881,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk, smaxbuf.as<float>(), smin_d, sabs_d);
       if (rc == 0) { paired = true; forked = fk != 0; }
       else if (rc != 1) { if (fk) aux_join(); return rc; }
+      if (paired) { rc = clear_buffers(); if (rc) { if (forked) aux_join(); return rc; } }
     }
     if (!paired) {
       {
@@ -907,6 +914,8 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
     }
   }
+  rc = clear_buffers();
+  if (rc) { if (forked) aux_join(); return rc; }
   if (forked) { rc = aux_join(); if (rc) return rc; }
   const double t1 = now_ms();
   // device buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity]; the header and the first FIRST candidates come back
