@@ -231,17 +231,25 @@ template <int Z, int R> constexpr int fold_off(int z) {
   for (int i = 0; i < z; ++i) o += fold_hi<Z, R>(i) - fold_lo<Z, R>(i) + 1;
   return o;
 }
+// flat position i of the packed weight stream -> its row, and the row offsets, as tables built once per (Z, R) (the
+// kernel asks for them at every one of its ~Z^2 / 2 compile-time positions)
+template <int Z, int R> struct FoldTab {
+  static constexpr int H = (Z + 1) / 2, N = fold_off<Z, R>((Z + 1) / 2);
+  int off[H + 1];
+  int row[N];
+  constexpr FoldTab() : off(), row() {
+    int o = 0;
+    for (int z = 0; z < H; ++z) {
+      off[z] = o;
+      const int n = fold_hi<Z, R>(z) - fold_lo<Z, R>(z) + 1;
+      for (int k = 0; k < n; ++k) row[o + k] = z;
+      o += n;
+    }
+    off[H] = o;
+  }
+};
+template <int Z, int R> inline constexpr FoldTab<Z, R> fold_tab{};
 
-// flat position i of the packed weight stream -> its row
-template <int Z, int R> constexpr int fold_row(int i) {
-  int z = 0;
-  while (i >= fold_off<Z, R>(z + 1)) ++z;
-  return z;
-}
-
-// RF > 0: the same launch also runs the axis-0 pass of a SHORT filter (radius RF, 'reflect' border) over the column
-// it holds and writes it to fout — the DoG seed detector filters one stack with a short and a long kernel, and the
-// two first passes share every load (NI_Correlate1D's sequence, unfused: the short pass is not a certified path).
 // buffer-descriptor access: vector byte offset + scalar byte offset
 typedef unsigned bv4u __attribute__((ext_vector_type(4)));
 typedef unsigned bv2u __attribute__((ext_vector_type(2)));
@@ -260,7 +268,7 @@ template <> __device__ __forceinline__ void buf_st<uint16_t>(uint16_t v, __amdgp
   __builtin_amdgcn_raw_buffer_store_b16((short)v, r, voff, soff, 0);
 }
 
-template <class T, int Z, int R, int RF = 0>
+template <class T, int Z, int R, int RF>
 __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
                                                           const double* __restrict__ wf, Taps taps, int mode, int cert,
                                                           T* __restrict__ fout, Taps ftaps,
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
   if (!all) {
     // the weight stream is read in pieces of CH doubles (scalar loads), the next piece in flight while this one is
     // used; the scheduling barrier keeps the compiler from hoisting every load to the top (and spilling SGPRs)
-    constexpr int N = fold_off<Z, R>((Z + 1) / 2), CH = 8, NC = (N + CH - 1) / CH;
+    constexpr int N = FoldTab<Z, R>::N, CH = 8, NC = (N + CH - 1) / CH;
     double a = 0.0, b = 0.0;
     double cur[CH], nxt[CH];
 #pragma unroll
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ 
       auto tap = [&](auto ic) -> bool {
         constexpr int i = c * CH + decltype(ic)::value;
         if constexpr (i < N) {
-          constexpr int z = fold_row<Z, R>(i), zz = Z - 1 - z, lo = fold_lo<Z, R>(z), k = i - fold_off<Z, R>(z);
-          constexpr bool last = i + 1 == fold_off<Z, R>(z + 1);
+          constexpr int z = fold_tab<Z, R>.row[i], zz = Z - 1 - z, lo = fold_lo<Z, R>(z), k = i - fold_tab<Z, R>.off[z];
+          constexpr bool last = i + 1 == fold_tab<Z, R>.off[z + 1];
           const double w = cur[i - c * CH];
           if constexpr (k == 0) {
             a = v[lo] * w;
@@ -862,11 +870,23 @@ const double* folded_rows(const Taps& t, int mode, hipStream_t s) {
   return e.d;
 }
 
+// stack depths the column kernel is instantiated for (the column lives in registers: one kernel per depth, dtype and
+// variant, ~12 s of compile time each — extend the list for other production depths up to ~60 planes)
+#define IA3_FOLD_DEPTHS(X) X(30) X(40) X(50)
+inline bool fold_depth(int Z) {
+  switch (Z) {
+#define IA3_FOLD_CASE(ZZ) case ZZ: return true;
+    IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
+#undef IA3_FOLD_CASE
+    default: return false;
+  }
+}
+
 template <class T, int Z, int R>
 int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipStream_t s, int cert) {
   const double* wf = folded_rows<Z, R>(t, mode, s);
   if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
-  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert,
+  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R, 0>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert,
                      (T*)nullptr, t, (float*)nullptr, (float*)nullptr, 0);
   return 0;
 }
@@ -913,9 +933,9 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   {
     ia3rt::ProfScope ps("gauss_axis0_pair");
     switch (Z) {
-      case 30: rc = run_folded_pair<T, 30, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
-      case 40: rc = run_folded_pair<T, 40, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
-      case 50: rc = run_folded_pair<T, 50, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
+#define IA3_FOLD_CASE(ZZ) case ZZ: rc = run_folded_pair<T, ZZ, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
+      IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
+#undef IA3_FOLD_CASE
       default: return 1;
     }
   }
@@ -999,10 +1019,10 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
       if (g_fold_on && cert >= 0 && (size_t)Z * plane * sizeof(T) < 0x7fffffffULL) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel; 32-bit buffer offsets)
         const int fc = g_cert == -2 ? 3 * R + Z + 16 : cert;
         int rc = -1;
-        switch (Z) {
-          case 30: rc = run_folded<T, 30, R>(src, plane, t, mode, dst, s, fc); break;
-          case 40: rc = run_folded<T, 40, R>(src, plane, t, mode, dst, s, fc); break;
-          case 50: rc = run_folded<T, 50, R>(src, plane, t, mode, dst, s, fc); break;
+        switch (Z) {   // the depths instantiated (IA3_FOLD_DEPTHS); other stacks take the sliding window
+#define IA3_FOLD_CASE(ZZ) case ZZ: rc = run_folded<T, ZZ, R>(src, plane, t, mode, dst, s, fc); break;
+          IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
+#undef IA3_FOLD_CASE
           default: break;
         }
         if (rc > 0) return rc;
@@ -1141,7 +1161,7 @@ int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double
                    void* dst_front, void* dst_zp, void* tmp, int* forked, float* tmax, float* smin, float* sabs) {
   if (Y % 32 != 0) smin = sabs = nullptr;   // strips are aligned groups of 32 lanes (callers check dog_pair_strips first)
   *forked = 0;
-  if (!g_fold_on || rf != 3 || rb != 30 || (Z != 30 && Z != 40 && Z != 50) || (size_t)Z * X * Y * (dtype == IA3_F32 ? 4 : 2) >= 0x7fffffffULL || Y < 8 || X < 4) return 1;
+  if (!g_fold_on || rf != 3 || rb != 30 || !fold_depth(Z) || (size_t)Z * X * Y * (dtype == IA3_F32 ? 4 : 2) >= 0x7fffffffULL || Y < 8 || X < 4) return 1;
   for (int j = 1; j <= rf; ++j) if (wf[rf + j] != wf[rf - j]) return 1;
   for (int j = 1; j <= rb; ++j) if (wb[rb + j] != wb[rb - j]) return 1;
   Taps ft, bt;

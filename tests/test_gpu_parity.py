@@ -911,7 +911,7 @@ def test_dog_filter_pair_shared_axis0_launch_bit_exact():
     lib = L.lib()
     rng = np.random.RandomState(13)
     try:
-        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120)):
+        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120), (45, 20, 96)):
             shape = (Z, X, Y)
             pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
             pos[:, :20, :20] = 0
