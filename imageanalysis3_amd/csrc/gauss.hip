@@ -18,64 +18,13 @@
 //     LDS so that every lane slides the same register window along its own row while global access stays
 //     row-coalesced.  Long filters (VALU-bound, R >= 16): the axis-1 pass stores each plane transposed and the
 //     axis-2 pass is the strided kernel over that transposed plane, storing transposed again.
-#include "ia3_rt.h"
-#include <type_traits>
+#include "ia3_gauss.h"
 #include <cstring>
 #include <mutex>
 
+using namespace ia3g;
+
 namespace {
-
-__host__ __device__ __forceinline__ int border_idx(int q, int n, int mode) {
-  if (mode == IA3_MODE_NEAREST) return q < 0 ? 0 : (q >= n ? n - 1 : q);
-  if (q >= 0 && q < n) return q;
-  int p = 2 * n;
-  q %= p;
-  if (q < 0) q += p;
-  return q < n ? q : p - 1 - q;
-}
-
-template <class T> __device__ __forceinline__ double ld(const T* p, size_t i);
-template <> __device__ __forceinline__ double ld<float>(const float* p, size_t i) { return (double)p[i]; }
-template <> __device__ __forceinline__ double ld<uint16_t>(const uint16_t* p, size_t i) { return (double)p[i]; }
-template <class T> __device__ __forceinline__ T cvt(double v);
-template <> __device__ __forceinline__ float cvt<float>(double v) { return (float)v; }
-template <> __device__ __forceinline__ uint16_t cvt<uint16_t>(double v) { return (uint16_t)(int)v; }
-
-struct Taps { double w[64]; };
-
-// ---- certified fast path of the long (VALU-bound) passes ------------------------------------------------------
-// The contract fixes the f32 / u16 value of every output, not the f64 bits behind it.  For non-negative inputs the
-// same sum with each (multiply, add) pair fused differs from NI_Correlate1D's by at most (2R+1) f64 ulps (all
-// partial sums are non-negative and bounded by the result), so the quantised value can only differ when the fused
-// sum lies within that distance of a quantisation boundary: a float32 rounding midpoint (low 29 mantissa bits
-// 0x10000000) or, for uint16 truncation, an integer.  Such outputs (a few per 10^7), sums outside the normal float32
-// range and threads that have seen a sign bit are recomputed with the unfused sequence; everything else takes
-// two VALU instructions per tap pair instead of three.  `cert` = the guard distance in f64 ulps (4R+8 by default).
-template <class T> __device__ __forceinline__ bool uncertain(double s, int cert);
-template <> __device__ __forceinline__ bool uncertain<float>(double s, int cert) {
-  const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
-  // |(lo & 0x1FFFFFFF) - 0x10000000| <= cert as one unsigned range test (cert < 2^28 + ..., see cert_for and the tests' 1 << 28)
-  const unsigned c = (unsigned)cert < 0x10000000u ? (unsigned)cert : 0x10000000u;
-  const bool near_mid = ((lo & 0x1FFFFFFFu) - (0x10000000u - c)) <= 2u * c;
-  // exponent outside [2^-100, inf): zero is exact on both paths, anything else (tiny, inf, nan) is recomputed
-  const bool odd_exp = (hi - 0x39B00000u) >= (0x7FF00000u - 0x39B00000u) && (hi | lo) != 0u;
-  return near_mid || odd_exp;
-}
-template <> __device__ __forceinline__ bool uncertain<uint16_t>(double s, int cert) {
-  // |s - nearest integer| <= cert ulps of s (ulp(s) <= s * 2^-52); s == 0 is exact on both paths
-  return s != 0.0 && fabs(s - rint(s)) <= s * ((double)cert * 2.220446049250313e-16);
-}
-template <class T> __device__ __forceinline__ unsigned sign_of(T v);
-template <> __device__ __forceinline__ unsigned sign_of<float>(float v) { return __float_as_uint(v); }
-template <> __device__ __forceinline__ unsigned sign_of<uint16_t>(uint16_t) { return 0u; }
-
-// f(integral_constant<0>), f(<1>), ... while f returns true
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for_until(F& f) {
-  if constexpr (I < N) {
-    if (f(std::integral_constant<int, I>{})) static_for_until<I + 1, N>(f);
-  }
-}
 
 // bmap[i] = border-mapped source index of position (i - R), i in [0, count); positions past the
 // end of the last chunk are only ever loaded, never stored, and map to valid indices as well.
@@ -210,214 +159,6 @@ __global__ __launch_bounds__(256) void gauss_strided(const T* __restrict__ in, T
       return true;
     };
     static_for_until<0, U>(chunk);
-  }
-}
-
-// ---- axis 0 of a long filter on a short stack: the whole column in registers, border folded into the weights ----
-// With Z <= 64 planes and R = 30 most taps of an output land on the reflected (or clamped) border, i.e. on a plane
-// the sum already holds: out[z] = sum_p W[z][p] * in[p] with W[z][p] = the taps that map to plane p added up
-// (host, f64), p in [max(0, z-R), min(Z-1, z+R)].  That is 31..Z fused multiply-adds per output instead of R pair
-// additions + R+1 multiply-adds (Z = 50: 42 on average against 66 with the 6-wide chunks), every input is read
-// once, and the rows of z and Z-1-z share their weights (W[Z-1-z][Z-1-p] = W[z][p]).  The order of operations is
-// not NI_Correlate1D's, so this is a certified path like the fused one above: for non-negative data and taps both
-// sums are within (3R+1) resp. (Z+2) * 2^-53 * S of the exact sum S, so the float32 / uint16 value can only differ
-// when the folded sum lies within 3R+Z+3 f64 ulps of a quantisation boundary.  Those outputs, and every output of
-// a thread that saw a sign bit, are recomputed with the reference sequence from global memory.  wf = the folded
-// rows 0 .. (Z-1)/2 packed one after the other (uniform, compile-time offsets -> scalar loads).
-template <int Z, int R> constexpr int fold_lo(int z) { return z - R > 0 ? z - R : 0; }
-template <int Z, int R> constexpr int fold_hi(int z) { return z + R < Z - 1 ? z + R : Z - 1; }
-template <int Z, int R> constexpr int fold_off(int z) {
-  int o = 0;
-  for (int i = 0; i < z; ++i) o += fold_hi<Z, R>(i) - fold_lo<Z, R>(i) + 1;
-  return o;
-}
-// flat position i of the packed weight stream -> its row, and the row offsets, as tables built once per (Z, R) (the
-// kernel asks for them at every one of its ~Z^2 / 2 compile-time positions)
-template <int Z, int R> struct FoldTab {
-  static constexpr int H = (Z + 1) / 2, N = fold_off<Z, R>((Z + 1) / 2);
-  int off[H + 1];
-  int row[N];
-  constexpr FoldTab() : off(), row() {
-    int o = 0;
-    for (int z = 0; z < H; ++z) {
-      off[z] = o;
-      const int n = fold_hi<Z, R>(z) - fold_lo<Z, R>(z) + 1;
-      for (int k = 0; k < n; ++k) row[o + k] = z;
-      o += n;
-    }
-    off[H] = o;
-  }
-};
-template <int Z, int R> inline constexpr FoldTab<Z, R> fold_tab{};
-
-// buffer-descriptor access: vector byte offset + scalar byte offset
-typedef unsigned bv4u __attribute__((ext_vector_type(4)));
-typedef unsigned bv2u __attribute__((ext_vector_type(2)));
-template <class T> __device__ __forceinline__ T buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
-template <> __device__ __forceinline__ float buf_ld<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-template <> __device__ __forceinline__ uint16_t buf_ld<uint16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
-}
-template <class T> __device__ __forceinline__ void buf_st(T v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
-template <> __device__ __forceinline__ void buf_st<float>(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
-}
-template <> __device__ __forceinline__ void buf_st<uint16_t>(uint16_t v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b16((short)v, r, voff, soff, 0);
-}
-
-template <class T, int Z, int R, int RF>
-__global__ __launch_bounds__(256) void gauss_axis0_folded(const T* __restrict__ in, T* __restrict__ out, size_t plane,
-                                                          const double* __restrict__ wf, Taps taps, int mode, int cert,
-                                                          T* __restrict__ fout, Taps ftaps,
-                                                          float* __restrict__ smin, float* __restrict__ sabs, int Y) {
-  // addressing: buffer descriptors, this thread's 32-bit byte offset in the plane + the plane's byte offset as the
-  // scalar operand (the host checks Z * plane * sizeof(T) < 2^31): no vector address arithmetic per access
-  const unsigned p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= plane) return;
-  const unsigned voff = p * (unsigned)sizeof(T), pbytes = (unsigned)plane * (unsigned)sizeof(T);
-  const int nbytes = (int)((unsigned)Z * pbytes);
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, nbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, nbytes, 0x00020000);
-  // smin / sabs (optional; the seed detector's lazy background filter): smallest value and largest magnitude of this
-  // launch's long-filter output per group of planes (NGZ groups), row and 32-column strip — the block minima the
-  // detector's bound is made from, taken from the registers instead of a pass over the stored stack.  The folded value of
-  // an output that is recomputed below may differ from the stored one by a float32 ulp / one count: the bound's slack
-  // covers it (seed.hip).
-  constexpr int NGZ = ia3k::DOG_PAIR_ZGROUPS;
-  float gmin[NGZ], gabs[NGZ];   // of the quantised outputs (uint16: magnitudes are not needed, the slack is a constant)
-#pragma unroll
-  for (int g = 0; g < NGZ; ++g) { gmin[g] = INFINITY; gabs[g] = 0.f; }
-  auto note = [&](int g, T q) {
-    const float f = (float)q;
-    gmin[g] = fminf(gmin[g], f);
-    if constexpr (sizeof(T) == 4) gabs[g] = fmaxf(gabs[g], fabsf(f));
-  };
-  double v[Z];
-  unsigned sbits = 0;
-#pragma unroll
-  for (int z = 0; z < Z; ++z) {
-    const T t = buf_ld<T>(rin, voff, (unsigned)z * pbytes);
-    sbits |= sign_of<T>(t);
-    v[z] = (double)t;
-  }
-  if constexpr (RF > 0) {
-    static_assert(Z > RF, "single reflection");
-    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)fout, (short)0, nbytes, 0x00020000);
-    auto frow = [&](auto zc) -> bool {
-      constexpr int z = decltype(zc)::value;
-      double acc = v[z] * ftaps.w[0];
-#pragma unroll
-      for (int j = RF; j >= 1; --j) {
-        const int lo = z - j < 0 ? -(z - j) - 1 : z - j, hi = z + j >= Z ? 2 * Z - 1 - (z + j) : z + j;   // compile-time
-        acc = acc + (v[lo] + v[hi]) * ftaps.w[j];
-      }
-      buf_st<T>(cvt<T>(acc), rf, voff, (unsigned)z * pbytes);
-      return true;
-    };
-    static_for_until<0, Z>(frow);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  unsigned long long redo = 0;   // outputs that need NI_Correlate1D's own sequence (about one thread in 3e4 has one)
-  const bool all = cert < 0 || (int)sbits < 0;
-  if (all) redo = Z == 64 ? ~0ull : (1ull << Z) - 1;
-  if (!all) {
-    // the weight stream is read in pieces of CH doubles (scalar loads), the next piece in flight while this one is
-    // used; the scheduling barrier keeps the compiler from hoisting every load to the top (and spilling SGPRs)
-    constexpr int N = FoldTab<Z, R>::N, CH = 8, NC = (N + CH - 1) / CH;
-    double a = 0.0, b = 0.0;
-    double cur[CH], nxt[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) nxt[i] = wf[i];   // the table is padded to a multiple of CH
-    auto piece = [&](auto cc) -> bool {
-      constexpr int c = decltype(cc)::value;
-#pragma unroll
-      for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
-      if constexpr (c + 1 < NC) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) nxt[i] = wf[(c + 1) * CH + i];
-      }
-      auto tap = [&](auto ic) -> bool {
-        constexpr int i = c * CH + decltype(ic)::value;
-        if constexpr (i < N) {
-          constexpr int z = fold_tab<Z, R>.row[i], zz = Z - 1 - z, lo = fold_lo<Z, R>(z), k = i - fold_tab<Z, R>.off[z];
-          constexpr bool last = i + 1 == fold_tab<Z, R>.off[z + 1];
-          const double w = cur[i - c * CH];
-          if constexpr (k == 0) {
-            a = v[lo] * w;
-            if constexpr (zz != z) b = v[Z - 1 - lo] * w;
-          } else {
-            a = __builtin_fma(v[lo + k], w, a);
-            if constexpr (zz != z) b = __builtin_fma(v[Z - 1 - lo - k], w, b);
-          }
-          if constexpr (last) {
-            if (uncertain<T>(a, cert)) redo |= 1ull << z;
-            const T qa = cvt<T>(a);
-            buf_st<T>(qa, rout, voff, (unsigned)z * pbytes);
-            if constexpr (RF > 0) note(z * NGZ / Z, qa);
-            if constexpr (zz != z) {
-              if (uncertain<T>(b, cert)) redo |= 1ull << zz;
-              const T qb = cvt<T>(b);
-              buf_st<T>(qb, rout, voff, (unsigned)zz * pbytes);
-              if constexpr (RF > 0) note(zz * NGZ / Z, qb);
-            }
-          }
-        }
-        return true;
-      };
-      static_for_until<0, CH>(tap);
-      __builtin_amdgcn_sched_barrier(0);
-      return true;
-    };
-    static_for_until<0, NC>(piece);
-  }
-  // NI_Correlate1D's own sequence, inputs re-read (a few outputs per 10^7 on non-negative data)
-  // NI_Correlate1D's own sequence, inputs re-read from memory, all 2R+1 loads of an output in flight together
-  while (redo) {
-    const int z = __builtin_ctzll(redo);
-    redo &= redo - 1;
-    T lo[R], hi[R];
-#pragma unroll
-    for (int j = 1; j <= R; ++j) {
-      lo[j - 1] = in[(size_t)border_idx(z - j, Z, mode) * plane + p];
-      hi[j - 1] = in[(size_t)border_idx(z + j, Z, mode) * plane + p];
-    }
-    double acc = ld<T>(in, (size_t)z * plane + p) * taps.w[0];
-#pragma unroll
-    for (int j = R; j >= 1; --j) acc = acc + ((double)lo[j - 1] + (double)hi[j - 1]) * taps.w[j];
-    const T qr = cvt<T>(acc);
-    out[(size_t)z * plane + p] = qr;
-    if constexpr (RF > 0) {
-      const int g = z * NGZ / Z;
-#pragma unroll
-      for (int k = 0; k < NGZ; ++k)
-        if (k == g) note(k, qr);
-    }
-  }
-  if (RF > 0 && smin) {   // Y % 32 == 0 (host): 32 consecutive lanes are 32 consecutive columns of one row
-    float fmn[NGZ], fab[NGZ];
-#pragma unroll
-    for (int g = 0; g < NGZ; ++g) {
-      fmn[g] = gmin[g];
-      fab[g] = gabs[g];
-#pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) {
-        fmn[g] = fminf(fmn[g], __shfl_xor(fmn[g], o));
-        fab[g] = fmaxf(fab[g], __shfl_xor(fab[g], o));
-      }
-    }
-    if ((threadIdx.x & 31) == 0) {
-      const unsigned x = p / (unsigned)Y, yb = (p % (unsigned)Y) >> 5;
-      const size_t rows = plane / (unsigned)Y, nby = (unsigned)Y >> 5;
-#pragma unroll
-      for (int g = 0; g < NGZ; ++g) {
-        smin[((size_t)g * rows + x) * nby + yb] = fmn[g];
-        sabs[((size_t)g * rows + x) * nby + yb] = fab[g];
-      }
-    }
   }
 }
 
@@ -836,60 +577,7 @@ __global__ __launch_bounds__(256, 5) void gauss_xy_short(const T* __restrict__ i
 int g_cert = -2;   // -2: default guard (4R+8 ulps), -1: fused path off, >= 0: guard distance in ulps (tests)
 inline int cert_for(int R) { return g_cert == -2 ? 4 * R + 8 : g_cert; }
 
-// folded weight rows of gauss_axis0_folded, cached on the device per (Z, R, mode, taps)
-struct FoldKey { int Z, R, mode; std::vector<double> w; };
-struct FoldEntry { FoldKey k; double* d = nullptr; };
-std::mutex g_fold_mu;
-std::vector<FoldEntry> g_fold;
 int g_fold_on = 1;
-
-template <int Z, int R>
-const double* folded_rows(const Taps& t, int mode, hipStream_t s) {
-  std::lock_guard<std::mutex> g(g_fold_mu);
-  for (auto& e : g_fold)
-    if (e.k.Z == Z && e.k.R == R && e.k.mode == mode && std::memcmp(e.k.w.data(), t.w, (R + 1) * sizeof(double)) == 0) return e.d;
-  std::vector<double> rows;
-  for (int z = 0; z < (Z + 1) / 2; ++z) {
-    const int lo = fold_lo<Z, R>(z), hi = fold_hi<Z, R>(z);
-    for (int p = lo; p <= hi; ++p) {
-      double acc = 0.0;
-      for (int j = -R; j <= R; ++j)
-        if (border_idx(z + j, Z, mode) == p) acc += t.w[j < 0 ? -j : j];
-      rows.push_back(acc);
-    }
-  }
-  rows.resize((rows.size() + 15) / 16 * 16, 0.0);
-  FoldEntry e;
-  e.k = FoldKey{Z, R, mode, std::vector<double>(t.w, t.w + R + 1)};
-  if (hipMalloc((void**)&e.d, rows.size() * sizeof(double)) != hipSuccess) return nullptr;
-  // a blocking copy, once per filter: the table must be in place before any stream uses the cached pointer
-  if (hipMemcpy(e.d, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.d); return nullptr; }
-  (void)s;
-  if (g_fold.size() >= 16) { g_fold.erase(g_fold.begin()); }   // the evicted table stays allocated: launches may be in flight
-  g_fold.push_back(e);
-  return e.d;
-}
-
-// stack depths the column kernel is instantiated for (the column lives in registers: one kernel per depth, dtype and
-// variant, ~12 s of compile time each — extend the list for other production depths up to ~60 planes)
-#define IA3_FOLD_DEPTHS(X) X(30) X(40) X(50)
-inline bool fold_depth(int Z) {
-  switch (Z) {
-#define IA3_FOLD_CASE(ZZ) case ZZ: return true;
-    IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
-#undef IA3_FOLD_CASE
-    default: return false;
-  }
-}
-
-template <class T, int Z, int R>
-int run_folded(const T* src, size_t plane, const Taps& t, int mode, T* dst, hipStream_t s, int cert) {
-  const double* wf = folded_rows<Z, R>(t, mode, s);
-  if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
-  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R, 0>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t, mode, cert,
-                     (T*)nullptr, t, (float*)nullptr, (float*)nullptr, 0);
-  return 0;
-}
 
 // border map (position i - R -> source index) kept on the device per (count, R, len, mode): the plane-wise kernel is
 // launched right behind the column kernel, a map-building launch in between would sit on the critical path
@@ -910,17 +598,6 @@ const int* cached_border_map(int count, int R, int len, int mode) {
   return d;
 }
 
-// both first passes of the DoG pair in one launch (long: folded, -> dst; short: radius RF, reflect, -> fdst)
-template <class T, int Z, int R, int RF>
-int run_folded_pair(const T* src, size_t plane, const Taps& t, T* dst, const Taps& ft, T* fdst, hipStream_t s, int cert,
-                    float* smin, float* sabs, int Y) {
-  const double* wf = folded_rows<Z, R>(t, IA3_MODE_REFLECT, s);
-  if (!wf) return ia3rt::set_error(IA3_ENOMEM, "folded weight table");
-  hipLaunchKernelGGL((gauss_axis0_folded<T, Z, R, RF>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, wf, t,
-                     (int)IA3_MODE_REFLECT, cert, fdst, ft, smin, sabs, Y);
-  return 0;
-}
-
 template <class T>
 int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt, T* dst_front, T* dst_zp, T* tmp, hipStream_t s,
                float* tmax, float* smin, float* sabs) {
@@ -932,12 +609,10 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   int rc;
   {
     ia3rt::ProfScope ps("gauss_axis0_pair");
-    switch (Z) {
-#define IA3_FOLD_CASE(ZZ) case ZZ: rc = run_folded_pair<T, ZZ, RB, RF>(src, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y); break;
-      IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
-#undef IA3_FOLD_CASE
-      default: return 1;
-    }
+    static_assert(RF == 3 && RB == 30, "the radii gauss_col.inc instantiates");
+    if constexpr (std::is_same_v<T, float>) rc = folded_pair_f32(src, Z, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y);
+    else rc = folded_pair_u16(src, Z, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y);
+    if (rc == -1) return 1;
   }
   if (rc) return rc;
   // axes 1 and 2 of the short filter: tmp -> dst_front, on the auxiliary stream (the caller goes on with dst_zp)
@@ -1019,11 +694,9 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
       if (g_fold_on && cert >= 0 && (size_t)Z * plane * sizeof(T) < 0x7fffffffULL) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel; 32-bit buffer offsets)
         const int fc = g_cert == -2 ? 3 * R + Z + 16 : cert;
         int rc = -1;
-        switch (Z) {   // the depths instantiated (IA3_FOLD_DEPTHS); other stacks take the sliding window
-#define IA3_FOLD_CASE(ZZ) case ZZ: rc = run_folded<T, ZZ, R>(src, plane, t, mode, dst, s, fc); break;
-          IA3_FOLD_DEPTHS(IA3_FOLD_CASE)
-#undef IA3_FOLD_CASE
-          default: break;
+        if constexpr (R == 30) {   // the depths instantiated (IA3_FOLD_DEPTHS, radius 30); other stacks take the sliding window
+          if constexpr (std::is_same_v<T, float>) rc = folded_axis0_f32(src, Z, plane, t, mode, dst, s, fc);
+          else rc = folded_axis0_u16(src, Z, plane, t, mode, dst, s, fc);
         }
         if (rc > 0) return rc;
         done = rc == 0;
