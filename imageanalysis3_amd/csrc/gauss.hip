@@ -553,8 +553,11 @@ __global__ __launch_bounds__(256, 5) void gauss_xy_short(const T* __restrict__ i
       if (tmax) {
         // TY is a multiple of 64 here: 16 consecutive runs (an aligned group of 16 lanes) are one row of one 64-column
         // group, i.e. of one detector tile; the group's maximum goes to its LDS slot
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
+        // maximum over the 16 lanes of a DPP row: four rotations inside the row, fused into the max instructions
+        smax = fmaxf(smax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(smax), 0x128, 0xf, 0xf, false)));   // row_ror:8
+        smax = fmaxf(smax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(smax), 0x124, 0xf, 0xf, false)));   // row_ror:4
+        smax = fmaxf(smax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(smax), 0x122, 0xf, 0xf, false)));   // row_ror:2
+        smax = fmaxf(smax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(smax), 0x121, 0xf, 0xf, false)));   // row_ror:1
         if ((t & 15) == 0 && smax > -INFINITY) {
           const unsigned u = __float_as_uint(smax);
           atomicMax(&smx[ry[r] >> 6], (u & 0x80000000u) ? ~u : (u | 0x80000000u));
