@@ -776,7 +776,7 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
   }
   {
     ProfScope ps("seed_detect");
-    constexpr int ZT = 64;
+    constexpr int ZT = 32;   // planes per block: two chunks of a 50-plane stack balance the skipped planes better than one (0.174 -> 0.164 ms)
     const unsigned tiles = (unsigned)((Y + 63) / 64) * (unsigned)((X + 15) / 16);
     dim3 gt(8 * ((tiles + 7) / 8), 1, (unsigned)((Z + ZT - 1) / ZT));
     const double th_test = th_low - fabs(th_low) * 1e-6 - 1e-300;   // the exact test is made in float32: keep the bound test looser
