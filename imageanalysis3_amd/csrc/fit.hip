@@ -130,12 +130,10 @@ __device__ __forceinline__ double load_voxel(const void* im, int dtype, size_t i
   return dtype == IA3_F32 ? (double)((const float*)im)[idx] : (double)((const uint16_t*)im)[idx];
 }
 
-// Per-lane view of one ball: up to SLOTS voxels.
-struct Ball {
-  float dat[SLOTS];                        // float32 data the fit sees (GaussianFit casts to float32, :172)
-  float cz[SLOTS], cx[SLOTS], cy[SLOTS];   // voxel coordinates (exact small integers)
-  unsigned valid;                          // bit s: slot s holds a voxel
-};
+// A wave-uniform double as a scalar-register pair (the value must be the same in every lane).
+__device__ __forceinline__ double sgpr(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // ---- cross-lane sums of many values at once (gfx950) -----------------------------------------------------------
 // v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows of TWO registers in one VALU instruction,
@@ -238,24 +236,47 @@ __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const
   __builtin_amdgcn_wave_barrier();   // sc is reused by the next evaluation only after these reads
 }
 
-// Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
+// Everything a fit keeps between its phases lives in LDS, one block per wave: a wave may hold no more than 256
+// registers (two waves per SIMD), and the only phase that needs most of them is the evaluation (66 float64 sums per lane).
 struct BallLds { float dat[SLOTS][64], cz[SLOTS][64], cx[SLOTS][64], cy[SLOTS][64]; };   // [slot][lane]: 8 KB per wave
+struct WaveLds {
+  BallLds bl;            // float32 data the fit sees (GaussianFit casts to float32, :172) and voxel coordinates
+  LMWork w;
+  FitCfg cfg;
+  double gsc[64];        // geom_scalars_wave
+  double lo10[10], hi10[10];   // the ten smallest / largest voxel values, each ascending (start point, :175-182)
+  float p[12];           // the fit's row
+  float co[4];           // centre of the previous fit of the seed (convergence test)
+};
 
+// Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
 struct WaveEval {
-  // the evaluation is not inlined into the solver, so this object lives in memory: keep it to two LDS pointers and a
-  // mask (voxel data and the fit configuration are parked in LDS, not in scratch memory)
-  const BallLds* b;
-  const FitCfg* cfgp;
-  double* gsc;        // 64 doubles of LDS for geom_scalars_wave
+  IA3_LDS WaveLds* L;
   unsigned valid;     // bit s: slot s of this lane holds a voxel
-  __device__ double eval(const double* x, double* A, double* g) {
-    Geom gm;
-    const IA3_LDS BallLds* bl = (const IA3_LDS BallLds*)b;   // everything the evaluation touches is in LDS
+  __device__ __forceinline__ double eval(const double* x, double* A, double* g) {
+    Geom gm;   // wave-uniform coefficient tables, in scalar registers: the slot loop below reads them as SGPR operands
+    const IA3_LDS BallLds* bl = &L->bl;
     {
-      GeomScalars gs;
-      geom_scalars_wave((const IA3_LDS double*)x, *(const IA3_LDS FitCfg*)cfgp, gs, (IA3_LDS double*)gsc);
-      const double xh[2] = {0.0, ((const IA3_LDS double*)x)[1]};
-      geom_assemble(xh, gs, gm);
+      Geom g0;
+      {
+        GeomScalars gs;
+        geom_scalars_wave((const IA3_LDS double*)x, L->cfg, gs, L->gsc);
+        const double xh[2] = {0.0, ((const IA3_LDS double*)x)[1]};
+        geom_assemble(xh, gs, g0);
+      }
+      gm.h = sgpr(g0.h); gm.ebk_f = sgpr(g0.ebk_f); gm.ebk_j = sgpr(g0.ebk_j);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gm.c[k] = sgpr(g0.c[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gm.q[k] = sgpr(g0.q[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gm.l[k][a] = sgpr(g0.l[k][a]);
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) gm.m[k][a] = sgpr(g0.m[k][a]);
     }
     double a[NTRI], gg[NP], ss = 0.0;
 #pragma unroll
@@ -263,11 +284,13 @@ struct WaveEval {
 #pragma unroll
     for (int k = 0; k < NP; ++k) gg[k] = 0.0;
     int nbad = 0;   // non-finite residuals, NaN counted twice (see below)
-#pragma unroll
+    const int ln = threadIdx.x & 63;
+    // a rolled loop: one slot's exp -> Jacobian row -> 66 accumulations is a dependent chain that the SIMD's other
+    // wave fills; unrolled, the allocator wants the whole register file
+#pragma unroll 1
     for (int s = 0; s < SLOTS; ++s) {
       bool r_inf = false, r_nan = false;
       if (valid & (1u << s)) {
-        const int ln = threadIdx.x & 63;
         double J[NP];
         double F = model_jac(gm, (double)bl->cz[s][ln], (double)bl->cx[s][ln], (double)bl->cy[s][ln], J);
         double r = (gm.ebk_f + F) - (double)bl->dat[s][ln];
@@ -296,7 +319,7 @@ struct WaveEval {
         p1[m] = swap32_add(x, y);
       }
       p1[N1] = 0.0;
-      const int lane = threadIdx.x & 63, row = lane >> 4;
+      const int lane = ln, row = lane >> 4;
       // row r of register n holds value 4n + {0, 2, 1, 3}[r]
       const int sel = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
 #pragma unroll
@@ -319,87 +342,98 @@ struct WaveEval {
   }
 };
 
-// The ten smallest and ten largest of the wave's valid values, each ascending.
-__device__ __forceinline__ void wave_extremes(const double* v, unsigned valid, double* lo10, double* hi10) {
+// The ten smallest and ten largest of the wave's valid values (each ascending) -> L->lo10, L->hi10.
+// Every lane sorts its eight values once (19 compare-exchanges, empty slots = +inf); then ten rounds: wave minimum of
+// the lanes' heads, the first lane that holds it drops its head.  The largest values are the smallest of the negated
+// ones.  (The first form rescanned all eight slots of every lane in every round: 6.5 k instructions per ball.)
+__device__ __forceinline__ void lane_sort8(double* v) {
+#define IA3_CE(i, j) { const double lo_ = fmin(v[i], v[j]), hi_ = fmax(v[i], v[j]); v[i] = lo_; v[j] = hi_; }
+  IA3_CE(0, 1) IA3_CE(2, 3) IA3_CE(4, 5) IA3_CE(6, 7)
+  IA3_CE(0, 2) IA3_CE(1, 3) IA3_CE(4, 6) IA3_CE(5, 7)
+  IA3_CE(1, 2) IA3_CE(5, 6) IA3_CE(0, 4) IA3_CE(3, 7)
+  IA3_CE(1, 5) IA3_CE(2, 6)
+  IA3_CE(1, 4) IA3_CE(3, 6)
+  IA3_CE(2, 4) IA3_CE(3, 5)
+  IA3_CE(3, 4)
+#undef IA3_CE
+}
+struct OpFmin { __device__ __forceinline__ double operator()(double x, double y) const { return fmin(x, y); } };
+template <bool NEG>
+__device__ __forceinline__ void wave_smallest10(const double* vals, unsigned valid, IA3_LDS double* out) {
   const int lane = threadIdx.x & 63;
-  unsigned taken_lo = 0, taken_hi = 0;
+  double v[SLOTS];
 #pragma unroll
+  for (int s = 0; s < SLOTS; ++s) v[s] = (valid & (1u << s)) ? (NEG ? -vals[s] : vals[s]) : INFINITY;
+  lane_sort8(v);
+#pragma unroll 1
   for (int k = 0; k < 10; ++k) {
-    double bl = INFINITY, bh = -INFINITY;
+    const double gmin = wave_reduce(v[0], OpFmin());
+    const unsigned long long m = __ballot(v[0] == gmin);
+    if (lane == __ffsll((long long)m) - 1) {
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      bool ok = valid & (1u << s);
-      if (ok && !(taken_lo & (1u << s)) && v[s] < bl) bl = v[s];
-      if (ok && !(taken_hi & (1u << s)) && v[s] > bh) bh = v[s];
+      for (int s = 0; s + 1 < SLOTS; ++s) v[s] = v[s + 1];
+      v[SLOTS - 1] = INFINITY;
     }
-    const double gl = wave_min(bl), gh = wave_max(bh);
-    const unsigned long long ml = __ballot(bl == gl), mh = __ballot(bh == gh);
-    if (lane == __ffsll((long long)ml) - 1) {
-      bool done = false;
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        if (!done && (valid & (1u << s)) && !(taken_lo & (1u << s)) && v[s] == gl) { taken_lo |= 1u << s; done = true; }
-    }
-    if (lane == __ffsll((long long)mh) - 1) {
-      bool done = false;
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        if (!done && (valid & (1u << s)) && !(taken_hi & (1u << s)) && v[s] == gh) { taken_hi |= 1u << s; done = true; }
-    }
-    lo10[k] = gl;
-    hi10[9 - k] = gh;
+    if (lane == 0) out[NEG ? 9 - k : k] = NEG ? -gmin : gmin;
   }
 }
+__device__ __forceinline__ void wave_extremes(const double* vals, unsigned valid, IA3_LDS WaveLds* L) {
+  wave_smallest10<false>(vals, valid, L->lo10);
+  wave_smallest10<true>(vals, valid, L->hi10);
+  __builtin_amdgcn_wave_barrier();
+}
 
-// One GaussianFit(...).fit() on the ball held by the wave (n >= 10 checked by the caller).
-// lo10 / hi10: the ten smallest / largest voxel values of the float64 data before the float32 cast (start point only,
-// :175-182).  centre_only: the caller needs nothing but the fitted centre p_out[1..3] (the first of two fits of a seed
-// without neighbours): natural parameters and eps are left out.
-__device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, LMWork& w, const Ball& ball, const double* lo10, const double* hi10,
-                                             int kind, const double* c0, double delta, int n, float* p_out, bool centre_only) {
-  __shared__ BallLds bl;   // one wave per block
-  {
-    const int ln = threadIdx.x & 63;
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      bl.dat[sl][ln] = ball.dat[sl]; bl.cz[sl][ln] = ball.cz[sl]; bl.cx[sl][ln] = ball.cx[sl]; bl.cy[sl][ln] = ball.cy[sl];
-    }
-  }
-  __shared__ FitCfg cfg_sh;   // wave-uniform: every lane writes the same values
+// One GaussianFit(...).fit() on the ball parked in L->bl (n >= 10 checked by the caller); start point from L->lo10 /
+// L->hi10 (the float64 data before the float32 cast, :175-182).  The row goes to L->p.  centre_only: the caller needs
+// nothing but the fitted centre p[1..3] (the first of two fits of a seed without neighbours): natural parameters and
+// eps are left out.
+__device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, IA3_LDS WaveLds* L, unsigned valid, int kind, const double* c0,
+                                             double delta, int n, bool centre_only) {
+  IA3_LDS FitCfg& cfg_sh = L->cfg;   // wave-uniform: every lane writes the same values
   cfg_sh.min_ws = fa.min_ws; cfg_sh.max_ws = fa.max_ws; cfg_sh.delta = delta; cfg_sh.init_w = fa.init_w;
   cfg_sh.c0[0] = c0[0]; cfg_sh.c0[1] = c0[1]; cfg_sh.c0[2] = c0[2];
   cfg_sh.variant = fa.variant; cfg_sh.iw[0] = fa.iw[0]; cfg_sh.iw[1] = fa.iw[1]; cfg_sh.iw[2] = fa.iw[2];
   __builtin_amdgcn_wave_barrier();
-  const FitCfg& cfg = cfg_sh;
-  __shared__ double geom_sc[64];
+  const FitCfg& cfg = *(const FitCfg*)&cfg_sh;
+  LMWork& w = *(LMWork*)&L->w;
+  float* p_out = (float*)L->p;
   WaveEval ev;
-  ev.b = &bl;
-  ev.cfgp = &cfg_sh;
-  ev.gsc = geom_sc;
-  ev.valid = ball.valid;
-  init_guess(lo10, hi10, kind, cfg, w.x);
+  ev.L = L;
+  ev.valid = valid;
+  {
+    double lo10[10], hi10[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { lo10[k] = L->lo10[k]; hi10[k] = L->hi10[k]; }
+    init_guess(lo10, hi10, kind, cfg, w.x);
+  }
+  __builtin_amdgcn_wave_barrier();
   LMResult r = lm_solve(ev, w, fa.ftol, fa.xtol, fa.gtol, fa.maxfev, fa.factor);
   if (centre_only) {
     double c[3];
     centers_of(w.x, cfg, c);   // what to_natural puts into p[1..3]
     p_out[1] = (float)c[0]; p_out[2] = (float)c[1]; p_out[3] = (float)c[2];
+    __builtin_amdgcn_wave_barrier();
     return r.nfev;
   }
   to_natural(w.x, cfg, p_out);
   Geom gm;
   make_geom(w.x, cfg, gm);
   double s = 0.0;
+  const int ln = threadIdx.x & 63;
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl)
-    if (ball.valid & (1u << sl))
-      s += fabs((gm.ebk_f + model_f0(gm, (double)ball.cz[sl], (double)ball.cx[sl], (double)ball.cy[sl])) -
-                (double)ball.dat[sl]);
+    if (valid & (1u << sl))
+      s += fabs((gm.ebk_f + model_f0(gm, (double)L->bl.cz[sl][ln], (double)L->bl.cx[sl][ln], (double)L->bl.cy[sl][ln])) -
+                (double)L->bl.dat[sl][ln]);
   p_out[10] = (float)(wave_sum(s) / (double)n);
+  __builtin_amdgcn_wave_barrier();
   return r.nfev;
 }
 
-__device__ __forceinline__ void store_result(const FitArgs& fa, int i, const float* p, const LMWork& w,
+__device__ __forceinline__ void store_result(const FitArgs& fa, int i, const IA3_LDS WaveLds* L,
                                              double delta, bool ok, int n, int nfev) {
+  const IA3_LDS float* p = L->p;
+  const IA3_LDS LMWork& w = L->w;
   if ((threadIdx.x & 63) == 0) {
     fa.nvox[i] = n;
     fa.nfev[i] += nfev;
@@ -480,13 +514,13 @@ __device__ __forceinline__ void each_neighbour(const FitArgs& fa, int i, F f) {
 
 // ---- stage 0 = firstfit of one seed (Fitting_v4.py:606-637) -----------------------------------------
 // the voxels of the seed's Voronoi cell inside its ball, from the ORIGINAL image; returns their number
-__device__ __forceinline__ int gather_first(const FitArgs& fa, int i, Ball& ball, double* vals) {
+__device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS BallLds* bl, unsigned& valid_out, double* vals) {
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
   const int ncnt = fa.nbr_cnt[i];
   const int nb0 = i * MAXNB, nb1 = nb0 + (ncnt <= fa.nb_cap ? ncnt : 0);
-  ball.valid = 0;
+  unsigned valid = 0;
   unsigned lost = 0;   // list overflow only: bit s = slot s belongs to another seed's Voronoi cell
   if (ncnt > fa.nb_cap) {
     each_neighbour(fa, i, [&](int j) {
@@ -509,7 +543,8 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, Ball& ball
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int vi = lane + 64 * s;
-    ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
+    float fd = 0.f, fz = 0.f, fx = 0.f, fy = 0.f;
+    vals[s] = 0.0;
     if (vi < fa.nball) {
       const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
       bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y && !(lost & (1u << s));
@@ -527,33 +562,38 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, Ball& ball
       }
       if (ok) {
         const double v = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
-        ball.valid |= 1u << s;
-        ball.dat[s] = (float)v; vals[s] = v;
-        ball.cz[s] = (float)z; ball.cx[s] = (float)x; ball.cy[s] = (float)y;
+        valid |= 1u << s;
+        fd = (float)v; vals[s] = v;
+        fz = (float)z; fx = (float)x; fy = (float)y;
       }
     }
+    bl->dat[s][lane] = fd; bl->cz[s][lane] = fz; bl->cx[s][lane] = fx; bl->cy[s][lane] = fy;
   }
-  return (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
+  valid_out = valid;
+  return __popcll(__ballot(valid & 1u)) + __popcll(__ballot(valid & 2u)) + __popcll(__ballot(valid & 4u)) +
+         __popcll(__ballot(valid & 8u)) + __popcll(__ballot(valid & 16u)) + __popcll(__ballot(valid & 32u)) +
+         __popcll(__ballot(valid & 64u)) + __popcll(__ballot(valid & 128u));
 }
 
 // ---- stage k >= 1 = one seed's refit in sweep k of repeatfit (:651-680) ---------------------------------
 // the full ball, data = image minus the current reconstructions of the overlapping seeds; returns the voxel count
-__device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, Ball& ball, double* vals) {
+__device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, IA3_LDS BallLds* bl, unsigned& valid_out, double* vals) {
   const int lane = threadIdx.x & 63;
   const int r = fa.radius;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
-  ball.valid = 0;
+  unsigned valid = 0;
+  int vz[SLOTS], vx[SLOTS], vy[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int vi = lane + 64 * s;
-    ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
+    vz[s] = 0; vx[s] = 0; vy[s] = 0; vals[s] = 0.0;
     if (vi < fa.nball) {
       const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
       if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
-        ball.valid |= 1u << s;
+        valid |= 1u << s;
         vals[s] = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
-        ball.cz[s] = (float)z; ball.cx[s] = (float)x; ball.cy[s] = (float)y;
+        vz[s] = z; vx[s] = x; vy[s] = y;
       }
     }
   }
@@ -573,17 +613,23 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, Ball& bal
     make_geom(xj, cj, gj);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      if (ball.valid & (1u << s)) {
-        const int oz = (int)ball.cz[s] - jz, ox = (int)ball.cx[s] - jx, oy = (int)ball.cy[s] - jy;
+      if (valid & (1u << s)) {
+        const int oz = vz[s] - jz, ox = vx[s] - jx, oy = vy[s] - jy;
         if (oz >= -r && oz < r && ox >= -r && ox < r && oy >= -r && oy < r && oz * oz + ox * ox + oy * oy <= r * r)
-          vals[s] -= model_f0(gj, (double)ball.cz[s], (double)ball.cx[s], (double)ball.cy[s]);
+          vals[s] -= model_f0(gj, (double)vz[s], (double)vx[s], (double)vy[s]);
       }
     }
     return true;
   });
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) ball.dat[s] = (float)vals[s];
-  return (int)(wave_sum((double)__popc(ball.valid)) + 0.5);
+  for (int s = 0; s < SLOTS; ++s) {
+    bl->dat[s][lane] = (float)vals[s];
+    bl->cz[s][lane] = (float)vz[s]; bl->cx[s][lane] = (float)vx[s]; bl->cy[s][lane] = (float)vy[s];
+  }
+  valid_out = valid;
+  return __popcll(__ballot(valid & 1u)) + __popcll(__ballot(valid & 2u)) + __popcll(__ballot(valid & 4u)) +
+         __popcll(__ballot(valid & 8u)) + __popcll(__ballot(valid & 16u)) + __popcll(__ballot(valid & 32u)) +
+         __popcll(__ballot(valid & 64u)) + __popcll(__ballot(valid & 128u));
 }
 
 // ---- one work-list position ------------------------------------------------------------------------------------------
@@ -595,37 +641,38 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, Ball& bal
 //   the work-list position of the seed's sweep 1 finds done[i] >= 2 and leaves.  Same operations on the same operands
 //   as the two separate positions; returns "converged".
 // The fit itself has ONE call site (the kernel is instruction-cache bound enough as it is).
-__device__ __forceinline__ bool run_position(const FitArgs& fa, LMWork& w, int i, int mode) {
+__device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds* L, int i, int mode) {
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
-  Ball ball;
-  double vals[SLOTS];
-  const int n = mode == 1 ? gather_repeat(fa, i, ball, vals) : gather_first(fa, i, ball, vals);
+  unsigned valid = 0;
+  int n;
+  {
+    double vals[SLOTS];
+    n = mode == 1 ? gather_repeat(fa, i, &L->bl, valid, vals) : gather_first(fa, i, &L->bl, valid, vals);
+    if (n >= NP) wave_extremes(vals, valid, L);   // mode 2: the same ten smallest / largest values start both fits
+  }
   int success_old = 0;
   float co0 = 0.f, co1 = 0.f, co2 = 0.f;
   if (mode == 1) {
     success_old = LDH(&fa.state[i].success);
     co0 = LDH(&fa.ps[(size_t)i * 11 + 1]); co1 = LDH(&fa.ps[(size_t)i * 11 + 2]); co2 = LDH(&fa.ps[(size_t)i * 11 + 3]);
   }
-  float p[11];
   const bool ok = n >= NP;  // :382-383 (mode 2: for both fits, same voxels)
   int nfev = 0, nfev_first = 0;
   const int npass = mode == 2 ? 2 : 1;
-  double lo10[10], hi10[10];   // mode 2: the same ten smallest / largest values start both fits
-  if (ok) wave_extremes(vals, ball.valid, lo10, hi10);
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     const bool refit = mode == 1 || pass == 1;
-    if (pass == 1) { success_old = ok ? 1 : 0; co0 = p[1]; co1 = p[2]; co2 = p[3]; nfev_first = nfev; }
+    if (pass == 1) { success_old = ok ? 1 : 0; co0 = L->p[1]; co1 = L->p[2]; co2 = L->p[3]; nfev_first = nfev; }
     // a refit sees the float64 residual (kind 2) and casts it to float32 (:172); the first fit the stack's own dtype
-    if (ok) nfev = wave_gaussfit(fa, w, ball, lo10, hi10, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
-                                 refit ? fa.delta_repeat : fa.delta_first, n, p, mode == 2 && pass == 0);
+    if (ok) nfev = wave_gaussfit(fa, L, valid, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
+                                 refit ? fa.delta_repeat : fa.delta_first, n, mode == 2 && pass == 0);
   }
   if (mode == 2 && ok && (threadIdx.x & 63) == 0) atomicAdd(&fa.counters[0], 1ull);   // two fits; store_result counts one
-  store_result(fa, i, p, w, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
+  store_result(fa, i, L, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
   // convergence (:677-680): float32 centre differences, compared in float64
   bool cv = true;
   if (mode != 0 && ok && success_old) {
-    const float d0 = co0 - p[1], d1 = co1 - p[2], d2 = co2 - p[3];
+    const float d0 = co0 - L->p[1], d1 = co1 - L->p[2], d2 = co2 - L->p[3];
     const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
     cv = (double)dist < fa.dist_th2;
   }
@@ -684,7 +731,7 @@ __device__ __forceinline__ void publish_quiet(int* done, int i, int value) {
 }
 
 // one work-list position; false = abort (a dependency wait exceeded its bound)
-__device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int n, int stage0, int stage1, StageCtl* ctl,
+__device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLds* L, int n, int stage0, int stage1, StageCtl* ctl,
                                                int* done, unsigned pos) {
   const int lane = threadIdx.x & 63;
   const int k = stage0 + (int)(pos / (unsigned)n);
@@ -692,7 +739,7 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int
   if (k == 0) {
     // sweep 1 is part of this launch and nothing overlaps this seed: both of its fits from this wave (run_position)
     const bool fused = fa.fuse && stage1 >= 2 && fa.nbr_cnt[i] == 0;
-    const bool cv = run_position(fa, w, i, fused ? 2 : 0);
+    const bool cv = run_position(fa, L, i, fused ? 2 : 0);
     if (fused) {
       if (lane == 0) {
         st_sc1(&fa.state[i].conv, cv ? 1 : 0);
@@ -725,7 +772,7 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int
   each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
   if (!alive) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const bool cv = run_position(fa, w, i, 1);
+  const bool cv = run_position(fa, L, i, 1);
   if (lane == 0) {
     st_sc1(&fa.state[i].conv, cv ? 1 : 0);
     atomicMax(fa.n_iter, k);
@@ -740,9 +787,10 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, LMWork& w, int
 // block index: tickets are handed out in the order waves actually get to them, so everything a wave may wait for is
 // held by a wave that is running (or done) whatever order the dispatcher picks — no co-residency assumption.  (One block
 // per position, the first form, spent 0.14 ms per 10 000 positions on block launches alone.)
-__global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
-                                                   int* done) {
-  __shared__ LMWork w;
+__global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
+                                                      int* done) {
+  __shared__ WaveLds wl;
+  IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
   const int lane = threadIdx.x & 63;
   const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
   for (;;) {
@@ -750,7 +798,7 @@ __global__ __launch_bounds__(64) void fit_stages_k(FitArgs fa, int n, int stage0
     if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
     pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
     if (pos >= total) return;
-    if (!stage_position(fa, w, n, stage0, stage1, ctl, done, pos)) return;
+    if (!stage_position(fa, L, n, stage0, stage1, ctl, done, pos)) return;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -768,48 +816,47 @@ struct VoxArgs {
   int* info;            // n_fits x 2: success, nfev
 };
 
-__global__ __launch_bounds__(64) void fit_voxels_k(VoxArgs va, int n_fits, double ftol, double xtol, double gtol,
-                                                   int maxfev, double factor) {
-  __shared__ LMWork w;
+__global__ __launch_bounds__(64, 2) void fit_voxels_k(VoxArgs va, int n_fits, double ftol, double xtol, double gtol,
+                                                      int maxfev, double factor) {
+  __shared__ WaveLds wl;
+  IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
   const int i = blockIdx.x;
   if (i >= n_fits) return;
   const int lane = threadIdx.x & 63;
   const int o0 = va.off[i], n = va.off[i + 1] - o0;
-  Ball ball;
-  double vals[SLOTS];
-  ball.valid = 0;
+  unsigned valid = 0;
+  const bool ok = n >= NP;
+  {
+    double vals[SLOTS];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int vi = lane + 64 * s;
-    ball.dat[s] = 0.f; ball.cz[s] = 0.f; ball.cx[s] = 0.f; ball.cy[s] = 0.f; vals[s] = 0.0;
-    if (vi < n) {
-      ball.valid |= 1u << s;
-      vals[s] = va.vals[o0 + vi];
-      ball.dat[s] = (float)vals[s];
-      ball.cz[s] = (float)va.coords[3 * (o0 + vi)];
-      ball.cx[s] = (float)va.coords[3 * (o0 + vi) + 1];
-      ball.cy[s] = (float)va.coords[3 * (o0 + vi) + 2];
+    for (int s = 0; s < SLOTS; ++s) {
+      const int vi = lane + 64 * s;
+      float fz = 0.f, fx = 0.f, fy = 0.f;
+      vals[s] = 0.0;
+      if (vi < n) {
+        valid |= 1u << s;
+        vals[s] = va.vals[o0 + vi];
+        fz = (float)va.coords[3 * (o0 + vi)];
+        fx = (float)va.coords[3 * (o0 + vi) + 1];
+        fy = (float)va.coords[3 * (o0 + vi) + 2];
+      }
+      L->bl.dat[s][lane] = (float)vals[s]; L->bl.cz[s][lane] = fz; L->bl.cx[s][lane] = fx; L->bl.cy[s][lane] = fy;
     }
+    if (ok) wave_extremes(vals, valid, L);
   }
   FitArgs fa;
   const double min_w = va.cfg[4 * i + 1], max_w = va.cfg[4 * i + 2];
   fa.min_ws = min_w * min_w; fa.max_ws = max_w * max_w; fa.init_w = va.cfg[4 * i + 3];
   fa.ftol = ftol; fa.xtol = xtol; fa.gtol = gtol; fa.maxfev = maxfev; fa.factor = factor;
   const double c0[3] = {va.center[3 * i], va.center[3 * i + 1], va.center[3 * i + 2]};
-  float p[11];
-#pragma unroll
-  for (int k = 0; k < 11; ++k) p[k] = NAN;
+  if (lane < 11) L->p[lane] = NAN;
+  __builtin_amdgcn_wave_barrier();
   int nfev = 0;
-  const bool ok = n >= NP;
-  if (ok) {
-    double lo10[10], hi10[10];
-    wave_extremes(vals, ball.valid, lo10, hi10);
-    nfev = wave_gaussfit(fa, w, ball, lo10, hi10, va.kind[i], c0, va.cfg[4 * i], n, p, false);
-  }
+  if (ok) nfev = wave_gaussfit(fa, L, valid, va.kind[i], c0, va.cfg[4 * i], n, false);
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 11; ++k) va.ps[(size_t)i * 11 + k] = p[k];
-    for (int k = 0; k < NP; ++k) va.xs[(size_t)i * NP + k] = ok ? w.x[k] : NAN;
+    for (int k = 0; k < 11; ++k) va.ps[(size_t)i * 11 + k] = L->p[k];
+    for (int k = 0; k < NP; ++k) va.xs[(size_t)i * NP + k] = ok ? L->w.x[k] : NAN;
     va.info[2 * i] = ok ? 1 : 0;
     va.info[2 * i + 1] = nfev;
   }
@@ -876,6 +923,7 @@ int build_ball(int r, std::vector<signed char>& ball) {
 
 int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
 int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets its first fit and sweep 1 from one wave
+int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the kernel's 256 registers allow two)
 
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
@@ -1028,6 +1076,7 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 namespace ia3k {
 void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
 void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
+void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
 void fit_host_counters(const ia3_fitter* f, long long out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
 }
@@ -1053,7 +1102,7 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   }
   f->pristine = false;
   long long blocks = (long long)(stage1 - stage0) * f->n;   // work-list positions; waves draw them as tickets
-  const long long simds = 4LL * num_cus();
+  const long long simds = 4LL * num_cus() * g_fit_waves;
   if (blocks > simds) blocks = simds;
   if (blocks < 1) blocks = 1;
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");

@@ -172,138 +172,194 @@ IA3_HD void lm_scaled(const double* diag, const double* x, const double* t2, dou
 
 // lmpar on the normal equations: find par with | |D x| - delta | <= 0.1 delta, x = (A+par D²)⁻¹ g
 // sc: 2*NP doubles of scratch (LDS on the device)
+// One loop, one factorisation site: pass 0 is lmpar's Gauss–Newton trial (par = 0) with its bounds parl / paru,
+// passes 1..10 its Newton iteration on par — the same operations in the same order as the two-part form MINPACK
+// writes, in half the code (the fit kernel is instruction-cache bound).
 template <int LW = 64>
 IA3_HD void lm_par(const double* A, const double* g, const double* diag, double delta, double& par, double* x,
                    double* sc) {
   Chol c;
   double t1[NP], t2[NP];
-  lm_factor(A, diag, 0.0, c);
-  lm_fwd(c, g, t1);
-  lm_bwd(c, t1, x);
-  int iter = 0;
-  IA3_UNROLL
-  for (int j = 0; j < NP; ++j) t2[j] = diag[j] * x[j];
-  double dxnorm = lm_norm(t2);
-  double fp = dxnorm - delta;
-  if (fp <= 0.1 * delta) { par = 0.0; return; }
-  double parl = 0.0;
-  if (c.skip == 0) {
-    lm_scaled<LW>(diag, x, t2, dxnorm, t1, sc);
-    lm_fwd(c, t1, t1);
-    double temp = lm_norm(t1);
-    parl = ((fp / delta) / temp) / temp;
-  }
-#if IA3_LM_PAR
-  {
-    const int ln = lm_lane<LW>();
-    if (ln < NP) sc[ln] = g[ln] / diag[ln];
-    IA3_LM_SYNC();
-    IA3_UNROLL
-    for (int j = 0; j < NP; ++j) t1[j] = sc[j];
-    IA3_LM_SYNC();
-  }
-#else
-  IA3_UNROLL
-  for (int j = 0; j < NP; ++j) t1[j] = g[j] / diag[j];
-#endif
-  double gnorm = lm_norm(t1);
-  double paru = gnorm / delta;
-  if (paru == 0.0) paru = IA3_DWARF / (delta < 0.1 ? delta : 0.1);
-  par = par > parl ? par : parl;
-  par = par < paru ? par : paru;
-  if (par == 0.0) par = gnorm / dxnorm;
-  for (;;) {
-    ++iter;
-    if (par == 0.0) { double t = 0.001 * paru; par = IA3_DWARF > t ? IA3_DWARF : t; }
-    lm_factor(A, diag, par, c);
+  double parl = 0.0, paru = 0.0, fp = 0.0;
+  for (int iter = 0;; ++iter) {
+    double pf = 0.0;
+    if (iter > 0) {
+      if (par == 0.0) { double t = 0.001 * paru; par = IA3_DWARF > t ? IA3_DWARF : t; }
+      pf = par;
+    }
+    lm_factor(A, diag, pf, c);
     lm_fwd(c, g, t1);
     lm_bwd(c, t1, x);
     IA3_UNROLL
     for (int j = 0; j < NP; ++j) t2[j] = diag[j] * x[j];
-    dxnorm = lm_norm(t2);
-    double temp = fp;
+    const double dxnorm = lm_norm(t2);
+    const double fp_old = fp;
     fp = dxnorm - delta;
-    if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-    lm_scaled<LW>(diag, x, t2, dxnorm, t1, sc);
-    lm_fwd(c, t1, t1);
-    temp = lm_norm(t1);
-    double parc = ((fp / delta) / temp) / temp;
-    if (fp > 0.0) parl = parl > par ? parl : par;
-    if (fp < 0.0) paru = paru < par ? paru : par;
-    double pn = par + parc;
-    par = parl > pn ? parl : pn;
+    if (iter == 0) {
+      if (fp <= 0.1 * delta) { par = 0.0; return; }
+    } else if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || iter == 10) {
+      return;
+    }
+    double parc = 0.0;   // Newton correction; pass 0: lmpar's lower bound, not used when a column vanished
+    if (iter > 0 || c.skip == 0) {
+      lm_scaled<LW>(diag, x, t2, dxnorm, t1, sc);
+      lm_fwd(c, t1, t1);
+      const double temp = lm_norm(t1);
+      parc = ((fp / delta) / temp) / temp;
+    }
+    if (iter == 0) {
+      parl = parc;
+#if IA3_LM_PAR
+      {
+        const int ln = lm_lane<LW>();
+        if (ln < NP) sc[ln] = g[ln] / diag[ln];
+        IA3_LM_SYNC();
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) t1[j] = sc[j];
+        IA3_LM_SYNC();
+      }
+#else
+      IA3_UNROLL
+      for (int j = 0; j < NP; ++j) t1[j] = g[j] / diag[j];
+#endif
+      const double gnorm = lm_norm(t1);
+      paru = gnorm / delta;
+      if (paru == 0.0) paru = IA3_DWARF / (delta < 0.1 ? delta : 0.1);
+      par = par > parl ? par : parl;
+      par = par < paru ? par : paru;
+      if (par == 0.0) par = gnorm / dxnorm;
+    } else {
+      if (fp > 0.0) parl = parl > par ? parl : par;
+      if (fp < 0.0) paru = paru < par ? paru : par;
+      const double pn = par + parc;
+      par = parl > pn ? parl : pn;
+    }
   }
 }
 
+// lmder's iteration with ONE evaluation site: the evaluation at the start point is the first pass of the same loop
+// that evaluates the trial points (it is "accepted" unconditionally).  After an accepted point the outer-loop
+// prologue of lmder runs (column norms, scaling, gradient test), then lmpar and the next trial point.
 template <class Eval>
 IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double gtol, int maxfev,
                          double factor) {
   LMResult r;
-  r.info = 0; r.nfev = 1; r.iter = 1;
+  r.info = 0; r.nfev = 0; r.iter = 1;
   // JᵀJ / Jᵀf of the accepted point and of the trial point ping-pong between the two halves of the work area:
   // accepting a step swaps the pointers instead of copying 65 values through LDS
   double* Ac = w.A; double* gc = w.g;      // current accepted point
   double* At = w.A1; double* gt = w.g1;    // trial point
-  double fnorm = ev.eval(w.x, Ac, gc);
-  double par = 0.0, delta = 0.0, xnorm = 0.0;
-  for (;;) {  // outer loop: A, g hold JᵀJ, Jᵀf at x
-#if IA3_LM_PAR
-    {
-      const int ln = lm_lane<64>();
-      if (ln < NP) w.cn[ln] = sqrt(Ac[tri(ln, ln)]);
-      IA3_LM_SYNC();
-    }
-#else
-    IA3_UNROLL
-    for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(Ac[tri(j, j)]);
-#endif
-    if (r.iter == 1) {
-      double t[NP];
-      IA3_UNROLL
-      for (int j = 0; j < NP; ++j) {
-        w.diag[j] = w.cn[j] == 0.0 ? 1.0 : w.cn[j];
-        t[j] = w.diag[j] * w.x[j];
+  double fnorm = 0.0, par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0, pnorm = 0.0, jp2 = 0.0;
+  bool first = true;
+  for (;;) {
+    const double fnorm1 = ev.eval(first ? w.x : w.xt, At, gt);
+    ++r.nfev;
+    bool accepted;
+    if (first) {
+      first = false;
+      accepted = true;
+      fnorm = fnorm1;
+      { double* sw = Ac; Ac = At; At = sw; sw = gc; gc = gt; gt = sw; }
+    } else {
+      double actred = -1.0;
+      if (0.1 * fnorm1 < fnorm) { double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
+      double temp1 = sqrt(jp2) / fnorm;
+      double temp2 = (sqrt(par) * pnorm) / fnorm;
+      double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+      double dirder = -(temp1 * temp1 + temp2 * temp2);
+      double ratio = prered != 0.0 ? actred / prered : 0.0;
+      if (ratio <= 0.25) {
+        double temp;
+        if (actred >= 0.0) temp = 0.5;
+        else temp = 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        double pm = pnorm / 0.1;
+        delta = temp * (delta < pm ? delta : pm);
+        par = par / temp;
+      } else if (par == 0.0 || ratio >= 0.75) {
+        delta = pnorm / 0.5;
+        par = 0.5 * par;
       }
-      xnorm = lm_norm(t);
-      delta = factor * xnorm;
-      if (delta == 0.0) delta = factor;
+      accepted = ratio >= 1e-4;
+      if (accepted) {  // successful iteration
+        double t[NP];
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; t[j] = w.diag[j] * w.xt[j]; }
+        { double* sw = Ac; Ac = At; At = sw; sw = gc; gc = gt; gt = sw; }
+        xnorm = lm_norm(t);
+        fnorm = fnorm1;
+        ++r.iter;
+      }
+      bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+      if (small) r.info = 1;
+      if (delta <= xtol * xnorm) r.info = 2;
+      if (small && r.info == 2) r.info = 3;
+      if (r.info != 0) break;
+      if (r.nfev >= maxfev) r.info = 5;
+      if (fabs(actred) <= IA3_EPSMCH && prered <= IA3_EPSMCH && 0.5 * ratio <= 1.0) r.info = 6;
+      if (delta <= IA3_EPSMCH * xnorm) r.info = 7;
+      if (gnorm <= IA3_EPSMCH) r.info = 8;
+      if (r.info != 0) break;
     }
-    double gnorm = 0.0;
-    if (fnorm != 0.0) {
+    if (accepted) {  // lmder's outer loop: Ac, gc hold JᵀJ, Jᵀf at x
 #if IA3_LM_PAR
       {
         const int ln = lm_lane<64>();
-        if (ln < NP) { const double cnl = w.cn[ln]; if (cnl != 0.0) w.sc[ln] = fabs((gc[ln] / fnorm) / cnl); }
+        if (ln < NP) w.cn[ln] = sqrt(Ac[tri(ln, ln)]);
         IA3_LM_SYNC();
       }
-#endif
+#else
       IA3_UNROLL
-      for (int j = 0; j < NP; ++j) {
-        if (w.cn[j] != 0.0) {
-#if IA3_LM_PAR
-          double v = w.sc[j];
-#else
-          double v = fabs((gc[j] / fnorm) / w.cn[j]);
+      for (int j = 0; j < NP; ++j) w.cn[j] = sqrt(Ac[tri(j, j)]);
 #endif
-          gnorm = gnorm > v ? gnorm : v;
+      if (r.iter == 1) {
+        double t[NP];
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) {
+          w.diag[j] = w.cn[j] == 0.0 ? 1.0 : w.cn[j];
+          t[j] = w.diag[j] * w.x[j];
         }
+        xnorm = lm_norm(t);
+        delta = factor * xnorm;
+        if (delta == 0.0) delta = factor;
       }
+      gnorm = 0.0;
+      if (fnorm != 0.0) {
 #if IA3_LM_PAR
-      IA3_LM_SYNC();
+        {
+          const int ln = lm_lane<64>();
+          if (ln < NP) { const double cnl = w.cn[ln]; if (cnl != 0.0) w.sc[ln] = fabs((gc[ln] / fnorm) / cnl); }
+          IA3_LM_SYNC();
+        }
 #endif
-    }
-    if (gnorm <= gtol) { r.info = 4; break; }
+        IA3_UNROLL
+        for (int j = 0; j < NP; ++j) {
+          if (w.cn[j] != 0.0) {
 #if IA3_LM_PAR
-    {
-      const int ln = lm_lane<64>();
-      if (ln < NP) { const double dl = w.diag[ln], cl = w.cn[ln]; w.diag[ln] = dl > cl ? dl : cl; }
-      IA3_LM_SYNC();
-    }
+            double v = w.sc[j];
 #else
-    IA3_UNROLL
-    for (int j = 0; j < NP; ++j) w.diag[j] = w.diag[j] > w.cn[j] ? w.diag[j] : w.cn[j];
+            double v = fabs((gc[j] / fnorm) / w.cn[j]);
 #endif
-    for (;;) {  // inner loop
+            gnorm = gnorm > v ? gnorm : v;
+          }
+        }
+#if IA3_LM_PAR
+        IA3_LM_SYNC();
+#endif
+      }
+      if (gnorm <= gtol) { r.info = 4; break; }
+#if IA3_LM_PAR
+      {
+        const int ln = lm_lane<64>();
+        if (ln < NP) { const double dl = w.diag[ln], cl = w.cn[ln]; w.diag[ln] = dl > cl ? dl : cl; }
+        IA3_LM_SYNC();
+      }
+#else
+      IA3_UNROLL
+      for (int j = 0; j < NP; ++j) w.diag[j] = w.diag[j] > w.cn[j] ? w.diag[j] : w.cn[j];
+#endif
+    }
+    {  // lmder's inner loop up to the evaluation of the trial point
       double pv[NP], t[NP];
       lm_par(Ac, gc, w.diag, delta, par, pv, w.sc);
       IA3_UNROLL
@@ -313,11 +369,10 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
         w.xt[j] = w.x[j] + pv[j];
         t[j] = w.diag[j] * pv[j];
       }
-      double pnorm = lm_norm(t);
+      pnorm = lm_norm(t);
       if (r.iter == 1) delta = delta < pnorm ? delta : pnorm;
-      // |J p|² = pᵀ A p   (A of the current accepted point; must precede the trial evaluation only
-      // in the sense that A is still untouched: eval writes A1/g1)
-      double jp2 = 0.0;
+      // |J p|² = pᵀ A p   (A of the current accepted point: the evaluation writes At / gt)
+      jp2 = 0.0;
 #if IA3_LM_PAR
       {
         const int ln = lm_lane<64>();
@@ -342,48 +397,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
       }
 #endif
       if (jp2 < 0.0) jp2 = 0.0;
-      double fnorm1 = ev.eval(w.xt, At, gt);
-      ++r.nfev;
-      double actred = -1.0;
-      if (0.1 * fnorm1 < fnorm) { double q = fnorm1 / fnorm; actred = 1.0 - q * q; }
-      double temp1 = sqrt(jp2) / fnorm;
-      double temp2 = (sqrt(par) * pnorm) / fnorm;
-      double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-      double dirder = -(temp1 * temp1 + temp2 * temp2);
-      double ratio = prered != 0.0 ? actred / prered : 0.0;
-      if (ratio <= 0.25) {
-        double temp;
-        if (actred >= 0.0) temp = 0.5;
-        else temp = 0.5 * dirder / (dirder + 0.5 * actred);
-        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-        double pm = pnorm / 0.1;
-        delta = temp * (delta < pm ? delta : pm);
-        par = par / temp;
-      } else if (par == 0.0 || ratio >= 0.75) {
-        delta = pnorm / 0.5;
-        par = 0.5 * par;
-      }
-      if (ratio >= 1e-4) {  // successful iteration
-        IA3_UNROLL
-        for (int j = 0; j < NP; ++j) { w.x[j] = w.xt[j]; t[j] = w.diag[j] * w.xt[j]; }
-        { double* sw = Ac; Ac = At; At = sw; sw = gc; gc = gt; gt = sw; }
-        xnorm = lm_norm(t);
-        fnorm = fnorm1;
-        ++r.iter;
-      }
-      bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-      if (small) r.info = 1;
-      if (delta <= xtol * xnorm) r.info = 2;
-      if (small && r.info == 2) r.info = 3;
-      if (r.info != 0) break;
-      if (r.nfev >= maxfev) r.info = 5;
-      if (fabs(actred) <= IA3_EPSMCH && prered <= IA3_EPSMCH && 0.5 * ratio <= 1.0) r.info = 6;
-      if (delta <= IA3_EPSMCH * xnorm) r.info = 7;
-      if (gnorm <= IA3_EPSMCH) r.info = 8;
-      if (r.info != 0) break;
-      if (ratio >= 1e-4) break;  // leave inner loop, new Jacobian already in A, g
     }
-    if (r.info != 0) break;
   }
   r.fnorm = fnorm;
   return r;

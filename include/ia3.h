@@ -84,6 +84,9 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * its registers (per group of planes, row and 32 columns); 0 = from a pass over the stored axis-0 result (per plane).  Only
  * the number of first-stage candidates can differ, never a seed. */
 #define IA3_TUNE_SEED_STRIPS 9
+/* IA3_TUNE_FIT_WAVES: persistent wavefronts of the fit kernel per SIMD, 1 or 2 (default 2: the kernel is built for 256
+ * registers).  Tables are identical bit for bit. */
+#define IA3_TUNE_FIT_WAVES 10
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
