@@ -26,7 +26,7 @@ EXPORTS = [
     "ia3_stack_deinterleave", "ia3_buffer_upload", "ia3_buffer_free", "ia3_remove_hot_pixels_dev",
     "ia3_z_shift_correction_dev", "ia3_illumination_correct_dev", "ia3_bleedthrough_correct_dev",
     "ia3_illumination_rescale_dev", "ia3_bleedthrough_rescale_dev",
-    "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_run", "ia3_fit_results", "ia3_fit_results_ex", "ia3_fit_nfev", "ia3_fit_stats",
+    "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_run", "ia3_fit_results", "ia3_fit_results_ex", "ia3_fit_nfev", "ia3_fit_stats", "ia3_fit_counters",
     "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_fit_fov_stats", "ia3_fit_fovs",
     "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
@@ -313,8 +313,9 @@ def fit_fovs(ims, seed_params, fit_params, in_flight=4, capacity=16384):
             j.rows, j.capacity = r.ctypes.data, capacity
         rc = lib().ia3_fit_fovs(jobs, n, code, shape[0], shape[1], shape[2], C.byref(seed_params), C.byref(fit_params),
                                 int(in_flight))
-        if rc == IA3_ECAPACITY:
-            capacity = max(j.n_rows for j in jobs)
+        need = max(j.n_rows for j in jobs)
+        if rc == IA3_ECAPACITY and need > capacity:   # a row table was too small (the seed stage reports the same code
+            capacity = need                           # for "too many candidates", with n_rows = 0: that one is an error)
             continue
         check(rc)
         break

@@ -24,6 +24,7 @@
 #include "ia3_rt.h"
 #include "ia3_lm.h"
 #include "ia3_init.h"
+#include "ia3_kdtree.h"
 #include <algorithm>
 #include <numeric>
 #include <math.h>
@@ -36,6 +37,11 @@
 #include <mutex>
 
 using namespace ia3;
+
+namespace ia3k {   // kdtree.cpp: the seed tree with scipy.spatial.cKDTree's layout
+void kd_build(const double* points, int n, std::vector<ia3::KdNode>& nodes, std::vector<int>& indices, double* mins,
+              double* maxes);
+}
 
 namespace {
 
@@ -61,7 +67,8 @@ struct FitArgs {
   double nb_r2;             // (2r)²: seeds closer than this interact
   const int* nbr_cnt;       // n: number of neighbours of seed i (NOT clamped: > MAXNB = list overflow, see each_neighbour)
   const int* nbr_idx;       // n x MAXNB: the first MAXNB seeds j != i with |c_i - c_j|² <= (2r)², ascending
-  const signed char* ball;  // nball x 4 (dz,dx,dy,0), np.indices order
+  const int* ball;          // nball packed offsets (dz, dx, dy, 0) as signed bytes, np.indices order: one load per voxel
+  const unsigned long long* tie_lost;  // n x SLOTS lane masks: voxels this seed loses in an exact Voronoi tie (voronoi_ties_k); may be null
   int nball, radius;
   SeedState* state;
   float* ps;                // n x 11
@@ -82,8 +89,10 @@ struct FitArgs {
 __device__ __forceinline__ double lane_mk(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 template <int N>
 __device__ __forceinline__ double lane_ror(double v) {   // value of the lane N places further along the same row
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 | N, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 | N, 0xF, 0xF, false);
+  // (mov_dpp, not update_dpp with an `old` operand: a row rotation reads a valid lane everywhere, and an explicit old
+  // value costs two register initialisations per rotation — a third of the cross-lane sums' instructions)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 | N, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 | N, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // the partner copies of v across the row pairs (0<->1, 2<->3) and across the half-waves
@@ -178,8 +187,8 @@ __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const
   const double delta = cfg.delta, min_ws = cfg.min_ws, max_ws = cfg.max_ws;
   // ---- stage 1: sc[i] = exp(arg_i) ------------------------------------------------------------------------------
   //  0 tp   1 pp   2-4 w1..3   5-7 centre (variant 1: numerator exp(-a))   8-10 variant 1: exp(-b)
-  //  11-13 -|xp|,-|yp|,-|zp|   14-16 -|w1..3|   17 -|pp|/2   18 -|tp|/2   19 bk   20 clipped bk
-  if (ln < 21) {
+  //  11-13 -|xp|,-|yp|,-|zp|   14-16 -|w1..3|   17 -|pp|/2   18 -|tp|/2   19 bk   20 clipped bk   21 h (natural_wave)
+  if (ln < 22) {
     double arg;
     if (ln < 2) arg = x[9 - ln];
     else if (ln < 5) arg = x[3 + ln];
@@ -189,6 +198,7 @@ __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const
     else if (ln < 17) arg = -fabs(x[ln - 9]);
     else if (ln < 19) arg = -fabs(x[ln - 9]) / 2;          // 17: pp = x[8], 18: tp = x[9]
     else if (ln == 19) arg = x[0];
+    else if (ln == 21) arg = x[1];
     else { const double bk = x[0]; arg = bk < -709.78 ? -709.78 : (bk > 709.78 ? 709.78 : bk); }
     sc[ln] = exp(arg);
   }
@@ -222,9 +232,13 @@ __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const
     sc[32 + ln] = r;
   }
   __builtin_amdgcn_wave_barrier();
-  // ---- stage 3: 1 / ws_k (lanes 0-2), cosines (lanes 3, 4) ------------------------------------------------------
+  // ---- stage 3: 1 / ws_k (lanes 0-2), cosines (lanes 3, 4), widths sqrt(ws_k) (lanes 5-7, for natural_wave) -------
   if (ln < 3) sc[48 + ln] = 1. / sc[34 + ln];
-  else if (ln < 5) { const double u = sc[29 + ln]; const double u2 = u * u; sc[48 + ln] = sqrt(1 - u2); }   // 3: t, 4: p
+  else if (ln < 8) {
+    const double u = sc[29 + ln];                       // 3: t, 4: p, 5-7: ws_k
+    const double u2 = u * u;
+    sc[48 + ln] = sqrt(ln < 5 ? 1 - u2 : u);
+  }
   __builtin_amdgcn_wave_barrier();
   q.t = sc[32]; q.p = sc[33];
   q.tc = sc[51]; q.pc = sc[52];
@@ -234,6 +248,19 @@ __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const
   q.ebk_j = sc[19];
   q.ebk_f = variant == 1 ? sc[19] : sc[20];
   __builtin_amdgcn_wave_barrier();   // sc is reused by the next evaluation only after these reads
+}
+
+// to_natural (ia3_model.h) from what geom_scalars_wave left in sc: the same operations on the same operands as the
+// serial form (whose dozen exponentials, divisions and square roots a lone wave sits through one after the other)
+__device__ __forceinline__ void natural_wave(const IA3_LDS double* sc, IA3_LDS float* p) {
+  const int ln = threadIdx.x & 63;
+  if (ln == 0) {
+    p[0] = (float)sc[21];                                                     // exp(h)
+    p[1] = (float)sc[37]; p[2] = (float)sc[38]; p[3] = (float)sc[39];         // centre
+    p[4] = (float)sc[19];                                                     // exp(bk)
+    p[5] = (float)sc[53]; p[6] = (float)sc[54]; p[7] = (float)sc[55];         // sqrt(ws_k)
+    p[8] = (float)sc[32]; p[9] = (float)sc[33];                               // sin t, sin p
+  }
 }
 
 // Everything a fit keeps between its phases lives in LDS, one block per wave: a wave may hold no more than 256
@@ -247,13 +274,34 @@ struct WaveLds {
   double lo10[10], hi10[10];   // the ten smallest / largest voxel values, each ascending (start point, :175-182)
   float p[12];           // the fit's row
   float co[4];           // centre of the previous fit of the seed (convergence test)
+  // tallies of this wave, flushed with one atomic each when the wave leaves the kernel: the per-fit atomics on three
+  // shared cache lines (counters, stage control, n_iter) were the kernel's largest wait at two waves per SIMD — 43 us
+  // per work-list position behind the ticket draw, which queues behind them (profiles/r03a/fit_stamps.log)
+  unsigned long long tally[3];   // fits run, function evaluations, voxel evaluations
+  int tally_conv, tally_iter;    // seeds that converged, highest sweep made
+#ifdef IA3_FIT_STAMPS
+  unsigned long long t_last, stamp[24];   // profiling build only (scripts/fit_stamps.sh): shader cycles per phase
+#endif
 };
+
+// Profiling build (-DIA3_FIT_STAMPS, never the shipped library): cycles since the previous stamp are added to phase k.
+#ifdef IA3_FIT_STAMPS
+#define IA3_STAMP(L, k)                                                                       \
+  do {                                                                                        \
+    const unsigned long long t_ = __builtin_readcyclecounter();                               \
+    if ((threadIdx.x & 63) == 0) { (L)->stamp[k] += t_ - (L)->t_last; (L)->t_last = t_; }     \
+    __builtin_amdgcn_wave_barrier();                                                          \
+  } while (0)
+#else
+#define IA3_STAMP(L, k) do { } while (0)
+#endif
 
 // Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
 struct WaveEval {
   IA3_LDS WaveLds* L;
   unsigned valid;     // bit s: slot s of this lane holds a voxel
   __device__ __forceinline__ double eval(const double* x, double* A, double* g) {
+    IA3_STAMP(L, 9);   // algebra since the last evaluation (or the fit's set-up before the first)
     Geom gm;   // wave-uniform coefficient tables, in scalar registers: the slot loop below reads them as SGPR operands
     const IA3_LDS BallLds* bl = &L->bl;
     {
@@ -278,6 +326,7 @@ struct WaveEval {
 #pragma unroll
         for (int a = 0; a < 6; ++a) gm.m[k][a] = sgpr(g0.m[k][a]);
     }
+    IA3_STAMP(L, 6);   // (geometry; the time since the previous stamp up to the call is the solver's algebra)
     double a[NTRI], gg[NP], ss = 0.0;
 #pragma unroll
     for (int k = 0; k < NTRI; ++k) a[k] = 0.0;
@@ -306,6 +355,7 @@ struct WaveEval {
       }
       nbad += __popcll(__ballot(r_inf)) + 2 * __popcll(__ballot(r_nan));
     }
+    IA3_STAMP(L, 7);   // voxel slots
     // sum the 65 partials over the wave: 65 -> 34 -> 17 registers by pairwise lane swaps, then inside the rows
     {
       constexpr int NV = NTRI + NP;            // 65
@@ -338,6 +388,7 @@ struct WaveEval {
     // the trust-region update.  Reached by the legacy model (no clip on the background exponent) when a trial
     // step sends bk past 709.
     const double fn = sqrt(wave_sum(ss));
+    IA3_STAMP(L, 8);   // cross-lane sums
     return nbad >= 2 ? NAN : fn;
   }
 };
@@ -407,17 +458,25 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, IA3_LDS WaveLds*
     init_guess(lo10, hi10, kind, cfg, w.x);
   }
   __builtin_amdgcn_wave_barrier();
+  IA3_STAMP(L, 3);   // fit set-up, start point
   LMResult r = lm_solve(ev, w, fa.ftol, fa.xtol, fa.gtol, fa.maxfev, fa.factor);
-  if (centre_only) {
-    double c[3];
-    centers_of(w.x, cfg, c);   // what to_natural puts into p[1..3]
-    p_out[1] = (float)c[0]; p_out[2] = (float)c[1]; p_out[3] = (float)c[2];
-    __builtin_amdgcn_wave_barrier();
-    return r.nfev;
-  }
-  to_natural(w.x, cfg, p_out);
+  IA3_STAMP(L, 4);   // solver tail after the last evaluation
+  // natural parameters and eps: the transcendental part once more through the lanes (geom_scalars_wave), at w.x
   Geom gm;
-  make_geom(w.x, cfg, gm);
+  {
+    GeomScalars gs;
+    // (the values stay in L->gsc after the call: nothing writes there before the next evaluation)
+    geom_scalars_wave((const IA3_LDS double*)L->w.x, L->cfg, gs, L->gsc);
+    if (centre_only) {
+      if ((threadIdx.x & 63) == 0) { L->p[1] = (float)gs.c[0]; L->p[2] = (float)gs.c[1]; L->p[3] = (float)gs.c[2]; }
+      __builtin_amdgcn_wave_barrier();
+      IA3_STAMP(L, 10);   // natural parameters, eps
+      return r.nfev;
+    }
+    natural_wave(L->gsc, L->p);
+    const double xh[2] = {0.0, L->w.x[1]};
+    geom_assemble(xh, gs, gm);
+  }
   double s = 0.0;
   const int ln = threadIdx.x & 63;
 #pragma unroll
@@ -425,44 +484,75 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, IA3_LDS WaveLds*
     if (valid & (1u << sl))
       s += fabs((gm.ebk_f + model_f0(gm, (double)L->bl.cz[sl][ln], (double)L->bl.cx[sl][ln], (double)L->bl.cy[sl][ln])) -
                 (double)L->bl.dat[sl][ln]);
-  p_out[10] = (float)(wave_sum(s) / (double)n);
+  const double eps = wave_sum(s) / (double)n;
+  if (ln == 0) L->p[10] = (float)eps;
   __builtin_amdgcn_wave_barrier();
+  IA3_STAMP(L, 10);
   return r.nfev;
 }
 
-__device__ __forceinline__ void store_result(const FitArgs& fa, int i, const IA3_LDS WaveLds* L,
-                                             double delta, bool ok, int n, int nfev) {
-  const IA3_LDS float* p = L->p;
-  const IA3_LDS LMWork& w = L->w;
-  if ((threadIdx.x & 63) == 0) {
+// Hand a fit's results over: the seed's state record (unconstrained parameters, delta, flags) and its row, in ONE store
+// instruction — lane l < 26 writes dword l of the SeedState, lanes 32..42 the eleven floats of the row.  (Lane 0 writing
+// 25 values one after the other cost 29 us per work-list position at two waves per SIMD: write-through `sc1` stores of
+// one wave complete one at a time, ~1.2 us each under load, and the next ticket draw waits for all of them;
+// profiles/r03a/fit_stamps.log.)  Readers take the record only after done[i] has been raised behind the drained store.
+__device__ __forceinline__ void store_result(const FitArgs& fa, int i, IA3_LDS WaveLds* L,
+                                             double delta, bool ok, int n, int nfev, bool write_conv, bool cv) {
+  const int lane = threadIdx.x & 63;
+  static_assert(sizeof(SeedState) == 26 * 4 && offsetof(SeedState, delta) == 80 && offsetof(SeedState, success) == 88 &&
+                offsetof(SeedState, has_rec) == 92 && offsetof(SeedState, conv) == 96, "store_result writes SeedState by dwords");
+  unsigned v = 0u;
+  bool act = false;
+  if (lane < 20) { v = ((const IA3_LDS unsigned*)L->w.x)[lane]; act = ok; }
+  else if (lane < 22) { v = lane == 20 ? (unsigned)__double2loint(delta) : (unsigned)__double2hiint(delta); act = ok; }
+  else if (lane == 22) { v = ok ? 1u : 0u; act = true; }
+  else if (lane == 23) { v = 1u; act = ok; }
+  else if (lane == 24) { v = cv ? 1u : 0u; act = write_conv; }
+  else if (lane >= 32 && lane < 43) { v = ((const IA3_LDS unsigned*)L->p)[lane - 32]; act = ok; }
+  unsigned* dst = lane < 32 ? (unsigned*)&fa.state[i] + lane : (unsigned*)&fa.ps[(size_t)i * 11] + (lane - 32);
+  if (act) st_sc1(dst, v);
+  if (lane == 0) {
     fa.nvox[i] = n;
     fa.nfev[i] += nfev;
-    SeedState& st = fa.state[i];
-    st_sc1(&st.success, ok ? 1 : 0);
     if (ok) {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) st_sc1(&st.x[k], w.x[k]);
-      st_sc1(&st.delta, delta);
-      st_sc1(&st.has_rec, 1);
-#pragma unroll
-      for (int k = 0; k < 11; ++k) st_sc1(&fa.ps[(size_t)i * 11 + k], p[k]);
-      atomicAdd(&fa.counters[0], 1ull);
-      atomicAdd(&fa.counters[1], (unsigned long long)nfev);
-      atomicAdd(&fa.counters[2], (unsigned long long)nfev * (unsigned long long)n);
+      L->tally[0] += 1ull;
+      L->tally[1] += (unsigned long long)nfev;
+      L->tally[2] += (unsigned long long)nfev * (unsigned long long)n;
     }
   }
 }
 
+// Squared distance as scipy's cKDTree forms it (query.cxx: s = 0; s += d_k * d_k for k = 0, 1, 2; separate multiply and
+// add): the Voronoi decisions compare these values for equality, so no contraction into fused multiply-adds here.
+__device__ __forceinline__ double dist2_seq(double az, double ax, double ay, double bz, double bx, double by) {
+  const double d0 = az - bz, d1 = ax - bx, d2 = ay - by;
+  return __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+}
+
+// offsets of ball voxel vi from the truncated seed position (packed signed bytes dz, dx, dy)
+struct BallOff { int dz, dx, dy; };
+__device__ __forceinline__ BallOff ball_off(const int* __restrict__ ball, int vi) {
+  const int w = ball[vi];
+  return BallOff{(int)(signed char)(w & 0xff), (int)(signed char)((w >> 8) & 0xff), (int)(signed char)((w >> 16) & 0xff)};
+}
+
+struct StageCtl;
 // ---- neighbour lists on the device: one wave per seed scans all seeds 64 at a time; hits are appended with
 // ballot + prefix rank, so every list comes out in ascending index order (5 k seeds: 25 M distance tests, ~10 µs;
-// the seed list never goes back to the host for this)
+// the seed list never goes back to the host for this).  For every neighbour found the wave also looks for EXACT Voronoi
+// ties — a voxel of seed i's ball, inside the image, as far from seed j as from seed i — and flags the seed and the
+// fitter: the reference resolves those by cKDTree's traversal order (ia3_kdtree.h), which needs a tree built on the host.
 __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ seeds, int n, double r2, int* __restrict__ cnt,
-                                                   int* __restrict__ idx, int* __restrict__ overflow) {
+                                                   int* __restrict__ idx, int* __restrict__ overflow,
+                                                   const int* __restrict__ ball, int nball, int Z, int X, int Y,
+                                                   int* __restrict__ tie_flag, int* __restrict__ ctl_ties) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;   // whole wave leaves together
   const double cz = seeds[3 * i], cx = seeds[3 * i + 1], cy = seeds[3 * i + 2];
+  const int iz = (int)cz, ix = (int)cx, iy = (int)cy;
   int c = 0;
+  bool tie = false;
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     bool hit = false;
@@ -470,16 +560,33 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
       const double a = cz - seeds[3 * j], b = cx - seeds[3 * j + 1], d = cy - seeds[3 * j + 2];
       hit = a * a + b * b + d * d <= r2;
     }
-    const unsigned long long m = __ballot(hit);
+    unsigned long long m = __ballot(hit);
     if (hit) {
       const int pos = c + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < MAXNB) idx[(size_t)i * MAXNB + pos] = j;
     }
     c += __popcll(m);
+    while (m) {   // wave-uniform: the ball of seed i against neighbour j0 + b
+      const int bj = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const double sz = seeds[3 * (j0 + bj)], sx = seeds[3 * (j0 + bj) + 1], sy = seeds[3 * (j0 + bj) + 2];
+      for (int s = 0; s < SLOTS; ++s) {
+        const int vi = lane + 64 * s;
+        if (vi < nball) {
+          const BallOff o = ball_off(ball, vi);
+          const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
+          if (z >= 0 && z < Z && x >= 0 && x < X && y >= 0 && y < Y)
+            tie |= dist2_seq(cz, cx, cy, (double)z, (double)x, (double)y) == dist2_seq(sz, sx, sy, (double)z, (double)x, (double)y);
+        }
+      }
+    }
   }
+  const bool any_tie = __ballot(tie) != 0ull;
   if (lane == 0) {
     if (c > MAXNB) atomicMax(overflow, c);   // statistics only: consumers fall back to each_neighbour's scan
     cnt[i] = c;
+    tie_flag[i] = any_tie ? 1 : 0;
+    if (any_tie) atomicOr(ctl_ties, 1);
   }
 }
 
@@ -518,48 +625,44 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS Ba
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];  // Python int(): toward zero
-  const int ncnt = fa.nbr_cnt[i];
-  const int nb0 = i * MAXNB, nb1 = nb0 + (ncnt <= fa.nb_cap ? ncnt : 0);
-  unsigned valid = 0;
-  unsigned lost = 0;   // list overflow only: bit s = slot s belongs to another seed's Voronoi cell
-  if (ncnt > fa.nb_cap) {
+  // Voronoi (:612, :422-424): a voxel is dropped if another seed is strictly nearer, or equally near and the
+  // reference's cKDTree query meets that one first — a property of the tree, resolved beforehand into fa.tie_lost
+  // (voronoi_ties_k).  Without masks (nbr_build_k found no tie in the whole field) the tie branch is never taken.
+  unsigned lost = 0;   // bit s = slot s belongs to another seed's Voronoi cell
+  if (fa.nbr_cnt[i] > 0) {
+    unsigned tied = 0;
     each_neighbour(fa, i, [&](int j) {
       const double sz = fa.seeds[3 * j], sx = fa.seeds[3 * j + 1], sy = fa.seeds[3 * j + 2];
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
         const int vi = lane + 64 * s;
         if (vi < fa.nball) {
-          const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
-          const double dz = z - c0[0], dx = x - c0[1], dy = y - c0[2];
-          const double dme = dz * dz + dx * dx + dy * dy;
-          const double ez = z - sz, ex = x - sx, ey = y - sy;
-          const double dj = ez * ez + ex * ex + ey * ey;
-          if (dj < dme || (dj == dme && j < i)) lost |= 1u << s;
+          const BallOff o = ball_off(fa.ball, vi);
+          const double z = (double)(iz + o.dz), x = (double)(ix + o.dx), y = (double)(iy + o.dy);
+          const double dme = dist2_seq(c0[0], c0[1], c0[2], z, x, y);
+          const double dj = dist2_seq(sz, sx, sy, z, x, y);
+          if (dj < dme) lost |= 1u << s;
+          else if (dj == dme) { tied |= 1u << s; if (!fa.tie_lost && j < i) lost |= 1u << s; }
         }
       }
       return true;
     });
+    if (fa.tie_lost && __ballot(tied != 0u)) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if ((fa.tie_lost[(size_t)i * SLOTS + s] >> lane) & 1ull) lost |= tied & (1u << s);
+    }
   }
+  unsigned valid = 0;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int vi = lane + 64 * s;
     float fd = 0.f, fz = 0.f, fx = 0.f, fy = 0.f;
     vals[s] = 0.0;
     if (vi < fa.nball) {
-      const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
-      bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y && !(lost & (1u << s));
-      if (ok) {
-        // Voronoi (:612, :422-424): drop the voxel if another seed is strictly nearer, or equally
-        // near with a lower index (the reference's cKDTree leaves exact ties to its tree layout).
-        const double dz = z - c0[0], dx = x - c0[1], dy = y - c0[2];
-        const double dme = dz * dz + dx * dx + dy * dy;
-        for (int q = nb0; q < nb1 && ok; ++q) {
-          const int j = fa.nbr_idx[q];
-          const double ez = z - fa.seeds[3 * j], ex = x - fa.seeds[3 * j + 1], ey = y - fa.seeds[3 * j + 2];
-          const double dj = ez * ez + ex * ex + ey * ey;
-          if (dj < dme || (dj == dme && j < i)) ok = false;
-        }
-      }
+      const BallOff o = ball_off(fa.ball, vi);
+      const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
+      const bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y && !(lost & (1u << s));
       if (ok) {
         const double v = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
         valid |= 1u << s;
@@ -573,6 +676,59 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS Ba
   return __popcll(__ballot(valid & 1u)) + __popcll(__ballot(valid & 2u)) + __popcll(__ballot(valid & 4u)) +
          __popcll(__ballot(valid & 8u)) + __popcll(__ballot(valid & 16u)) + __popcll(__ballot(valid & 32u)) +
          __popcll(__ballot(valid & 64u)) + __popcll(__ballot(valid & 128u));
+}
+
+// ---- exact Voronoi ties by the reference's rule (ia3_kdtree.h) -----------------------------------------------------
+// One wave per seed that nbr_build_k flagged.  Every in-image voxel of the seed's ball that is exactly as far from the
+// seed as from its nearest other seed asks the tree (one query per lane, the lane's queue in LDS): the voxel stays with
+// the seed iff cKDTree.query(voxel) returns the seed.  Result: per slot a lane mask of lost tie voxels.
+constexpr int KDQ_CAP = 24;   // queue entries per lane (realistic fields need <= 5, a 4 600-seed blob of 6 px sigma 16)
+__global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, const int* __restrict__ tie_flag,
+                                                     unsigned long long* __restrict__ tie_lost, int* __restrict__ ctl_abort) {
+  __shared__ KdQEntry heap[KDQ_CAP][64];
+  const int i = blockIdx.x;
+  if (i >= fa.n || !tie_flag[i]) return;
+  const int lane = threadIdx.x & 63;
+  const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
+  const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
+  unsigned lost = 0, tied = 0;
+  each_neighbour(fa, i, [&](int j) {
+    const double sz = fa.seeds[3 * j], sx = fa.seeds[3 * j + 1], sy = fa.seeds[3 * j + 2];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int vi = lane + 64 * s;
+      if (vi < fa.nball) {
+        const BallOff o = ball_off(fa.ball, vi);
+          const double z = (double)(iz + o.dz), x = (double)(ix + o.dx), y = (double)(iy + o.dy);
+        const double dme = dist2_seq(c0[0], c0[1], c0[2], z, x, y);
+        const double dj = dist2_seq(sz, sx, sy, z, x, y);
+        if (dj < dme) lost |= 1u << s;
+        else if (dj == dme) tied |= 1u << s;
+      }
+    }
+    return true;
+  });
+  tied &= ~lost;   // a strictly nearer seed decides without the tree
+  bool overflow = false;
+#pragma unroll 1
+  for (int s = 0; s < SLOTS; ++s) {
+    bool lose = false;
+    const int vi = lane + 64 * s;
+    if ((tied >> s) & 1u) {
+      const BallOff o = ball_off(fa.ball, vi);
+      const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
+      if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
+        const double q[3] = {(double)z, (double)x, (double)y};
+        KdQueue<IA3_LDS KdQEntry*> queue((IA3_LDS KdQEntry*)&heap[0][lane], 64, KDQ_CAP);
+        const int w = kd_nearest(tree, q, 2.0 * fa.radius, queue);
+        overflow |= queue.overflow;
+        lose = w != i;
+      }
+    }
+    const unsigned long long m = __ballot(lose);
+    if (lane == 0) tie_lost[(size_t)i * SLOTS + s] = m;
+  }
+  if (__ballot(overflow) && lane == 0) atomicMax(ctl_abort, 3);
 }
 
 // ---- stage k >= 1 = one seed's refit in sweep k of repeatfit (:651-680) ---------------------------------
@@ -589,7 +745,8 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, IA3_LDS B
     const int vi = lane + 64 * s;
     vz[s] = 0; vx[s] = 0; vy[s] = 0; vals[s] = 0.0;
     if (vi < fa.nball) {
-      const int z = iz + fa.ball[4 * vi], x = ix + fa.ball[4 * vi + 1], y = iy + fa.ball[4 * vi + 2];
+      const BallOff o = ball_off(fa.ball, vi);
+      const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
       if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
         valid |= 1u << s;
         vals[s] = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
@@ -648,7 +805,9 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
   {
     double vals[SLOTS];
     n = mode == 1 ? gather_repeat(fa, i, &L->bl, valid, vals) : gather_first(fa, i, &L->bl, valid, vals);
+    IA3_STAMP(L, 1);   // gather
     if (n >= NP) wave_extremes(vals, valid, L);   // mode 2: the same ten smallest / largest values start both fits
+    IA3_STAMP(L, 2);   // extremes
   }
   int success_old = 0;
   float co0 = 0.f, co1 = 0.f, co2 = 0.f;
@@ -667,8 +826,7 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
     if (ok) nfev = wave_gaussfit(fa, L, valid, refit ? 2 : (fa.dtype == IA3_F32 ? 0 : 1), c0,
                                  refit ? fa.delta_repeat : fa.delta_first, n, mode == 2 && pass == 0);
   }
-  if (mode == 2 && ok && (threadIdx.x & 63) == 0) atomicAdd(&fa.counters[0], 1ull);   // two fits; store_result counts one
-  store_result(fa, i, L, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first);
+  if (mode == 2 && ok && (threadIdx.x & 63) == 0) L->tally[0] += 1ull;   // two fits; store_result counts one
   // convergence (:677-680): float32 centre differences, compared in float64
   bool cv = true;
   if (mode != 0 && ok && success_old) {
@@ -676,6 +834,8 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
     const float dist = (d0 * d0 + d1 * d1) + d2 * d2;
     cv = (double)dist < fa.dist_th2;
   }
+  store_result(fa, i, L, mode == 0 ? fa.delta_first : fa.delta_repeat, ok, n, nfev + nfev_first, mode != 0, cv);
+  IA3_STAMP(L, 11);   // store_result
   return cv;
 }
 
@@ -693,8 +853,9 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
 struct StageCtl {
   unsigned int claim;       // next work-list position
   int n_unconv;             // seeds not yet converged (repeat stages stop when it reaches 0)
-  int abort;                // set if a spin-wait exceeded its bound (never expected)
-  int pad;
+  int abort;                // 1: a spin-wait exceeded its bound (never expected); 2: exact Voronoi ties exist and no tie masks
+                            // were supplied (the host resolves them and launches again); 3: tie queue overflow
+  int ties;                 // nbr_build_k: some ball voxel is equidistant from its seed and another one
 };
 
 // wave-uniform poll: every lane issues the (same-address) load, lane 0's value decides for the whole wave
@@ -736,53 +897,57 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
   const int lane = threadIdx.x & 63;
   const int k = stage0 + (int)(pos / (unsigned)n);
   const int i = (int)(pos % (unsigned)n);   // seed order inside a stage: lower-index neighbours come first
+  // run_position (the fit) has ONE call site below: the kernel is instruction-cache bound, a second copy of the
+  // solver costs more than the branches around this one.
+  int mode;
   if (k == 0) {
     // sweep 1 is part of this launch and nothing overlaps this seed: both of its fits from this wave (run_position)
     const bool fused = fa.fuse && stage1 >= 2 && fa.nbr_cnt[i] == 0;
-    const bool cv = run_position(fa, L, i, fused ? 2 : 0);
-    if (fused) {
-      if (lane == 0) {
-        st_sc1(&fa.state[i].conv, cv ? 1 : 0);
-        atomicMax(fa.n_iter, 1);
-        if (cv) atomicSub(&ctl->n_unconv, 1);
-      }
-      // converged and without neighbours: no wave of this kernel will read this seed's rows or state again (its later
-      // positions leave at the done[] test below), so the hand-over needs no release; the end of the kernel publishes it
-      if (cv) publish_quiet(done, i, 1 << 20);
-      else publish(done, i, 2);
-    } else {
-      publish(done, i, 1);
+    mode = fused ? 2 : 0;
+  } else {
+    // sweep k of this seed already made by the wave of an earlier position (the fused first fit)
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
+    // nothing left to refit anywhere: every remaining position is a skip.  The claimed position is still
+    // published (as "all stages done") so that a block which passed this check earlier and waits on it can go on.
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
+      publish(done, i, 1 << 20);
+      return true;
     }
+    if (!wait_done(done, i, k, ctl)) return false;
+    // ... or made meanwhile: the wave that holds this seed's first fit may have been running until now
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return true; }   // converged: skipped (:652)
+    bool alive = true;
+    each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
+    if (!alive) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    mode = 1;
+  }
+  IA3_STAMP(L, 13);   // admission (dependency waits)
+  const bool cv = run_position(fa, L, i, mode);
+  if (mode == 0) {
+    publish(done, i, 1);
     return true;
   }
-  // sweep k of this seed already made by the wave of an earlier position (the fused first fit above)
-  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
-  // nothing left to refit anywhere: every remaining position is a skip.  The claimed position is still
-  // published (as "all stages done") so that a block which passed this check earlier and waits on it can go on.
-  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) {
-    publish(done, i, 1 << 20);
-    return true;
+  if (lane == 0) {   // (the seed's conv flag went out with its record, store_result)
+    const int sweep = mode == 2 ? 1 : k;
+    if (sweep > L->tally_iter) L->tally_iter = sweep;
+    if (cv) L->tally_conv += 1;
   }
-  if (!wait_done(done, i, k, ctl)) return false;
-  // ... or made meanwhile: the wave that holds this seed's first fit may have been running until now
-  if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (__builtin_amdgcn_readfirstlane(LDH(&fa.state[i].conv))) { publish(done, i, k + 1); return true; }   // converged: skipped (:652)
-  bool alive = true;
-  each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
-  if (!alive) return false;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const bool cv = run_position(fa, L, i, 1);
-  if (lane == 0) {
-    st_sc1(&fa.state[i].conv, cv ? 1 : 0);
-    atomicMax(fa.n_iter, k);
-    if (cv) atomicSub(&ctl->n_unconv, 1);
-  }
-  publish(done, i, k + 1);
+  // fused, converged and without neighbours: no wave of this kernel will read this seed's rows or state again (its later
+  // positions leave at the done[] test above), so the hand-over needs no release; the end of the kernel publishes it
+  if (mode == 2 && cv) publish_quiet(done, i, 1 << 20);
+  else publish(done, i, mode == 2 ? 2 : k + 1);
+  IA3_STAMP(L, 12);   // hand-over
+#ifdef IA3_FIT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IA3_STAMP(L, 14);   // drain of this position's stores (in the shipped kernel the next ticket draw waits for them)
+#endif
   return true;
 }
 
-// One wave per block, at most one block per SIMD of the device (the kernel's registers allow no more): every wave draws
+// One wave per block, at most two blocks per SIMD of the device (256 registers each): every wave draws
 // work-list positions until the list is empty.  A position is a TICKET drawn when its wave is ready for it, not a
 // block index: tickets are handed out in the order waves actually get to them, so everything a wave may wait for is
 // held by a wave that is running (or done) whatever order the dispatcher picks — no co-residency assumption.  (One block
@@ -793,14 +958,37 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
   IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
   const int lane = threadIdx.x & 63;
   const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
+  // exact Voronoi ties in this field and no tie masks yet: nothing is fitted; the host builds the seed tree, resolves the
+  // ties (voronoi_ties_k) and launches again
+  // (the legacy model's driver, Fitting_v3.py:39-46, takes cdist + argmin instead of a tree: lowest index, no masks)
+  if (stage0 == 0 && !fa.tie_lost && fa.variant == 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->ties, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    if (lane == 0) __hip_atomic_fetch_max(&ctl->abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (lane == 0) { L->tally[0] = L->tally[1] = L->tally[2] = 0ull; L->tally_conv = 0; L->tally_iter = 0; }
+#ifdef IA3_FIT_STAMPS
+  if (lane < 24) L->stamp[lane] = 0ull;
+  if (lane == 0) L->t_last = __builtin_readcyclecounter();
+#endif
+  __builtin_amdgcn_wave_barrier();
   for (;;) {
     unsigned pos = 0;
     if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
     pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
-    if (pos >= total) return;
-    if (!stage_position(fa, L, n, stage0, stage1, ctl, done, pos)) return;
+    IA3_STAMP(L, 0);   // ticket
+    if (pos >= total) break;
+    if (!stage_position(fa, L, n, stage0, stage1, ctl, done, pos)) break;
     __builtin_amdgcn_wave_barrier();
   }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {   // (n_unconv: later positions of this launch only lose an early exit while the count is stale-high)
+    if (L->tally[0]) { atomicAdd(&fa.counters[0], L->tally[0]); atomicAdd(&fa.counters[1], L->tally[1]); atomicAdd(&fa.counters[2], L->tally[2]); }
+    if (L->tally_conv) atomicSub(&ctl->n_unconv, L->tally_conv);
+    if (L->tally_iter) atomicMax(fa.n_iter, L->tally_iter);
+  }
+#ifdef IA3_FIT_STAMPS
+  if (lane < 24) atomicAdd(&fa.counters[8 + lane], L->stamp[lane]);   // the 256-byte counter slot holds 32 words
+#endif
 }
 
 // ---- standalone GaussianFit(im, X, center).fit() on explicit voxel lists (Fitting_v4.py:165-396) --
@@ -906,6 +1094,11 @@ struct ia3_fitter {
   bool first_done;
   StageCtl host_ctl;
   unsigned long long host_counters[3];   // copy of d_counters as of the last ia3_fit_results(_ex)
+  void *d_tie_flag, *d_tie_lost;   // per seed: has exact Voronoi ties (nbr_build_k) / lane masks of the tie voxels it loses
+  void* kd_block;      // device copy of the seed tree (nodes | permutation), made only when ties exist
+  bool ties_resolved;  // d_tie_lost is valid
+  std::vector<double> host_seeds;   // n x 3 when the seeds came from (or were fetched to) the host
+  std::vector<char> kd_stage;       // source of the asynchronous tree upload
   bool cached;         // host_stage holds [counters | n_iter | ctl | overflow | rows] of the finished fit (run_sweeps)
   std::vector<char> host_stage;  // source of the asynchronous setup upload; lives as long as the fitter
 };
@@ -923,6 +1116,7 @@ int build_ball(int r, std::vector<signed char>& ball) {
 
 int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
 int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets its first fit and sweep 1 from one wave
+int g_fit_maxfev = 0;   // IA3_DEBUG_FIT_MAXFEV: profiling only (splits the kernel time into a fixed and a per-evaluation part)
 int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the kernel's 256 registers allow two)
 
 FitArgs make_args(const ia3_fitter* f) {
@@ -930,7 +1124,8 @@ FitArgs make_args(const ia3_fitter* f) {
   a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
   a.n = f->n; a.fuse = g_fit_fuse; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
-  a.ball = (const signed char*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
+  a.ball = (const int*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
+  a.tie_lost = f->ties_resolved ? (const unsigned long long*)f->d_tie_lost : nullptr;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
   a.conv = (unsigned char*)f->d_conv; a.n_iter = (int*)f->d_niter; a.counters = (unsigned long long*)f->d_counters;
   a.min_ws = f->prm.min_w * f->prm.min_w; a.max_ws = f->prm.max_w * f->prm.max_w; a.init_w = f->prm.init_w;
@@ -949,6 +1144,7 @@ FitArgs make_args(const ia3_fitter* f) {
       a.iw[k] = log((a.max_ws - w * w) / (w * w - a.min_ws));
     }
   }
+  if (g_fit_maxfev > 0) a.maxfev = g_fit_maxfev;
   return a;
 }
 
@@ -959,6 +1155,7 @@ extern "C" {
 void ia3_fit_destroy(ia3_fitter* f) {
   if (!f) return;
   if (f->pool) ws_put(f->pool);   // back to the scratch cache; reuse is stream-ordered
+  if (f->kd_block) ws_put(f->kd_block);
   delete f;
 }
 
@@ -1004,7 +1201,8 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf;
   const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
   const size_t b_ncnt = al(sizeof(int) * (size_t)n), b_nidx = al(sizeof(int) * MAXNB * (size_t)n);
-  f->pool_bytes = up_bytes + zero_bytes + b_ps + b_ncnt + b_nidx;
+  const size_t b_tflag = al(sizeof(int) * (size_t)n), b_tlost = al(sizeof(unsigned long long) * SLOTS * (size_t)n);
+  f->pool_bytes = up_bytes + zero_bytes + b_ps + b_ncnt + b_nidx + b_tflag + b_tlost;
   f->pool = ws_get(f->pool_bytes);
   if (!f->pool) { delete f; return IA3_ENOMEM; }
   char* base = (char*)f->pool;
@@ -1025,13 +1223,16 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   f->d_nbr_overflow = base + o; o += b_ovf;
   f->d_ps = base + o; o += b_ps;
   f->d_nbr_cnt = base + o; o += b_ncnt;
-  f->d_nbr_idx = base + o;
+  f->d_nbr_idx = base + o; o += b_nidx;
+  f->d_tie_flag = base + o; o += b_tflag;
+  f->d_tie_lost = base + o;
   hipStream_t st = stream();
   hipError_t e = hipSuccess;
   if (n && centers_zxy) {   // seeds from the host: staged in the fitter (the copy is asynchronous)
     std::vector<char>& host = f->host_stage;
     host.assign(sizeof(double) * 3 * (size_t)n, 0);
     memcpy(host.data(), centers_zxy, host.size());
+    f->host_seeds.assign(centers_zxy, centers_zxy + 3 * (size_t)n);
     e = hipMemcpyAsync(f->d_seeds, host.data(), host.size(), hipMemcpyHostToDevice, st);
   }
   if (e != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "fitter setup failed: %s", hipGetErrorString(e)); }
@@ -1055,7 +1256,8 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
     const double rr = 2.0 * p->radius_fit;
     ProfScope ps("nbr_build");
     hipLaunchKernelGGL(nbr_build_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)f->d_seeds, n, rr * rr,
-                       (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow);
+                       (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow, (const int*)d_ball, nball,
+                       im->Z, im->X, im->Y, (int*)f->d_tie_flag, &((StageCtl*)f->d_ctl)->ties);
   }
   {
     hipError_t le = hipGetLastError();
@@ -1076,6 +1278,7 @@ int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const 
 namespace ia3k {
 void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
 void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
+void set_fit_maxfev(int n) { g_fit_maxfev = n; }
 void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
 void fit_host_counters(const ia3_fitter* f, long long out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
@@ -1123,23 +1326,75 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
   return IA3_OK;
 }
 
+// Exact Voronoi ties (nbr_build_k flagged them, the first launch left without fitting anything): build the seed tree with
+// cKDTree's layout on the host (kdtree.cpp), hand it to voronoi_ties_k, which leaves per seed the lane masks of the tie
+// voxels it loses.  Fields without ties — every isolated-spot field — never come here.
+static int resolve_ties(ia3_fitter* f) {
+  hipStream_t st = stream();
+  const int n = f->n;
+  if (f->host_seeds.empty()) {   // the seed list never left the device: fetch it now
+    f->host_seeds.resize(3 * (size_t)n);
+    IA3_HIP(hipMemcpyAsync(f->host_seeds.data(), f->d_seeds, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+    IA3_HIP(hipStreamSynchronize(st));
+  }
+  std::vector<ia3::KdNode> nodes;
+  std::vector<int> perm;
+  KdTree t;
+  ia3k::kd_build(f->host_seeds.data(), n, nodes, perm, t.mins, t.maxes);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t bn = al(nodes.size() * sizeof(ia3::KdNode)), bi = al(perm.size() * sizeof(int));
+  if (f->kd_block) { ws_put(f->kd_block); f->kd_block = nullptr; }
+  f->kd_block = ws_get(bn + bi);
+  if (!f->kd_block) return IA3_ENOMEM;
+  f->kd_stage.resize(bn + bi);
+  memcpy(f->kd_stage.data(), nodes.data(), nodes.size() * sizeof(ia3::KdNode));
+  memcpy(f->kd_stage.data() + bn, perm.data(), perm.size() * sizeof(int));
+  IA3_HIP(hipMemcpyAsync(f->kd_block, f->kd_stage.data(), bn + bi, hipMemcpyHostToDevice, st));
+  t.nodes = (const ia3::KdNode*)f->kd_block;
+  t.indices = (const int*)((char*)f->kd_block + bn);
+  t.data = (const double*)f->d_seeds;
+  t.n = n;
+  FitArgs a = make_args(f);
+  {
+    ProfScope ps("voronoi_ties");
+    hipLaunchKernelGGL(voronoi_ties_k, dim3((unsigned)n), dim3(64), 0, st, a, t, (const int*)f->d_tie_flag,
+                       (unsigned long long*)f->d_tie_lost, &((StageCtl*)f->d_ctl)->abort);
+  }
+  IA3_KCHECK();
+  f->ties_resolved = true;
+  return IA3_OK;
+}
+
+static int check_ctl(const StageCtl& hc) {
+  if (hc.abort == 3) return set_error(IA3_EUNSUPPORTED, "Voronoi tie query exceeded its queue (%d entries per voxel)", KDQ_CAP);
+  if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+  return IA3_OK;
+}
+
 // Sweeps are launched two at a time and the next pair only while some seed is still unconverged: a launch costs
 // one block per (stage, seed) even for converged seeds, and most fields converge after the first sweep.  The check
 // between pairs fetches the row table along with the control words: when nothing is left to refit (the common case)
 // ia3_fit_results finds everything on the host already and the fit costs ONE synchronisation.
-static int run_sweeps(ia3_fitter* f, int stage, bool fresh) {
-  const int last = f->prm.n_max_iter + 2;   // sweeps 1 .. n_max_iter+1 (Fitting_v4.py:683)
+static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
+  if (last < 0) last = f->prm.n_max_iter + 2;   // sweeps 1 .. n_max_iter+1 (Fitting_v4.py:683)
   f->cached = false;
   while (stage < last) {
     const int s1 = stage + 2 < last ? stage + 2 : last;
     int rc = launch_stages(f, stage, s1, fresh); if (rc) return rc;
-    fresh = false;
-    stage = s1;
-    if (stage >= last) break;
+    const bool with_first = stage == 0 && !f->ties_resolved;   // this launch may have left at once: exact Voronoi ties
+    if (s1 >= last && !with_first) break;
     rc = fetch_block(f, true); if (rc) return rc;
     StageCtl hc;
     memcpy(&hc, f->host_stage.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));
-    if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+    if (hc.abort == 2 && with_first) {
+      rc = resolve_ties(f); if (rc) return rc;
+      fresh = true;
+      continue;   // the same stages again, now with the tie masks
+    }
+    rc = check_ctl(hc); if (rc) return rc;
+    fresh = false;
+    stage = s1;
+    if (stage >= last) { f->cached = true; break; }
     if (hc.n_unconv <= 0) { f->cached = true; break; }
   }
   return IA3_OK;
@@ -1150,7 +1405,8 @@ int ia3_fit_first(ia3_fitter* f) {
   f->cached = false;
   if (f->n > 0) {
     if (!f->pristine) IA3_HIP(hipMemsetAsync(f->d_done, 0, sizeof(int) * (size_t)f->n, stream()));
-    int rc = launch_stages(f, 0, 1, true); if (rc) return rc;
+    int rc = run_sweeps(f, 0, true, 1); if (rc) return rc;
+    f->cached = false;   // ia3_fit_repeat follows
   }
   f->first_done = true;
   return IA3_OK;
@@ -1222,7 +1478,7 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
     memcpy(&ovf, hb.data() + ((char*)f->d_nbr_overflow - (char*)f->d_counters), sizeof(int));
     if (rows) memcpy(ps, hb.data() + head, rows);
   }
-  if (hc.abort) return set_error(IA3_EHIP, "fit kernel aborted: a dependency wait exceeded its bound");
+  { const int rc_ = check_ctl(hc); if (rc_) return rc_; }
   (void)ovf;   // > MAXNB neighbours somewhere: those seeds scanned the seed list instead (each_neighbour); not an error
   if (success) for (int i = 0; i < f->n; ++i) success[i] = (uint8_t)stv[i].success;
   return IA3_OK;
@@ -1239,6 +1495,13 @@ int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev) {
   IA3_HIP(hipMemcpy(c, f->d_counters, sizeof(c), hipMemcpyDeviceToHost));
   if (total_fits) *total_fits = (int64_t)c[0];
   if (total_nfev) *total_nfev = (int64_t)c[1];
+  return IA3_OK;
+}
+
+int ia3_fit_counters(ia3_fitter* f, uint64_t* out32) {
+  if (!f || !out32) return set_error(IA3_EINVAL, "null argument");
+  IA3_HIP(hipStreamSynchronize(stream()));
+  IA3_HIP(hipMemcpy(out32, f->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return IA3_OK;
 }
 

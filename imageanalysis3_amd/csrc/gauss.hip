@@ -19,6 +19,7 @@
 //     row-coalesced.  Long filters (VALU-bound, R >= 16): the axis-1 pass stores each plane transposed and the
 //     axis-2 pass is the strided kernel over that transposed plane, storing transposed again.
 #include "ia3_gauss.h"
+#include <unistd.h>
 #include <cstring>
 #include <mutex>
 
@@ -588,7 +589,14 @@ const int* cached_border_map(int count, int R, int len, int mode) {
   struct Key { int count, R, len, mode; const int* d; };
   static std::mutex mu;
   static std::vector<Key> maps;
+  static pid_t owner_pid = 0;
+  static int owner_dev = -1;
   std::lock_guard<std::mutex> g(mu);
+  {   // device pointers of another process (fork) or another device mean nothing here: start over, as get_plan does
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (owner_pid != getpid() || owner_dev != dev) { maps.clear(); owner_pid = getpid(); owner_dev = dev; }
+  }
   for (const Key& k : maps)
     if (k.count == count && k.R == R && k.len == len && k.mode == mode) return k.d;
   std::vector<int> h(count);
@@ -615,13 +623,15 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
     static_assert(RF == 3 && RB == 30, "the radii gauss_col.inc instantiates");
     if constexpr (std::is_same_v<T, float>) rc = folded_pair_f32(src, Z, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y);
     else rc = folded_pair_u16(src, Z, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y);
-    if (rc == -1) return 1;
   }
-  if (rc) return rc;
+  if (rc) return rc;   // FOLD_NOT_COVERED, or an error (negative)
   // axes 1 and 2 of the short filter: tmp -> dst_front, on the auxiliary stream (the caller goes on with dst_zp)
   int TY, ntile;
   ia3k::dog_pair_tiles(X, Y, &TY, &ntile, nullptr);
   const int xseg = 128;   // a multiple of the 16-row step: steps start on multiples of 16
+  // the candidate detector (seed_cand3_tiled) indexes the table of step maxima as [plane][row / 16][column / 64]: that is
+  // what this launch writes only while a y tile holds whole 64-column groups and segments start on multiples of 16 rows
+  if (TY % 64 != 0 || xseg % 16 != 0) return ia3rt::set_error(IA3_EUNSUPPORTED, "plane-wise filter geometry does not match the detector's tiles");
   const int cx = X + 2 * RF + 32, cy = ntile * TY + 2 * RF;
   const int* mx = cached_border_map(cx, RF, X, IA3_MODE_REFLECT);
   const int* my = cached_border_map(cy, RF, Y, IA3_MODE_REFLECT);
@@ -634,7 +644,7 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
     dim3 g(8 * ((tiles + 7) / 8), 1, (unsigned)Z);   // tiles, XCD-grouped inside the kernel
     hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg, tmax);
   }
-  return aux.ok ? 0 : -1;   // -1: no auxiliary stream, everything ran on the main one (nothing to join)
+  return aux.ok ? 0 : FOLD_NO_FORK;
 }
 
 // axes: bit 0 = the axis-0 pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst)
@@ -696,12 +706,12 @@ int run_fixed(const T* src, int Z, int X, int Y, const Taps& t, int mode, T* dst
     if constexpr (R >= 16) {
       if (g_fold_on && cert >= 0 && (size_t)Z * plane * sizeof(T) < 0x7fffffffULL) {   // short stacks: the column-in-registers form (guard: 3R + Z + 3 ulps, see the kernel; 32-bit buffer offsets)
         const int fc = g_cert == -2 ? 3 * R + Z + 16 : cert;
-        int rc = -1;
+        int rc = FOLD_NOT_COVERED;
         if constexpr (R == 30) {   // the depths instantiated (IA3_FOLD_DEPTHS, radius 30); other stacks take the sliding window
           if constexpr (std::is_same_v<T, float>) rc = folded_axis0_f32(src, Z, plane, t, mode, dst, s, fc);
           else rc = folded_axis0_u16(src, Z, plane, t, mode, dst, s, fc);
         }
-        if (rc > 0) return rc;
+        if (rc < 0) return rc;
         done = rc == 0;
       }
     }
@@ -846,9 +856,9 @@ int gauss_dog_pair(const void* src, int dtype, int Z, int X, int Y, const double
   int rc;
   if (dtype == IA3_F32) rc = dog_pair_t<float>((const float*)src, Z, X, Y, ft, bt, (float*)dst_front, (float*)dst_zp, (float*)tmp, s, tmax, smin, sabs);
   else rc = dog_pair_t<uint16_t>((const uint16_t*)src, Z, X, Y, ft, bt, (uint16_t*)dst_front, (uint16_t*)dst_zp, (uint16_t*)tmp, s, tmax, smin, sabs);
-  if (rc == 1) return 1;
-  if (rc > 0) return rc;
-  *forked = rc == 0;
+  if (rc < 0) return rc;                       // IA3 error codes are negative: the filtered stacks were not produced
+  if (rc == FOLD_NOT_COVERED) return 1;
+  *forked = rc == 0;                           // FOLD_NO_FORK: queued on the main stream, nothing to join
   IA3_KCHECK();
   return IA3_OK;
 }
@@ -887,6 +897,7 @@ int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_FFT_C2C) { ia3k::set_fft_c2c(value); return 0; }
   if (key == IA3_TUNE_FIT_FUSE) { ia3k::set_fit_fuse(value); return 0; }
   if (key == IA3_TUNE_FIT_WAVES) { ia3k::set_fit_waves(value); return 0; }
+  if (key == IA3_DEBUG_FIT_MAXFEV) { ia3k::set_fit_maxfev(value); return 0; }
   return set_error(IA3_EINVAL, "unknown tuning key");
 }
 

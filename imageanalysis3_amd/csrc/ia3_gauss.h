@@ -92,7 +92,10 @@ inline bool fold_depth(int Z) {
 
 
 // entry points of gauss_col_f32.hip / gauss_col_u16.hip (one translation unit per dtype: the kernels are long straight-line
-// code and compile for ~12 s each).  Return 0, an error code, or -1 when the depth is not instantiated.
+// code and compile for ~12 s each).  Return 0, a (negative) IA3 error code, or FOLD_NOT_COVERED when the depth is not
+// instantiated.  IA3 error codes are negative, the two private "nothing wrong, take the other path" codes positive.
+constexpr int FOLD_NOT_COVERED = 1;   // this depth / these radii have no column kernel: nothing was queued
+constexpr int FOLD_NO_FORK = 2;       // dog_pair_t: no auxiliary stream, everything ran on the main one (nothing to join)
 int folded_axis0_f32(const float* src, int Z, size_t plane, const Taps& t, int mode, float* dst, hipStream_t s, int cert);
 int folded_axis0_u16(const uint16_t* src, int Z, size_t plane, const Taps& t, int mode, uint16_t* dst, hipStream_t s, int cert);
 int folded_pair_f32(const float* src, int Z, size_t plane, const Taps& bt, float* dst, const Taps& ft, float* fdst, hipStream_t s, int cert,

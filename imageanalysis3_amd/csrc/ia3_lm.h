@@ -37,7 +37,9 @@ IA3_HD constexpr int tri(int i, int j) {  // packed upper-triangle index, i <= j
 
 #if defined(__HIPCC__) || defined(__clang__)
 #define IA3_UNROLL _Pragma("unroll")
+#define IA3_NOUNROLL _Pragma("clang loop unroll(disable)")
 #else
+#define IA3_NOUNROLL
 #define IA3_UNROLL _Pragma("GCC unroll 16")
 #endif
 
@@ -181,6 +183,7 @@ IA3_HD void lm_par(const double* A, const double* g, const double* diag, double 
   Chol c;
   double t1[NP], t2[NP];
   double parl = 0.0, paru = 0.0, fp = 0.0;
+  IA3_NOUNROLL
   for (int iter = 0;; ++iter) {
     double pf = 0.0;
     if (iter > 0) {
@@ -251,6 +254,7 @@ IA3_HD LMResult lm_solve(Eval& ev, LMWork& w, double ftol, double xtol, double g
   double* At = w.A1; double* gt = w.g1;    // trial point
   double fnorm = 0.0, par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0, pnorm = 0.0, jp2 = 0.0;
   bool first = true;
+  IA3_NOUNROLL
   for (;;) {
     const double fnorm1 = ev.eval(first ? w.x : w.xt, At, gt);
     ++r.nfev;

@@ -750,6 +750,12 @@ void set_seed_dense(int on) { g_seed_dense = on ? 1 : 0; }
 
 constexpr unsigned LAZY_CAP = 1u << 17;   // first-stage candidates of the lazy background path (2 MB)
 
+// layout of the lazy filter's bound block: [nb float block minima | nb float block magnitudes | pad to 8 bytes | nb double
+// lower bounds]; the block itself is 256-byte aligned (scratch cache), so the doubles are 8-byte aligned for every nb
+inline size_t lazy_bound_offset(size_t nb) { return 2 * ((nb + 1) & ~(size_t)1); }   // in floats
+inline double* lazy_bound_ptr(void* bnd, size_t nb) { return (double*)((float*)bnd + lazy_bound_offset(nb)); }
+inline size_t lazy_bound_bytes(size_t nb) { return lazy_bound_offset(nb) * sizeof(float) + nb * sizeof(double); }
+
 template <class T>
 static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, const double* w, int R, int edge,
                         double th_low, void* bnd, Cand0* c0, SeedCtl* ctl0, Cand* out, unsigned capacity, SeedCtl* ctl,
@@ -759,7 +765,7 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
   const size_t nb = (size_t)Z * nbx * nby;
   float* bmin = (float*)bnd;
   float* babs = bmin + nb;
-  double* lb = (double*)(babs + nb + (nb & 1));
+  double* lb = lazy_bound_ptr(bnd, nb);
   if (stage == 0) {   // needs only the axis-0 result: queued before the front filter is joined
     ProfScope ps("seed_blockmin");
     constexpr int V = 16 / (int)sizeof(T);
@@ -831,7 +837,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       if (!(wb[j] >= 0.0) || wb[j] != wb[2 * Rb - j]) lazy = false;
   const int Bk = Rb <= 32 ? 32 : 64;
   const size_t nblk = (size_t)Z * ((X + Bk - 1) / Bk) * ((Y + Bk - 1) / Bk);
-  Scratch bnd(lazy ? (nblk + (nblk & 1)) * 2 * sizeof(float) + nblk * sizeof(double) : 256);
+  Scratch bnd(lazy ? lazy_bound_bytes(nblk) : 256);
   Scratch c0buf(lazy ? (size_t)LAZY_CAP * sizeof(Cand0) : 256);
   if (!bnd.p || !c0buf.p) return IA3_ENOMEM;
   // candidate buffer = [SeedCtl out | SeedCtl lazy | Cand x capacity] and the workspace of the device-side finish; they are
@@ -899,7 +905,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       ProfScope ps("seed_blockmin");
       const int nbx = (X + 31) / 32, nby = Y / 32;
       const size_t nb = (size_t)Z * nbx * nby;
-      double* lb = (double*)((float*)bnd.p + 2 * nb + (nb & 1));   // as launch_lazy lays the block out
+      double* lb = lazy_bound_ptr(bnd.p, nb);   // as launch_lazy lays the block out
       const size_t nt = (size_t)DOG_PAIR_ZGROUPS * nbx * nby;
       hipLaunchKernelGGL(stripbound_k, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, (const float*)smin_d, (const float*)sabs_d, Z, X,
                          nbx, nby, (int)DOG_PAIR_ZGROUPS, (int)(im->dtype == IA3_U16), lb);

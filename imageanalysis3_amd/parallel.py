@@ -33,31 +33,52 @@ def pad_tables(tables, max_seeds):
     return out, counts
 
 
-def gather_spot_tables(rows, max_seeds, world_size=None):
-    """All-gather one (n,11) table (or a list of per-FOV tables) per rank.
+def gather_spot_tables(rows, max_seeds, world_size=None, return_counts=False):
+    """All-gather the per-FOV tables of every rank: ``rows`` is one (n,11) table or a list of them (any number per rank,
+    none included — the reference's pool takes any task count, classes/field_of_view.py:1129-1142).
 
-    Returns the concatenated (sum n, 11) float32 table in (rank, fov) order on every rank.  With a
-    single process this is a no-op copy; otherwise two collectives: counts, then the padded block."""
+    Returns the concatenated (sum n, 11) float32 table in (rank, fov) order on every rank (with ``return_counts`` also
+    the list of per-rank int32 count vectors).  With a single process this is a no-op copy; otherwise one tiny
+    all-reduce (the largest number of FOVs any rank holds, so that every rank contributes blocks of the same shape —
+    RCCL has no gatherv) and two ``all_gather_into_tensor`` collectives: the counts ``int32 [F]`` and the zero-padded
+    block ``float32 [F, max_seeds, 11]``, the reference's on-disk layout (:1361-1382).  With the ``nccl`` (= RCCL)
+    backend both live on the device from one upload to one download; gloo stays on the host."""
     tables = rows if isinstance(rows, (list, tuple)) else [rows]
+    tables = [np.asarray(t, dtype=np.float32).reshape(-1, 11) for t in tables]
     if world_size is None:
         import torch.distributed as dist
         world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if world_size == 1:
-        return np.concatenate([np.asarray(t, dtype=np.float32).reshape(-1, 11) for t in tables], axis=0)
+        out = np.concatenate(tables, axis=0) if tables else np.zeros((0, 11), dtype=np.float32)
+        return (out, [np.array([len(t) for t in tables], dtype=np.int32)]) if return_counts else out
     import torch
     import torch.distributed as dist
-    padded, counts = pad_tables(tables, max_seeds)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t_counts = torch.from_numpy(counts).to(dev)
+    nccl = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    # every rank contributes F blocks: F = the most FOVs any rank holds, missing ones are empty (count 0)
+    t_f = torch.tensor([len(tables)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t_f, op=dist.ReduceOp.MAX)
+    F = int(t_f.item())
+    if F == 0:
+        out = np.zeros((0, 11), dtype=np.float32)
+        return (out, [np.zeros(0, np.int32) for _ in range(world_size)]) if return_counts else out
+    padded, counts = pad_tables(tables + [np.zeros((0, 11), np.float32)] * (F - len(tables)), max_seeds)
+    nmine = np.array([len(tables)], dtype=np.int32)
+    head = np.concatenate([nmine, counts])                     # [number of real FOVs | counts of the F blocks]
+    t_head = torch.from_numpy(head).to(dev)
     t_pad = torch.from_numpy(padded).to(dev)
-    l_counts = [torch.empty_like(t_counts) for _ in range(world_size)]
-    l_pad = [torch.empty_like(t_pad) for _ in range(world_size)]
-    dist.all_gather(l_counts, t_counts)
-    dist.all_gather(l_pad, t_pad)
-    all_counts = torch.stack(l_counts).cpu().numpy()
-    all_pad = torch.stack(l_pad).cpu().numpy()
-    parts = []
+    # (outputs are the rank blocks concatenated along the first axis: the form both backends accept)
+    g_head = torch.empty((world_size * (F + 1),), dtype=torch.int32, device=dev)
+    g_pad = torch.empty((world_size * F, int(max_seeds), 11), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(g_head, t_head)
+    dist.all_gather_into_tensor(g_pad, t_pad)
+    all_head = g_head.cpu().numpy().reshape(world_size, F + 1)
+    all_pad = g_pad.cpu().numpy().reshape(world_size, F, int(max_seeds), 11)
+    parts, per_rank = [], []
     for r in range(world_size):
-        for f in range(all_counts.shape[1]):
-            parts.append(all_pad[r, f, :all_counts[r, f]])
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, 11), dtype=np.float32)
+        nr = int(all_head[r, 0])
+        per_rank.append(all_head[r, 1:1 + nr].astype(np.int32))
+        for f in range(nr):
+            parts.append(all_pad[r, f, :all_head[r, 1 + f]])
+    out = np.concatenate(parts, axis=0) if parts else np.zeros((0, 11), dtype=np.float32)
+    return (out, per_rank) if return_counts else out

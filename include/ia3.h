@@ -87,6 +87,9 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_FIT_WAVES: persistent wavefronts of the fit kernel per SIMD, 1 or 2 (default 2: the kernel is built for 256
  * registers).  Tables are identical bit for bit. */
 #define IA3_TUNE_FIT_WAVES 10
+/* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
+ * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */
+#define IA3_DEBUG_FIT_MAXFEV 100
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */
@@ -262,6 +265,9 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
 /* nfev: n ints, model evaluations spent on each seed so far (first fit + sweeps); MINPACK stops a fit at maxfev */
 int ia3_fit_nfev(ia3_fitter* f, int* nfev);
 int ia3_fit_stats(ia3_fitter* f, int64_t* total_fits, int64_t* total_nfev);
+/* the fitter's 32 device counters: [0] fits, [1] evaluations, [2] voxel evaluations; [8..31] shader cycles per phase in
+ * a profiling build of the fit kernel (-DIA3_FIT_STAMPS, scripts/fit_stamps.sh), zero in the shipped library */
+int ia3_fit_counters(ia3_fitter* f, uint64_t* out32);
 void ia3_fit_destroy(ia3_fitter* f);
 
 /* External/Fitting_v4.py:165-396 GaussianFit(im, X, center, ...).fit() for a batch of explicit voxel lists

@@ -62,6 +62,9 @@ CASES = {
                     n_territories=6),
     "hot_u16": dict(shape=[30, 128, 128], n=30, seed=6, layout="isolated", dtype="uint16",
                     hot_columns=[[40, 41, 9000], [90, 17, 12000]]),
+    # layout B of SURVEY.md §8(d) at 50 x 256 x 256: 16 territories of ~15 spots, exact Voronoi ties in most of them
+    "club_f32": dict(shape=[50, 256, 256], n=240, seed=8, layout="clustered", dtype="float32",
+                     n_territories=16),
 }
 
 
@@ -322,6 +325,54 @@ def seg_golden(meta):
     print("seg", {k: np.shape(v) for k, v in d.items()})
 
 
+def fit_case_golden(R, name, spec):
+    """Seed tables, first / final rows, fit_fov_image tables and a few Voronoi voxel sets of one case, all from the
+    reference's own functions."""
+    fit, F4 = R.fitting, R.F4
+    im = case_image(spec)
+    d = {}
+    d["seeds_h"] = fit.get_seeds(im, th_seed=600, return_h=True)
+    d["seeds_nodyn"] = fit.get_seeds(im, th_seed=600, use_dynamic_th=False, return_h=True)
+    d["seeds_hi_th"] = fit.get_seeds(im, th_seed=9000, return_h=True, min_dynamic_seeds=5)
+    d["seeds_nohot"] = fit.get_seeds(im, th_seed=600, remove_hot_pixel=False, return_h=True)
+    d["seeds_top10"] = fit.get_seeds(im, th_seed=600, max_num_seeds=10, return_h=True)
+    cen = [s // 2 for s in spec["shape"]]
+    d["sel_center"] = np.array(cen)
+    d["seeds_sel"] = fit.get_seeds(im, th_seed=600, sel_center=cen, seed_radius=20, return_h=True)
+    d["seeds_edge0"] = fit.get_seeds(im, th_seed=600, min_edge_distance=0, return_h=True)
+    # fitting
+    seeds = fit.get_seeds(im, th_seed=600)
+    fitter = F4.iter_fit_seed_points(im, seeds.T, radius_fit=5)
+    quiet(fitter.firstfit)
+    d["first_ps"] = np.array(fitter.ps, dtype=np.float32)
+    d["first_nvox"] = np.array([len(g[0]) for g in fitter.gparms])
+    quiet(fitter.repeatfit)
+    d["final_ps"] = np.array(fitter.ps, dtype=np.float32)
+    d["n_iter"] = np.array(fitter.n_iter)
+    d["table"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    d["table_max20"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=20, verbose=False)
+    d["centers"] = quiet(fit.get_centers, im, th_seed=600)
+    d["sparse"] = fit.select_sparse_centers(d["centers"], distance_th=25)
+    # a few voxel sets (Voronoi cells) of the first fit
+    for k in range(min(3, len(fitter.gparms))):
+        d["gp%d_X" % k] = np.array(fitter.gparms[k][1])
+        d["gp%d_im" % k] = np.array(fitter.gparms[k][0])
+    np.savez_compressed(os.path.join(OUT, "fit_%s.npz" % name), **d)
+    print(name, "seeds", len(d["seeds_h"]), "table", d["table"].shape, "n_iter", fitter.n_iter)
+
+
+def one_case(name):
+    """python oracle/make_golden.py case:<name> — one fitting case, meta.json updated in place."""
+    R = ref_loader.load_reference()
+    fit_case_golden(R, name, CASES[name])
+    mp = os.path.join(OUT, "meta.json")
+    with open(mp) as f:
+        meta = json.load(f)
+    meta["cases"][name] = CASES[name]
+    with open(mp, "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load_reference()
@@ -332,36 +383,7 @@ def main():
 
     # ---------------- seeding + fitting tables --------------------------------------------
     for name, spec in CASES.items():
-        im = case_image(spec)
-        d = {}
-        d["seeds_h"] = fit.get_seeds(im, th_seed=600, return_h=True)
-        d["seeds_nodyn"] = fit.get_seeds(im, th_seed=600, use_dynamic_th=False, return_h=True)
-        d["seeds_hi_th"] = fit.get_seeds(im, th_seed=9000, return_h=True, min_dynamic_seeds=5)
-        d["seeds_nohot"] = fit.get_seeds(im, th_seed=600, remove_hot_pixel=False, return_h=True)
-        d["seeds_top10"] = fit.get_seeds(im, th_seed=600, max_num_seeds=10, return_h=True)
-        cen = [s // 2 for s in spec["shape"]]
-        d["sel_center"] = np.array(cen)
-        d["seeds_sel"] = fit.get_seeds(im, th_seed=600, sel_center=cen, seed_radius=20, return_h=True)
-        d["seeds_edge0"] = fit.get_seeds(im, th_seed=600, min_edge_distance=0, return_h=True)
-        # fitting
-        seeds = fit.get_seeds(im, th_seed=600)
-        fitter = F4.iter_fit_seed_points(im, seeds.T, radius_fit=5)
-        quiet(fitter.firstfit)
-        d["first_ps"] = np.array(fitter.ps, dtype=np.float32)
-        d["first_nvox"] = np.array([len(g[0]) for g in fitter.gparms])
-        quiet(fitter.repeatfit)
-        d["final_ps"] = np.array(fitter.ps, dtype=np.float32)
-        d["n_iter"] = np.array(fitter.n_iter)
-        d["table"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=None, verbose=False)
-        d["table_max20"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=20, verbose=False)
-        d["centers"] = quiet(fit.get_centers, im, th_seed=600)
-        d["sparse"] = fit.select_sparse_centers(d["centers"], distance_th=25)
-        # a few voxel sets (Voronoi cells) of the first fit
-        for k in range(min(3, len(fitter.gparms))):
-            d["gp%d_X" % k] = np.array(fitter.gparms[k][1])
-            d["gp%d_im" % k] = np.array(fitter.gparms[k][0])
-        np.savez_compressed(os.path.join(OUT, "fit_%s.npz" % name), **d)
-        print(name, "seeds", len(d["seeds_h"]), "table", d["table"].shape, "n_iter", fitter.n_iter)
+        fit_case_golden(R, name, spec)
 
     # ---------------- single-spot known answer (GaussianFit) --------------------------------
     shape = (30, 64, 64)
@@ -464,6 +486,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate single fixtures: python oracle/make_golden.py seg_golden ...
         for _name in sys.argv[1:]:
-            globals()[_name]({})
+            if _name.startswith("case:"):
+                one_case(_name[5:])
+            else:
+                globals()[_name]({})
     else:
         main()

@@ -36,3 +36,18 @@ for waves in (1, 2, 1, 2):
     print("waves/SIMD %d: seeds %d sweeps %d fits %d nfev %d  fit_run best %.3f ms" % (waves, len(seeds), it.value, a.value, b.value, best), flush=True)
 same = np.array_equal(tables[1], tables[2], equal_nan=True)
 print("tables identical:", same)
+# fixed vs per-evaluation part (IA3_DEBUG_FIT_MAXFEV: results differ, timing only)
+if os.environ.get("AB_MAXFEV", "1") == "1":
+    L.check(lib.ia3_set_tuning(10, 2))
+    for mf in (1, 2, 3, 4, 6, 0):
+        L.check(lib.ia3_set_tuning(100, mf))
+        best = 1e9
+        for rep in range(3):
+            hh = C.c_void_p()
+            L.check(lib.ia3_fit_create(st._h, L.dptr(seeds), len(seeds), C.byref(fp), C.byref(hh)))
+            t0 = T(); L.check(lib.ia3_fit_run(hh)); t1 = T()
+            a, b = C.c_int64(0), C.c_int64(0); lib.ia3_fit_stats(hh, C.byref(a), C.byref(b))
+            lib.ia3_fit_destroy(hh)
+            best = min(best, 1e3 * (t1 - t0))
+        print("maxfev %d: fits %d nfev %d  fit_run best %.3f ms" % (mf, a.value, b.value, best), flush=True)
+    L.check(lib.ia3_set_tuning(100, 0))

@@ -45,7 +45,7 @@ def test_bench_fov_window_vs_oracle(dtype):
     win = np.ascontiguousarray(im[:, :WIN, :WIN])
     # ---- oracle on the window -------------------------------------------------------------------------------------
     so = O.get_seeds(win, th_seed=600.0, return_h=True)
-    fo = O.iter_fit_seed_points(win, so[:, :3].T, voronoi="lowest_index")
+    fo = O.iter_fit_seed_points(win, so[:, :3].T)
     fo.firstfit()
     fo.repeatfit()
     po = np.array(fo.ps, dtype=np.float64)
@@ -239,8 +239,8 @@ def test_neighbour_scan_equals_neighbour_list():
 
 def test_dense_grid_beyond_neighbour_list_vs_oracle():
     """A 7 x 7 x 7 lattice of narrow spots 3.5 voxels apart: the inner seeds have ~90 other seeds within 2 r = 10
-    voxels, more than the neighbour list holds.  Voronoi cell sizes exact, sweep count equal, rows against the oracle
-    (kernel's tie rule)."""
+    voxels, more than the neighbour list holds, and a lattice is nothing but exact Voronoi ties: cell sizes exact (the
+    reference's cKDTree rule), sweep count equal, rows against the oracle."""
     import np_oracle as O
     from imageanalysis3_amd import synth
     from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
@@ -251,7 +251,7 @@ def test_dense_grid_beyond_neighbour_list_vs_oracle():
     seeds = np.round(centers)
     d2 = ((seeds[:, None] - seeds[None]) ** 2).sum(-1)
     assert ((d2 <= 100).sum(1) - 1).max() > 64
-    fo = O.iter_fit_seed_points(im, seeds.T, voronoi="lowest_index")
+    fo = O.iter_fit_seed_points(im, seeds.T)
     fo.firstfit()
     first_o = np.array(fo.ps, dtype=np.float64)
     nvox_o = np.array([gp[1].shape[1] for gp in fo.gparms])

@@ -7,7 +7,7 @@ import pytest
 from conftest import build_case, load_golden
 import np_oracle as O
 
-FIT_CASES = ["c1_f32", "c1_u16", "m_f32", "edge_f32", "clu_f32", "hot_u16"]
+FIT_CASES = ["c1_f32", "c1_u16", "m_f32", "edge_f32", "clu_f32", "hot_u16", "club_f32"]
 
 
 def crc(a):
@@ -28,7 +28,7 @@ def test_get_seeds_variants(name):
     assert np.array_equal(O.get_seeds(im, th_seed=600, min_edge_distance=0, return_h=True), g["seeds_edge0"])
 
 
-@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "edge_f32", "clu_f32", "hot_u16"])
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "edge_f32", "clu_f32", "hot_u16", "club_f32"])
 def test_fit_tables_bit_exact(name):
     """Same MINPACK, same arithmetic order -> the oracle reproduces the reference bit for bit."""
     g = load_golden("fit_%s.npz" % name)

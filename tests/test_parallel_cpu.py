@@ -30,7 +30,7 @@ def test_pad_tables():
         pad_tables([np.zeros((5, 11))], 4)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
     try:
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
@@ -39,8 +39,15 @@ def _worker(rank, world, port, q):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         rng = np.random.default_rng(rank)
-        tables = [rng.random((3 + rank, 11)).astype(np.float32), rng.random((rank, 11)).astype(np.float32)]
-        out = gather_spot_tables(tables, max_seeds=8)
+        if mode == "even":
+            tables = [rng.random((3 + rank, 11)).astype(np.float32), rng.random((rank, 11)).astype(np.float32)]
+        elif mode == "uneven":   # 7 FOVs over 2 ranks: shard_fovs gives 4 and 3
+            from imageanalysis3_amd.parallel import shard_fovs
+            tables = [rng.random((1 + int(i) % 5, 11)).astype(np.float32) for i in shard_fovs(7, rank, world)]
+        else:                    # a rank without any FOV
+            tables = [] if rank == 1 else [rng.random((4, 11)).astype(np.float32)]
+        out, counts = gather_spot_tables(tables, max_seeds=8, return_counts=True)
+        assert [len(c) for c in counts] == ([2, 2] if mode == "even" else [4, 3] if mode == "uneven" else [1, 0])
         q.put((rank, out, tables))
         dist.barrier()
         dist.destroy_process_group()
@@ -48,12 +55,13 @@ def _worker(rank, world, port, q):
         q.put((rank, repr(e), None))
 
 
-def test_gather_spot_tables_gloo_world2():
+@pytest.mark.parametrize("mode", ["even", "uneven", "empty_rank"])
+def test_gather_spot_tables_gloo_world2(mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + {"even": 0, "uneven": 1, "empty_rank": 2}[mode]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -62,6 +70,6 @@ def test_gather_spot_tables_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    expect = np.concatenate([t for _, _, tabs in res for t in tabs], axis=0)
+    expect = np.concatenate([t for _, _, tabs in res for t in tabs] + [np.zeros((0, 11), np.float32)], axis=0)
     for _, out, _ in res:
         assert out.shape == expect.shape and np.array_equal(out, expect)
