@@ -27,7 +27,7 @@ EXPORTS = [
     "ia3_z_shift_correction_dev", "ia3_illumination_correct_dev", "ia3_bleedthrough_correct_dev",
     "ia3_illumination_rescale_dev", "ia3_bleedthrough_rescale_dev",
     "ia3_fit_create", "ia3_fit_first", "ia3_fit_repeat", "ia3_fit_run", "ia3_fit_results", "ia3_fit_results_ex", "ia3_fit_nfev", "ia3_fit_stats", "ia3_fit_counters",
-    "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_fit_fov_stats", "ia3_fit_fovs",
+    "ia3_fit_destroy", "ia3_fit_seeds", "ia3_fit_fov_dev", "ia3_fit_fov_stats", "ia3_fit_fov_wait_share", "ia3_fit_fovs",
     "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
     "ia3_stack_crop", "ia3_warp3d", "ia3_warp3d_dev",

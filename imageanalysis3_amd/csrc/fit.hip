@@ -278,6 +278,7 @@ struct WaveLds {
   // shared cache lines (counters, stage control, n_iter) were the kernel's largest wait at two waves per SIMD — 43 us
   // per work-list position behind the ticket draw, which queues behind them (profiles/r03a/fit_stamps.log)
   unsigned long long tally[3];   // fits run, function evaluations, voxel evaluations
+  unsigned long long tally_wait; // shader cycles spent in dependency waits (refit admission)
   int tally_conv, tally_iter;    // seeds that converged, highest sweep made
 #ifdef IA3_FIT_STAMPS
   unsigned long long t_last, stamp[24];   // profiling build only (scripts/fit_stamps.sh): shader cycles per phase
@@ -850,13 +851,27 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
 // Hand-off: producer sc1 stores -> vmcnt(0) -> relaxed agent store of done[j]; consumer relaxed agent poll of
 // done[j] -> sc1 loads of the payload (MI355X_MICROARCH.md "Valid forms": every load and store of the handed-off
 // words is sc1, the storing lane drains before it raises the counter, the polling wave loads only afterwards).
+// Work is handed out through NCLAIM + 1 ticket counters, each on a cache line of its own: an agent-scope atomic on ONE
+// word is served at ~50-80 ns apiece whoever asks (the XCDs' L2s are not coherent, the operation runs at the memory side),
+// so the 12 000 draws of a 5 000-seed field from a single counter held every wave 27 us per draw at two waves per SIMD
+// and bounded the kernel from below (profiles/r03a/fit_stamps.log).
+//   claim[0 .. NCLAIM-1]  stage 0 (first fits; they wait for nothing): the seeds are split into NCLAIM ranges, a wave
+//                         starts with the range of its block index and goes on to the others when that one is empty
+//   claim[NCLAIM]         later stages, in UNITS of 64 consecutive positions (one lane looks at each: most are skips)
+// A wave draws from claim[NCLAIM] only after it has seen every stage-0 range exhausted, i.e. when every first fit is in the
+// hands of a running wave; units are drawn in list order and worked through in order.  So whatever a position waits
+// for is either a first fit (running or done) or an earlier position of an earlier-or-same unit (running or done): the
+// argument that needs no co-residency stands.
+constexpr int NCLAIM = 8;
 struct StageCtl {
-  unsigned int claim;       // next work-list position
   int n_unconv;             // seeds not yet converged (repeat stages stop when it reaches 0)
   int abort;                // 1: a spin-wait exceeded its bound (never expected); 2: exact Voronoi ties exist and no tie masks
                             // were supplied (the host resolves them and launches again); 3: tie queue overflow
   int ties;                 // nbr_build_k: some ball voxel is equidistant from its seed and another one
+  int pad[29];
+  struct Claim { unsigned int next; unsigned int pad[31]; } claim[NCLAIM + 1];
 };
+static_assert(sizeof(StageCtl) == 128 * (NCLAIM + 2), "one 128-byte line per counter");
 
 // wave-uniform poll: every lane issues the (same-address) load, lane 0's value decides for the whole wave
 __device__ __forceinline__ bool wait_done(const int* done, int j, int need, StageCtl* ctl) {
@@ -892,11 +907,9 @@ __device__ __forceinline__ void publish_quiet(int* done, int i, int value) {
 }
 
 // one work-list position; false = abort (a dependency wait exceeded its bound)
-__device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLds* L, int n, int stage0, int stage1, StageCtl* ctl,
-                                               int* done, unsigned pos) {
+__device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLds* L, int stage1, StageCtl* ctl,
+                                               int* done, int k, int i) {
   const int lane = threadIdx.x & 63;
-  const int k = stage0 + (int)(pos / (unsigned)n);
-  const int i = (int)(pos % (unsigned)n);   // seed order inside a stage: lower-index neighbours come first
   // run_position (the fit) has ONE call site below: the kernel is instruction-cache bound, a second copy of the
   // solver costs more than the branches around this one.
   int mode;
@@ -913,6 +926,7 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
       publish(done, i, 1 << 20);
       return true;
     }
+    const unsigned long long t_wait = __builtin_readcyclecounter();
     if (!wait_done(done, i, k, ctl)) return false;
     // ... or made meanwhile: the wave that holds this seed's first fit may have been running until now
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= k + 1) return true;
@@ -922,6 +936,7 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
     each_neighbour(fa, i, [&](int j) { alive = wait_done(done, j, j < i ? k + 1 : k, ctl); return alive; });
     if (!alive) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) L->tally_wait += __builtin_readcyclecounter() - t_wait;   // cycles this wave sat in dependency waits
     mode = 1;
   }
   IA3_STAMP(L, 13);   // admission (dependency waits)
@@ -957,7 +972,6 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
   __shared__ WaveLds wl;
   IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
   const int lane = threadIdx.x & 63;
-  const unsigned total = (unsigned)(stage1 - stage0) * (unsigned)n;
   // exact Voronoi ties in this field and no tie masks yet: nothing is fitted; the host builds the seed tree, resolves the
   // ties (voronoi_ties_k) and launches again
   // (the legacy model's driver, Fitting_v3.py:39-46, takes cdist + argmin instead of a tree: lowest index, no masks)
@@ -965,24 +979,64 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
     if (lane == 0) __hip_atomic_fetch_max(&ctl->abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  if (lane == 0) { L->tally[0] = L->tally[1] = L->tally[2] = 0ull; L->tally_conv = 0; L->tally_iter = 0; }
+  if (lane == 0) { L->tally[0] = L->tally[1] = L->tally[2] = 0ull; L->tally_wait = 0ull; L->tally_conv = 0; L->tally_iter = 0; }
+  const unsigned long long t_start = __builtin_readcyclecounter();
 #ifdef IA3_FIT_STAMPS
   if (lane < 24) L->stamp[lane] = 0ull;
-  if (lane == 0) L->t_last = __builtin_readcyclecounter();
+  if (lane == 0) L->t_last = t_start;
 #endif
   __builtin_amdgcn_wave_barrier();
-  for (;;) {
-    unsigned pos = 0;
-    if (lane == 0) pos = atomicAdd(&ctl->claim, 1u);
-    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+  // one ticket: false when the counter is exhausted.  The load in front keeps exhausted counters free of atomics (the
+  // value only grows, so "exhausted" is never a stale answer).
+  auto draw = [&](StageCtl::Claim* c, unsigned size, unsigned& t) -> bool {
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&c->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= size) return false;
+    unsigned v = 0;
+    if (lane == 0) v = atomicAdd(&c->next, 1u);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     IA3_STAMP(L, 0);   // ticket
-    if (pos >= total) break;
-    if (!stage_position(fa, L, n, stage0, stage1, ctl, done, pos)) break;
+    return t < size;
+  };
+  // ONE loop, one call site of the fit (the kernel is instruction-cache bound): first fits from the NCLAIM seed ranges,
+  // own range first; then the refit sweeps in units of 64 positions, list order, each unit worked through in index order
+  const int home = (int)(blockIdx.x % NCLAIM);
+  const int later0 = stage0 > 1 ? stage0 : 1;
+  const unsigned per_stage = (unsigned)((n + 63) / 64);
+  const unsigned units = stage1 > later0 ? per_stage * (unsigned)(stage1 - later0) : 0u;
+  int r = stage0 == 0 ? 0 : NCLAIM;   // next stage-0 range to try; NCLAIM: every first fit is in the hands of a running wave
+  unsigned long long m = 0ull;        // positions of the current unit that still want a refit
+  int uk = 0, ui0 = 0;
+  for (;;) {
+    int k, i;
+    if (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      k = uk; i = ui0 + b;
+    } else if (r < NCLAIM) {
+      const int q = (home + r) % NCLAIM;
+      const int lo = (int)((long long)n * q / NCLAIM), hi = (int)((long long)n * (q + 1) / NCLAIM);
+      unsigned t;
+      if (!draw(&ctl->claim[q], (unsigned)(hi - lo), t)) { ++r; continue; }
+      k = 0; i = lo + (int)t;
+    } else {
+      unsigned u;
+      if (!units || !draw(&ctl->claim[NCLAIM], units, u)) break;
+      uk = later0 + (int)(u / per_stage);
+      ui0 = (int)(u % per_stage) * 64;
+      // every lane looks at one position of the unit: already made (a seed without neighbours gets sweep 1 with its
+      // first fit) or skipped for good (converged, 1 << 20) -> nothing to do; the rest in index order
+      bool need = false;
+      if (ui0 + lane < n) need = __hip_atomic_load(&done[ui0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < uk + 1;
+      m = __ballot(need);
+      continue;
+    }
+    if (!stage_position(fa, L, stage1, ctl, done, k, i)) break;
     __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {   // (n_unconv: later positions of this launch only lose an early exit while the count is stale-high)
     if (L->tally[0]) { atomicAdd(&fa.counters[0], L->tally[0]); atomicAdd(&fa.counters[1], L->tally[1]); atomicAdd(&fa.counters[2], L->tally[2]); }
+    if (L->tally_wait) atomicAdd(&fa.counters[3], L->tally_wait);
+    atomicAdd(&fa.counters[4], __builtin_readcyclecounter() - t_start);   // wave cycles: the share of [3] is the wait share
     if (L->tally_conv) atomicSub(&ctl->n_unconv, L->tally_conv);
     if (L->tally_iter) atomicMax(fa.n_iter, L->tally_iter);
   }
@@ -1070,7 +1124,7 @@ __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
   if (a.src) for (size_t i = t; i < (size_t)3 * n; i += step) a.seeds[i] = a.src[i];
   if (t < 32) a.counters[t] = 0ull;
   if (t == 33) *a.niter = 0;
-  if (t == 34) *a.ctl = StageCtl{0u, n, 0, 0};
+  for (size_t k = t; k < sizeof(StageCtl) / 4; k += step) ((int*)a.ctl)[k] = k == 0 ? n : 0;   // n_unconv = n, all else 0
   if (t == 35) *a.ovf = 0;
 }
 
@@ -1093,7 +1147,8 @@ struct ia3_fitter {
   bool pristine;       // the block is as fit_init_k left it: the first fit launch needs no further resets
   bool first_done;
   StageCtl host_ctl;
-  unsigned long long host_counters[3];   // copy of d_counters as of the last ia3_fit_results(_ex)
+  unsigned long long host_counters[5];   // copy of d_counters as of the last ia3_fit_results(_ex): fits, evaluations, voxel
+                                          // evaluations, shader cycles in dependency waits, wave cycles
   void *d_tie_flag, *d_tie_lost;   // per seed: has exact Voronoi ties (nbr_build_k) / lane masks of the tie voxels it loses
   void* kd_block;      // device copy of the seed tree (nodes | permutation), made only when ties exist
   bool ties_resolved;  // d_tie_lost is valid
@@ -1196,7 +1251,7 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n);
   const size_t up_bytes = b_seeds;
   const size_t b_state = al(sizeof(SeedState) * (size_t)n), b_nvox = al(sizeof(int) * (size_t)n), b_nfev = b_nvox,
-               b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = 256,
+               b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = al(sizeof(StageCtl)),
                b_ovf = 256;
   const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf;
   const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
@@ -1280,8 +1335,8 @@ void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : c
 void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
 void set_fit_maxfev(int n) { g_fit_maxfev = n; }
 void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
-void fit_host_counters(const ia3_fitter* f, long long out[3]) {
-  for (int k = 0; k < 3; ++k) out[k] = (long long)f->host_counters[k];
+void fit_host_counters(const ia3_fitter* f, long long out[5]) {
+  for (int k = 0; k < 5; ++k) out[k] = (long long)f->host_counters[k];
 }
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out) {
   return fit_create_impl(im, nullptr, d_centers_zxy, n, p, out);
@@ -1297,11 +1352,12 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   hipStream_t st = stream();
   if (fresh) {
     if (!f->pristine) {   // fit_init_k has armed the control record of a new fitter already
-      f->host_ctl = StageCtl{0u, f->n, 0, 0};
+      memset(&f->host_ctl, 0, sizeof(StageCtl));
+      f->host_ctl.n_unconv = f->n;
       IA3_HIP(hipMemcpyAsync(f->d_ctl, &f->host_ctl, sizeof(StageCtl), hipMemcpyHostToDevice, st));
     }
   } else {
-    IA3_HIP(hipMemsetAsync(f->d_ctl, 0, sizeof(unsigned int), st));   // StageCtl::claim is the first word
+    IA3_HIP(hipMemsetAsync((char*)f->d_ctl + offsetof(StageCtl, claim), 0, sizeof(StageCtl) - offsetof(StageCtl, claim), st));   // the ticket counters
   }
   f->pristine = false;
   long long blocks = (long long)(stage1 - stage0) * f->n;   // work-list positions; waves draw them as tickets
@@ -1453,7 +1509,8 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
   hipStream_t st = stream();
   std::vector<SeedState> stv;
   if (n_iter) *n_iter = 0;
-  StageCtl hc = StageCtl{0u, 0, 0, 0};
+  StageCtl hc;
+  memset(&hc, 0, sizeof(hc));
   int ovf = 0;
   if (f->n > 0) {
     // one copy: the four 256-byte control slots and the row table sit back to back in the pool (already on the host

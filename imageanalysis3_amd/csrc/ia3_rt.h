@@ -121,6 +121,7 @@ struct SeedDev {
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
 // fitter from centres that are already resident (n x 3 float64)
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
-// fits run / model evaluations / voxel evaluations of a fitter, as of its last ia3_fit_results(_ex)
-void fit_host_counters(const ia3_fitter* f, long long out[3]);
+// fits run / model evaluations / voxel evaluations / shader cycles in dependency waits / wave cycles of a fitter, as of its
+// last ia3_fit_results(_ex)
+void fit_host_counters(const ia3_fitter* f, long long out[5]);
 }  // namespace ia3k

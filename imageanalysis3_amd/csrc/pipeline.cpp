@@ -15,7 +15,7 @@
 using namespace ia3rt;
 
 // counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
-static thread_local long long t_last_stats[3] = {0, 0, 0};
+static thread_local long long t_last_stats[5] = {0, 0, 0, 0, 0};
 
 static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
   int m = 0;
@@ -61,7 +61,7 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   if (n_seeds) *n_seeds = 0;
   if (n_iter) *n_iter = 0;
   *n_rows = 0;
-  t_last_stats[0] = t_last_stats[1] = t_last_stats[2] = 0;
+  for (int k = 0; k < 5; ++k) t_last_stats[k] = 0;
   // (Leaving the seed COUNT on the device as well — fitter sized for the finish capacity, kernels reading the count —
   // was measured: no gain for one stream, since the host already queues ahead of the device, and 12 % slower with twelve
   // images in flight because every fit launch then carries 16 k mostly empty blocks; profiles/r02b/ab_sync.log.)
@@ -71,6 +71,12 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   if (n_seeds) *n_seeds = n;
   if (n == 0) return IA3_OK;  // fitting.py:206-207
   return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
+}
+
+extern "C" int ia3_fit_fov_wait_share(int64_t* wait_cycles, int64_t* wave_cycles) {
+  if (wait_cycles) *wait_cycles = t_last_stats[3];
+  if (wave_cycles) *wave_cycles = t_last_stats[4];
+  return IA3_OK;
 }
 
 extern "C" int ia3_fit_fov_stats(int64_t* fits, int64_t* nfev, int64_t* voxel_evals) {

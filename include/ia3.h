@@ -292,6 +292,9 @@ int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fi
 /* fits run, model evaluations and voxel evaluations (sum over fits of evaluations x voxels) of the calling thread's
  * last ia3_fit_fov_dev: what the counted-flop rate of the fit kernel is computed from (bench.py). */
 int ia3_fit_fov_stats(int64_t* fits, int64_t* nfev, int64_t* voxel_evals);
+/* of the calling thread's last ia3_fit_fov_dev: shader cycles its fit waves spent waiting for the fits a refit depends on
+ * (the reference's ordered sweeps, Fitting_v4.py:651-680), and the cycles those waves lived: the dependency-wait share */
+int ia3_fit_fov_wait_share(int64_t* wait_cycles, int64_t* wave_cycles);
 
 /* A batch of independent FOVs in one call: the per-image tasks the reference spreads over an mp.Pool
  * (classes/field_of_view.py:1129-1142, worker classes/batch_functions.py:60).  Each job is either a host stack
