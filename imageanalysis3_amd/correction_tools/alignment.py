@@ -77,10 +77,7 @@ def align_beads(tar_cts, ref_cts,
                 return_paired_cts=True,
                 verbose=True):
     """correction_tools/alignment.py:139-216 — mean shift of uniquely paired bead centres after an FFT
-    rough alignment of the two crops."""
-    _tar_cts = np.array(tar_cts)
-    _ref_cts = np.array(ref_cts)
-    _distance_th = float(match_distance_th)
+    rough alignment of the two crops.  Returns (drift,) or (drift, paired target centres, paired reference centres)."""
     from ..alignment_tools import fft3d_from2d
     from ..spot_tools.matching import find_paired_centers, check_paired_centers
     if not use_fft:
@@ -90,18 +87,42 @@ def align_beads(tar_cts, ref_cts,
         raise ValueError("both tar_im and ref_im should be given if use FFT!")
     if np.shape(tar_im) != np.shape(ref_im):
         raise IndexError(f"tar_im shape:{np.shape(tar_im)} should match ref_im shape:{np.shape(ref_im)}")
-    _rough_drift = fft3d_from2d(tar_im, ref_im, gb=fft_filt_size, max_disp=np.max(np.shape(tar_im)) / 2)
-    _drift, _paired_tar_cts, _paired_ref_cts = find_paired_centers(
-        _tar_cts, _ref_cts, _rough_drift, cutoff=_distance_th, return_paired_cts=True, verbose=verbose)
+    # integer shift from the projections' cross-correlation, searched over half the crop
+    coarse = fft3d_from2d(tar_im, ref_im, gb=fft_filt_size, max_disp=np.max(np.shape(tar_im)) / 2)
+    # beads that pair up uniquely within the matching distance once the coarse shift is applied
+    drift, pair_tar, pair_ref = find_paired_centers(np.array(tar_cts), np.array(ref_cts), coarse,
+                                                    cutoff=float(match_distance_th), return_paired_cts=True,
+                                                    verbose=verbose)
     if verbose:
-        print("before check:", _drift, len(_paired_ref_cts))
-    if check_paired_cts and len(_paired_ref_cts) > 3:
-        _drift, _paired_tar_cts, _paired_ref_cts = check_paired_centers(
-            _paired_tar_cts, _paired_ref_cts, outlier_sigma=outlier_sigma, return_paired_cts=True, verbose=verbose)
-    _return_args = [_drift]
-    if return_paired_cts:
-        _return_args += [_paired_tar_cts, _paired_ref_cts]
-    return tuple(_return_args)
+        print(f"-- {len(pair_ref)} bead pairs, drift before the outlier test: {drift}")
+    if check_paired_cts and len(pair_ref) > 3:   # neighbour-consistency test needs a triangulation: at least 4 pairs
+        drift, pair_tar, pair_ref = check_paired_centers(pair_tar, pair_ref, outlier_sigma=outlier_sigma,
+                                                         return_paired_cts=True, verbose=verbose)
+    return (drift, pair_tar, pair_ref) if return_paired_cts else (drift,)
+
+
+def _consensus_drift(drifts, min_good_drifts, drift_diff_th):
+    """alignment.py:664-674: once `min_good_drifts` crops are in, the crops within `drift_diff_th` of the running mean;
+    if enough of them agree their mean is the answer, else None."""
+    d = np.asarray(drifts, dtype=np.float64)
+    if len(d) < min_good_drifts:
+        return None, None
+    centre = np.nanmean(d, axis=0)
+    close = np.flatnonzero(np.linalg.norm(d - centre, axis=1) <= drift_diff_th)
+    if len(close) < min_good_drifts:
+        return None, None
+    return np.nanmean(d[close], axis=0), close
+
+
+def _closest_three_drift(drifts):
+    """alignment.py:676-693: no consensus — the two crops that agree best and the crop nearest to both of them."""
+    from scipy.spatial.distance import pdist, squareform
+    d = np.asarray(drifts, dtype=np.float64)
+    gaps = squareform(pdist(d))
+    np.fill_diagonal(gaps, np.inf)
+    pair = np.array(np.unravel_index(np.argmin(gaps), gaps.shape))
+    third = int(np.argmin(gaps[:, pair].sum(1)))
+    return np.nanmean(np.concatenate([d[pair], d[third:third + 1]]), axis=0)
 
 
 _default_align_corr_args = {
@@ -207,30 +228,19 @@ def align_image(
             _drifts.append(_dft)
             if verbose:
                 print(f"-- drift {_i}: {np.around(_dft, 2)} in {time.time()-_start_time:.3f}s.")
-            _mean_dft = np.nanmean(_drifts, axis=0)                                       # :664-674
-            if len(_drifts) >= min_good_drifts:
-                _dists = np.linalg.norm(_drifts - _mean_dft, axis=1)
-                _kept_drift_inds = np.where(_dists <= drift_diff_th)[0]
-                if len(_kept_drift_inds) >= min_good_drifts:
-                    _updated_mean_dft = np.nanmean(np.array(_drifts)[_kept_drift_inds], axis=0)
-                    if verbose:
-                        print(f"--- drifts for crops:{_kept_drift_inds} pass the thresold, exit cycle.")
-                    break
+            _updated_mean_dft, _agree = _consensus_drift(_drifts, min_good_drifts, drift_diff_th)
+            if _updated_mean_dft is not None:
+                if verbose:
+                    print(f"--- crops {_agree} agree within {drift_diff_th} px: done.")
+                break
     finally:
         if _own_src:
             _src.free()
         if _own_ref:
             _ref.free()
-    if _updated_mean_dft is None:                                                          # :676-693
+    if _updated_mean_dft is None:
         if verbose:
-            print("-- return a sub-optimal drift")
-        _drifts = np.array(_drifts)
-        from scipy.spatial.distance import pdist, squareform
-        _dist_mat = squareform(pdist(_drifts))
-        np.fill_diagonal(_dist_mat, np.inf)
-        _sel_inds = np.array(np.unravel_index(np.argmin(_dist_mat), np.shape(_dist_mat)))
-        _sel_drifts = list(_drifts[_sel_inds])
-        _sel_drifts.append(_drifts[np.argmin(_dist_mat[:, _sel_inds].sum(1))])
-        _updated_mean_dft = np.nanmean(_sel_drifts, axis=0)
+            print("-- the crops do not agree: mean of the closest three, flagged")
+        _updated_mean_dft = _closest_three_drift(_drifts)
         _result_flag += 1
     return _updated_mean_dft, _result_flag

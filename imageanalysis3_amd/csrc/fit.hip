@@ -58,10 +58,17 @@ struct SeedState {
   int pad;
 };
 
+// One fitter may hold the seeds of SEVERAL fields of view (same shape and dtype; ia3_fit_fovs): the seeds of FOV f are
+// the index range [fov_start[f], fov_start[f+1]), neighbours and dependencies exist only inside a range, and the work
+// list runs over all of them — the long dependent chains and maxfev fits of one field overlap with the other fields' work.
 struct FitArgs {
-  const void* im; int dtype; int Z, X, Y;
+  const void* const* ims;   // n_fov stacks (device pointers)
+  const int* fov_of;        // n: field of view of seed i
+  const int* fov_start;     // n_fov + 1
+  int n_fov;
+  int dtype; int Z, X, Y;
   const double* seeds;      // n x 3
-  int n;                    // number of seeds
+  int n;                    // number of seeds (all fields)
   int fuse;                 // a seed without neighbours: first fit and sweep 1 by the same wave (see fit_stages_k)
   int nb_cap;               // lists longer than this are not used (MAXNB; lowered by IA3_TUNE_FIT_NBLIST in tests)
   double nb_r2;             // (2r)²: seeds closer than this interact
@@ -75,8 +82,9 @@ struct FitArgs {
   int* nvox;                // n
   int* nfev;                // n (accumulated function evaluations)
   unsigned char* conv;      // n
-  int* n_iter;              // max sweeps over components
+  int* n_iter;              // n_fov: sweeps made per field (max over its seeds)
   unsigned long long* counters;  // [0] fits run, [1] function evaluations, [2] voxel evaluations (sum of nfev x voxels)
+  unsigned long long* fov_counters;   // n_fov x 4: the same three per field
   double min_ws, max_ws, init_w, delta_first, delta_repeat, dist_th2;
   int n_max_iter;
   double ftol, xtol, gtol; int maxfev; double factor;
@@ -277,11 +285,13 @@ struct WaveLds {
   // tallies of this wave, flushed with one atomic each when the wave leaves the kernel: the per-fit atomics on three
   // shared cache lines (counters, stage control, n_iter) were the kernel's largest wait at two waves per SIMD — 43 us
   // per work-list position behind the ticket draw, which queues behind them (profiles/r03a/fit_stamps.log)
-  unsigned long long tally[3];   // fits run, function evaluations, voxel evaluations
+  unsigned long long tally[3];   // fits run, function evaluations, voxel evaluations — of field tally_fov
   unsigned long long tally_wait; // shader cycles spent in dependency waits (refit admission)
-  int tally_conv, tally_iter;    // seeds that converged, highest sweep made
+  int tally_conv, tally_iter;    // seeds that converged; highest sweep made in field tally_fov
+  int tally_fov;                 // the field the per-field tallies belong to (-1: none yet); flushed when it changes
 #ifdef IA3_FIT_STAMPS
   unsigned long long t_last, stamp[24];   // profiling build only (scripts/fit_stamps.sh): shader cycles per phase
+  unsigned long long stamp_fit[24];       // ... of the fit in progress (IA3_FIT_STAMPS == 2 keeps only fits beyond 100 evaluations)
 #endif
 };
 
@@ -290,11 +300,30 @@ struct WaveLds {
 #define IA3_STAMP(L, k)                                                                       \
   do {                                                                                        \
     const unsigned long long t_ = __builtin_readcyclecounter();                               \
-    if ((threadIdx.x & 63) == 0) { (L)->stamp[k] += t_ - (L)->t_last; (L)->t_last = t_; }     \
+    if ((threadIdx.x & 63) == 0) {                                                            \
+      if ((k) == 3 || (k) == 4 || ((k) >= 6 && (k) <= 10)) (L)->stamp_fit[k] += t_ - (L)->t_last;   \
+      else (L)->stamp[k] += t_ - (L)->t_last;                                                 \
+      (L)->t_last = t_;                                                                       \
+    }                                                                                         \
+    __builtin_amdgcn_wave_barrier();                                                          \
+  } while (0)
+// end of a fit: its phases join the wave's totals (all fits, or only the stragglers)
+#define IA3_STAMP_FIT_END(L, nfev_)                                                           \
+  do {                                                                                        \
+    if ((threadIdx.x & 63) < 24) {                                                            \
+      const int l_ = threadIdx.x & 63;                                                        \
+      if (IA3_FIT_STAMPS != 2 || (nfev_) > 100) {                                             \
+        (L)->stamp[l_] += (L)->stamp_fit[l_];                                                 \
+        if (l_ == 15) (L)->stamp[15] += (unsigned long long)(nfev_);                          \
+        if (l_ == 16) (L)->stamp[16] += 1ull;                                                 \
+      }                                                                                       \
+      (L)->stamp_fit[l_] = 0ull;                                                              \
+    }                                                                                         \
     __builtin_amdgcn_wave_barrier();                                                          \
   } while (0)
 #else
 #define IA3_STAMP(L, k) do { } while (0)
+#define IA3_STAMP_FIT_END(L, n) do { } while (0)
 #endif
 
 // Wave-parallel evaluation of |f|, JᵀJ, Jᵀf for lm_solve.
@@ -472,6 +501,7 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, IA3_LDS WaveLds*
       if ((threadIdx.x & 63) == 0) { L->p[1] = (float)gs.c[0]; L->p[2] = (float)gs.c[1]; L->p[3] = (float)gs.c[2]; }
       __builtin_amdgcn_wave_barrier();
       IA3_STAMP(L, 10);   // natural parameters, eps
+      IA3_STAMP_FIT_END(L, r.nfev);
       return r.nfev;
     }
     natural_wave(L->gsc, L->p);
@@ -489,7 +519,30 @@ __device__ __forceinline__ int wave_gaussfit(const FitArgs& fa, IA3_LDS WaveLds*
   if (ln == 0) L->p[10] = (float)eps;
   __builtin_amdgcn_wave_barrier();
   IA3_STAMP(L, 10);
+  IA3_STAMP_FIT_END(L, r.nfev);
   return r.nfev;
+}
+
+// per-field tallies of the wave -> global memory (one atomic each; called when the wave moves on to another field and
+// when it leaves the kernel)
+__device__ __forceinline__ void flush_tallies(const FitArgs& fa, IA3_LDS WaveLds* L) {
+  if ((threadIdx.x & 63) == 0 && L->tally_fov >= 0) {
+    if (L->tally[0]) {
+      atomicAdd(&fa.counters[0], L->tally[0]); atomicAdd(&fa.counters[1], L->tally[1]); atomicAdd(&fa.counters[2], L->tally[2]);
+      unsigned long long* fc = fa.fov_counters + 4 * (size_t)L->tally_fov;
+      atomicAdd(&fc[0], L->tally[0]); atomicAdd(&fc[1], L->tally[1]); atomicAdd(&fc[2], L->tally[2]);
+    }
+    if (L->tally_iter) atomicMax(&fa.n_iter[L->tally_fov], L->tally_iter);
+    L->tally[0] = L->tally[1] = L->tally[2] = 0ull;
+    L->tally_iter = 0;
+  }
+}
+__device__ __forceinline__ void tally_field(const FitArgs& fa, IA3_LDS WaveLds* L, int fov) {
+  if (__builtin_amdgcn_readfirstlane(L->tally_fov) != fov) {
+    flush_tallies(fa, L);
+    if ((threadIdx.x & 63) == 0) L->tally_fov = fov;
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // Hand a fit's results over: the seed's state record (unconstrained parameters, delta, flags) and its row, in ONE store
@@ -543,18 +596,22 @@ struct StageCtl;
 // the seed list never goes back to the host for this).  For every neighbour found the wave also looks for EXACT Voronoi
 // ties — a voxel of seed i's ball, inside the image, as far from seed j as from seed i — and flags the seed and the
 // fitter: the reference resolves those by cKDTree's traversal order (ia3_kdtree.h), which needs a tree built on the host.
-__global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ seeds, int n, double r2, int* __restrict__ cnt,
+__global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ seeds, int n_all, double r2, int* __restrict__ cnt,
                                                    int* __restrict__ idx, int* __restrict__ overflow,
                                                    const int* __restrict__ ball, int nball, int Z, int X, int Y,
-                                                   int* __restrict__ tie_flag, int* __restrict__ ctl_ties) {
+                                                   int* __restrict__ tie_flag, int* __restrict__ ctl_ties,
+                                                   const int* __restrict__ fov_of, const int* __restrict__ fov_start,
+                                                   int* __restrict__ fov_ties) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;   // whole wave leaves together
+  if (i >= n_all) return;   // whole wave leaves together
+  const int fov = fov_of[i];
+  const int first = fov_start[fov], n = fov_start[fov + 1];   // candidates: the seeds of the same field
   const double cz = seeds[3 * i], cx = seeds[3 * i + 1], cy = seeds[3 * i + 2];
   const int iz = (int)cz, ix = (int)cx, iy = (int)cy;
   int c = 0;
   bool tie = false;
-  for (int j0 = 0; j0 < n; j0 += 64) {
+  for (int j0 = first; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     bool hit = false;
     if (j < n && j != i) {
@@ -587,7 +644,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
     if (c > MAXNB) atomicMax(overflow, c);   // statistics only: consumers fall back to each_neighbour's scan
     cnt[i] = c;
     tie_flag[i] = any_tie ? 1 : 0;
-    if (any_tie) atomicOr(ctl_ties, 1);
+    if (any_tie) { atomicOr(ctl_ties, 1); atomicOr(&fov_ties[fov], 1); }
   }
 }
 
@@ -604,10 +661,12 @@ __device__ __forceinline__ void each_neighbour(const FitArgs& fa, int i, F f) {
   }
   const int lane = threadIdx.x & 63;
   const double cz = fa.seeds[3 * i], cx = fa.seeds[3 * i + 1], cy = fa.seeds[3 * i + 2];
-  for (int j0 = 0; j0 < fa.n; j0 += 64) {
+  const int fov = fa.fov_of[i];
+  const int first = fa.fov_start[fov], last = fa.fov_start[fov + 1];   // neighbours live in the same field
+  for (int j0 = first; j0 < last; j0 += 64) {
     const int j = j0 + lane;
     bool hit = false;
-    if (j < fa.n && j != i) {
+    if (j < last && j != i) {
       const double a = cz - fa.seeds[3 * j], b = cx - fa.seeds[3 * j + 1], d = cy - fa.seeds[3 * j + 2];
       hit = a * a + b * b + d * d <= fa.nb_r2;
     }
@@ -665,7 +724,7 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS Ba
       const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
       const bool ok = z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y && !(lost & (1u << s));
       if (ok) {
-        const double v = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
+        const double v = load_voxel(fa.ims[fa.fov_of[i]], fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
         valid |= 1u << s;
         fd = (float)v; vals[s] = v;
         fz = (float)z; fx = (float)x; fy = (float)y;
@@ -684,11 +743,12 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS Ba
 // seed as from its nearest other seed asks the tree (one query per lane, the lane's queue in LDS): the voxel stays with
 // the seed iff cKDTree.query(voxel) returns the seed.  Result: per slot a lane mask of lost tie voxels.
 constexpr int KDQ_CAP = 24;   // queue entries per lane (realistic fields need <= 5, a 4 600-seed blob of 6 px sigma 16)
-__global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, const int* __restrict__ tie_flag,
+// Launched per field of view: `tree` is built from that field's seeds (its point indices are local: seed - seed0).
+__global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, int seed0, const int* __restrict__ tie_flag,
                                                      unsigned long long* __restrict__ tie_lost, int* __restrict__ ctl_abort) {
   __shared__ KdQEntry heap[KDQ_CAP][64];
-  const int i = blockIdx.x;
-  if (i >= fa.n || !tie_flag[i]) return;
+  const int i = seed0 + (int)blockIdx.x;
+  if (i >= seed0 + tree.n || !tie_flag[i]) return;
   const int lane = threadIdx.x & 63;
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
@@ -723,7 +783,7 @@ __global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, co
         KdQueue<IA3_LDS KdQEntry*> queue((IA3_LDS KdQEntry*)&heap[0][lane], 64, KDQ_CAP);
         const int w = kd_nearest(tree, q, 2.0 * fa.radius, queue);
         overflow |= queue.overflow;
-        lose = w != i;
+        lose = w != i - seed0;
       }
     }
     const unsigned long long m = __ballot(lose);
@@ -750,7 +810,7 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, IA3_LDS B
       const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
       if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
         valid |= 1u << s;
-        vals[s] = load_voxel(fa.im, fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
+        vals[s] = load_voxel(fa.ims[fa.fov_of[i]], fa.dtype, ((size_t)z * fa.X + x) * fa.Y + y);
         vz[s] = z; vx[s] = x; vy[s] = y;
       }
     }
@@ -800,6 +860,7 @@ __device__ __forceinline__ int gather_repeat(const FitArgs& fa, int i, IA3_LDS B
 //   as the two separate positions; returns "converged".
 // The fit itself has ONE call site (the kernel is instruction-cache bound enough as it is).
 __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds* L, int i, int mode) {
+  tally_field(fa, L, fa.fov_of[i]);
   const double c0[3] = {fa.seeds[3 * i], fa.seeds[3 * i + 1], fa.seeds[3 * i + 2]};
   unsigned valid = 0;
   int n;
@@ -979,10 +1040,10 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
     if (lane == 0) __hip_atomic_fetch_max(&ctl->abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  if (lane == 0) { L->tally[0] = L->tally[1] = L->tally[2] = 0ull; L->tally_wait = 0ull; L->tally_conv = 0; L->tally_iter = 0; }
+  if (lane == 0) { L->tally[0] = L->tally[1] = L->tally[2] = 0ull; L->tally_wait = 0ull; L->tally_conv = 0; L->tally_iter = 0; L->tally_fov = -1; }
   const unsigned long long t_start = __builtin_readcyclecounter();
 #ifdef IA3_FIT_STAMPS
-  if (lane < 24) L->stamp[lane] = 0ull;
+  if (lane < 24) { L->stamp[lane] = 0ull; L->stamp_fit[lane] = 0ull; }
   if (lane == 0) L->t_last = t_start;
 #endif
   __builtin_amdgcn_wave_barrier();
@@ -1033,12 +1094,11 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
     __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
+  flush_tallies(fa, L);
   if (lane == 0) {   // (n_unconv: later positions of this launch only lose an early exit while the count is stale-high)
-    if (L->tally[0]) { atomicAdd(&fa.counters[0], L->tally[0]); atomicAdd(&fa.counters[1], L->tally[1]); atomicAdd(&fa.counters[2], L->tally[2]); }
     if (L->tally_wait) atomicAdd(&fa.counters[3], L->tally_wait);
     atomicAdd(&fa.counters[4], __builtin_readcyclecounter() - t_start);   // wave cycles: the share of [3] is the wait share
     if (L->tally_conv) atomicSub(&ctl->n_unconv, L->tally_conv);
-    if (L->tally_iter) atomicMax(fa.n_iter, L->tally_iter);
   }
 #ifdef IA3_FIT_STAMPS
   if (lane < 24) atomicAdd(&fa.counters[8 + lane], L->stamp[lane]);   // the 256-byte counter slot holds 32 words
@@ -1123,7 +1183,7 @@ __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
   for (size_t i = t; i < a.row_words; i += step) a.rows[i] = uint4{~0u, ~0u, ~0u, ~0u};
   if (a.src) for (size_t i = t; i < (size_t)3 * n; i += step) a.seeds[i] = a.src[i];
   if (t < 32) a.counters[t] = 0ull;
-  if (t == 33) *a.niter = 0;
+  if (t >= 128 && t < 192) a.niter[t - 128] = 0;   // one sweep counter per field (<= 64 fields per fitter)
   for (size_t k = t; k < sizeof(StageCtl) / 4; k += step) ((int*)a.ctl)[k] = k == 0 ? n : 0;   // n_unconv = n, all else 0
   if (t == 35) *a.ovf = 0;
 }
@@ -1136,10 +1196,14 @@ __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
 using namespace ia3rt;
 
 struct ia3_fitter {
-  const ia3_stack* im;
+  const ia3_stack* im;              // the first field's stack (shape and dtype of all of them)
+  std::vector<const ia3_stack*> ims; // one per field of view
+  std::vector<int> fov_start;        // n_fov + 1: seed ranges
   ia3_fit_params prm;
-  int n;
+  int n;                             // seeds of all fields
   int nball;
+  void *d_ims, *d_fov_start, *d_fov_of, *d_fov_ties, *d_fov_counters;
+  std::vector<char> meta_stage;      // source of the asynchronous upload of the three tables above
   void* pool;          // one device block from the scratch cache holding every array below
   size_t pool_bytes;
   void *d_seeds, *d_nbr_cnt, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
@@ -1150,7 +1214,7 @@ struct ia3_fitter {
   unsigned long long host_counters[5];   // copy of d_counters as of the last ia3_fit_results(_ex): fits, evaluations, voxel
                                           // evaluations, shader cycles in dependency waits, wave cycles
   void *d_tie_flag, *d_tie_lost;   // per seed: has exact Voronoi ties (nbr_build_k) / lane masks of the tie voxels it loses
-  void* kd_block;      // device copy of the seed tree (nodes | permutation), made only when ties exist
+  void* kd_block;      // device copy of the seed trees (nodes | permutation per field), made only when ties exist
   bool ties_resolved;  // d_tie_lost is valid
   std::vector<double> host_seeds;   // n x 3 when the seeds came from (or were fetched to) the host
   std::vector<char> kd_stage;       // source of the asynchronous tree upload
@@ -1176,7 +1240,9 @@ int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the ke
 
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
-  a.im = f->im->d; a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
+  a.ims = (const void* const*)f->d_ims; a.fov_of = (const int*)f->d_fov_of; a.fov_start = (const int*)f->d_fov_start;
+  a.n_fov = (int)f->ims.size(); a.fov_counters = (unsigned long long*)f->d_fov_counters;
+  a.dtype = f->im->dtype; a.Z = f->im->Z; a.X = f->im->X; a.Y = f->im->Y;
   a.n = f->n; a.fuse = g_fit_fuse; a.nb_cap = g_nb_cap; a.nb_r2 = 4.0 * f->prm.radius_fit * (double)f->prm.radius_fit;
   a.seeds = (const double*)f->d_seeds; a.nbr_cnt = (const int*)f->d_nbr_cnt; a.nbr_idx = (const int*)f->d_nbr_idx;
   a.ball = (const int*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
@@ -1233,27 +1299,43 @@ static int ball_table(int radius, const signed char** d_ball, int* nball) {
   return IA3_OK;
 }
 
-static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const double* d_centers_zxy, int n,
-                           const ia3_fit_params* p, ia3_fitter** out) {
+constexpr int MAX_FOV = 64;   // fields of view per fitter (their sweep counters share one 256-byte slot)
+struct FovSeeds { const ia3_stack* im; const double* host_zxy; const double* dev_zxy; int n; };
+
+static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params* p, ia3_fitter** out) {
   int rc = ensure_init(); if (rc) return rc;
-  if (!im || !p || !out || n < 0 || (n > 0 && !centers_zxy && !d_centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
+  if (!fovs || n_fov < 1 || n_fov > MAX_FOV || !p || !out) return set_error(IA3_EINVAL, "bad argument");
   if (p->radius_fit < 1) return set_error(IA3_EINVAL, "radius_fit must be >= 1");
+  long long ntot = 0;
+  for (int k = 0; k < n_fov; ++k) {
+    const FovSeeds& q = fovs[k];
+    if (!q.im || q.n < 0 || (q.n > 0 && !q.host_zxy && !q.dev_zxy)) return set_error(IA3_EINVAL, "bad argument");
+    if (q.im->dtype != fovs[0].im->dtype || q.im->Z != fovs[0].im->Z || q.im->X != fovs[0].im->X || q.im->Y != fovs[0].im->Y)
+      return set_error(IA3_EINVAL, "the fields of one fitter must have the same shape and dtype");
+    if (q.host_zxy)
+      for (int i = 0; i < 3 * q.n; ++i)
+        if (!(fabs(q.host_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
+    ntot += q.n;
+  }
+  if (ntot > 0x3fffffff) return set_error(IA3_EUNSUPPORTED, "too many seeds");
+  const int n = (int)ntot;
+  const ia3_stack* im = fovs[0].im;
   const signed char* d_ball = nullptr;
   int nball = 0;
   rc = ball_table(p->radius_fit, &d_ball, &nball); if (rc) return rc;
-  if (centers_zxy)
-    for (int i = 0; i < 3 * n; ++i)
-      if (!(fabs(centers_zxy[i]) < 1e9)) return set_error(IA3_EINVAL, "non-finite seed coordinate");
   ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
   f->im = im; f->prm = *p; f->n = n; f->nball = nball;
+  f->fov_start.assign(1, 0);
+  for (int k = 0; k < n_fov; ++k) { f->ims.push_back(fovs[k].im); f->fov_start.push_back(f->fov_start.back() + fovs[k].n); }
   // one pooled device block: [uploaded read-only part | zero-initialised part | NaN-initialised rows | neighbour lists]
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t b_seeds = al(sizeof(double) * 3 * (size_t)n);
-  const size_t up_bytes = b_seeds;
+  const size_t b_ims = al(sizeof(void*) * (size_t)n_fov), b_fstart = al(sizeof(int) * (size_t)(n_fov + 1)), b_fof = al(sizeof(int) * (size_t)n);
+  const size_t up_bytes = b_seeds + b_ims + b_fstart + b_fof;
   const size_t b_state = al(sizeof(SeedState) * (size_t)n), b_nvox = al(sizeof(int) * (size_t)n), b_nfev = b_nvox,
                b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = al(sizeof(StageCtl)),
-               b_ovf = 256;
-  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf;
+               b_ovf = 256, b_fties = al(sizeof(int) * (size_t)n_fov), b_fcnt = al(4 * sizeof(unsigned long long) * (size_t)n_fov);
+  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf + b_fties + b_fcnt;
   const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
   const size_t b_ncnt = al(sizeof(int) * (size_t)n), b_nidx = al(sizeof(int) * MAXNB * (size_t)n);
   const size_t b_tflag = al(sizeof(int) * (size_t)n), b_tlost = al(sizeof(unsigned long long) * SLOTS * (size_t)n);
@@ -1263,6 +1345,10 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   char* base = (char*)f->pool;
   size_t o = 0;
   f->d_seeds = base + o; o += b_seeds;
+  char* meta0 = base + o;
+  f->d_ims = base + o; o += b_ims;
+  f->d_fov_start = base + o; o += b_fstart;
+  f->d_fov_of = base + o; o += b_fof;
   f->d_ball = (void*)d_ball;
   char* zero0 = base + o;
   f->d_state = base + o; o += b_state;
@@ -1270,6 +1356,8 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   f->d_nfev = base + o; o += b_nfev;
   f->d_conv = base + o; o += b_conv;
   f->d_done = base + o; o += b_done;
+  f->d_fov_ties = base + o; o += b_fties;
+  f->d_fov_counters = base + o; o += b_fcnt;
   // [counters | n_iter | stage control | overflow flag | rows]: contiguous, so the results come back in ONE
   // device-to-host copy (every separate copy into pageable memory costs a ~25 us round trip)
   f->d_counters = base + o; o += b_cnt;
@@ -1283,22 +1371,45 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
   f->d_tie_lost = base + o;
   hipStream_t st = stream();
   hipError_t e = hipSuccess;
-  if (n && centers_zxy) {   // seeds from the host: staged in the fitter (the copy is asynchronous)
+  // the three small tables: stack pointers, seed ranges, field of every seed
+  {
+    std::vector<char>& m = f->meta_stage;
+    m.assign(b_ims + b_fstart + b_fof, 0);
+    for (int k = 0; k < n_fov; ++k) { const void* d = fovs[k].im->d; memcpy(m.data() + sizeof(void*) * (size_t)k, &d, sizeof(void*)); }
+    memcpy(m.data() + b_ims, f->fov_start.data(), sizeof(int) * (size_t)(n_fov + 1));
+    int* fof = (int*)(m.data() + b_ims + b_fstart);
+    for (int k = 0; k < n_fov; ++k) for (int i = f->fov_start[k]; i < f->fov_start[k + 1]; ++i) fof[i] = k;
+    e = hipMemcpyAsync(meta0, m.data(), m.size(), hipMemcpyHostToDevice, st);
+  }
+  // seeds: from the host (staged in the fitter: the copy is asynchronous) or already resident (device-to-device)
+  bool all_host = true, any_host = false;
+  for (int k = 0; k < n_fov; ++k) { if (fovs[k].n) { if (fovs[k].host_zxy) any_host = true; else all_host = false; } }
+  if (any_host) {
     std::vector<char>& host = f->host_stage;
     host.assign(sizeof(double) * 3 * (size_t)n, 0);
-    memcpy(host.data(), centers_zxy, host.size());
-    f->host_seeds.assign(centers_zxy, centers_zxy + 3 * (size_t)n);
-    e = hipMemcpyAsync(f->d_seeds, host.data(), host.size(), hipMemcpyHostToDevice, st);
+    for (int k = 0; k < n_fov; ++k)
+      if (fovs[k].n && fovs[k].host_zxy)
+        memcpy(host.data() + sizeof(double) * 3 * (size_t)f->fov_start[k], fovs[k].host_zxy, sizeof(double) * 3 * (size_t)fovs[k].n);
+    if (all_host) f->host_seeds.assign((const double*)host.data(), (const double*)host.data() + 3 * (size_t)n);
+  }
+  for (int k = 0; k < n_fov && e == hipSuccess; ++k) {
+    if (!fovs[k].n) continue;
+    char* dst = (char*)f->d_seeds + sizeof(double) * 3 * (size_t)f->fov_start[k];
+    const size_t bytes = sizeof(double) * 3 * (size_t)fovs[k].n;
+    if (fovs[k].host_zxy)
+      e = hipMemcpyAsync(dst, f->host_stage.data() + sizeof(double) * 3 * (size_t)f->fov_start[k], bytes, hipMemcpyHostToDevice, st);
+    else if (n_fov > 1)   // (a single resident list is copied by fit_init_k itself: one launch less on the per-FOV path)
+      e = hipMemcpyAsync(dst, fovs[k].dev_zxy, bytes, hipMemcpyDeviceToDevice, st);
   }
   if (e != hipSuccess) { ia3_fit_destroy(f); return set_error(IA3_EHIP, "fitter setup failed: %s", hipGetErrorString(e)); }
   {
     InitArgs ia;
     const size_t head0 = (size_t)((char*)f->d_counters - zero0);
-    ia.zero0 = (uint4*)zero0; ia.zero_words = head0 / 16;           // [state .. done]; the head block is set by name
+    ia.zero0 = (uint4*)zero0; ia.zero_words = head0 / 16;           // [state .. field counters]; the head block is set by name
     ia.rows = (uint4*)f->d_ps; ia.row_words = b_ps / 16;
     ia.counters = (unsigned long long*)f->d_counters; ia.niter = (int*)f->d_niter; ia.ctl = (StageCtl*)f->d_ctl;
     ia.ovf = (int*)f->d_nbr_overflow;
-    ia.seeds = (double*)f->d_seeds; ia.src = centers_zxy ? nullptr : d_centers_zxy;
+    ia.seeds = (double*)f->d_seeds; ia.src = (n_fov == 1 && !fovs[0].host_zxy) ? fovs[0].dev_zxy : nullptr;
     ia.n = n;
     size_t words = ia.zero_words > ia.row_words ? ia.zero_words : ia.row_words;
     unsigned blocks = (unsigned)((words + 255) / 256);
@@ -1312,7 +1423,8 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
     ProfScope ps("nbr_build");
     hipLaunchKernelGGL(nbr_build_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)f->d_seeds, n, rr * rr,
                        (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow, (const int*)d_ball, nball,
-                       im->Z, im->X, im->Y, (int*)f->d_tie_flag, &((StageCtl*)f->d_ctl)->ties);
+                       im->Z, im->X, im->Y, (int*)f->d_tie_flag, &((StageCtl*)f->d_ctl)->ties,
+                       (const int*)f->d_fov_of, (const int*)f->d_fov_start, (int*)f->d_fov_ties);
   }
   {
     hipError_t le = hipGetLastError();
@@ -1324,8 +1436,9 @@ static int fit_create_impl(const ia3_stack* im, const double* centers_zxy, const
 
 int ia3_fit_create(const ia3_stack* im, const double* centers_zxy, int n, const ia3_fit_params* p,
                    ia3_fitter** out) {
-  if (n > 0 && !centers_zxy) return set_error(IA3_EINVAL, "bad argument");
-  return fit_create_impl(im, centers_zxy, nullptr, n, p, out);
+  if (!im || n < 0 || (n > 0 && !centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
+  const FovSeeds one{im, centers_zxy, nullptr, n};
+  return fit_create_impl(&one, 1, p, out);
 }
 
 }  // extern "C"
@@ -1339,8 +1452,33 @@ void fit_host_counters(const ia3_fitter* f, long long out[5]) {
   for (int k = 0; k < 5; ++k) out[k] = (long long)f->host_counters[k];
 }
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out) {
-  return fit_create_impl(im, nullptr, d_centers_zxy, n, p, out);
+  if (!im || n < 0 || (n > 0 && !d_centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
+  const FovSeeds one{im, nullptr, d_centers_zxy, n};
+  return fit_create_impl(&one, 1, p, out);
 }
+// one fitter over several fields of view (same shape and dtype, at most fit_max_fovs() of them): seeds resident per field
+int fit_max_fovs() { return MAX_FOV; }
+int fit_create_multi(const ia3_stack* const* ims, const double* const* d_centers_zxy, const int* n_seeds, int n_fov,
+                     const ia3_fit_params* p, ia3_fitter** out) {
+  std::vector<FovSeeds> v((size_t)(n_fov > 0 ? n_fov : 0));
+  for (int k = 0; k < n_fov; ++k) v[(size_t)k] = FovSeeds{ims[k], nullptr, d_centers_zxy[k], n_seeds[k]};
+  return fit_create_impl(v.data(), n_fov, p, out);
+}
+// after ia3_fit_results(_ex): per field its sweep count and its fits / evaluations / voxel evaluations
+int fit_fov_results(ia3_fitter* f, int* n_iter, long long* counters3) {
+  const int nf = (int)f->ims.size();
+  std::vector<int> it((size_t)nf);
+  std::vector<unsigned long long> c(4 * (size_t)nf);
+  IA3_HIP(hipStreamSynchronize(stream()));
+  IA3_HIP(hipMemcpy(it.data(), f->d_niter, sizeof(int) * (size_t)nf, hipMemcpyDeviceToHost));
+  IA3_HIP(hipMemcpy(c.data(), f->d_fov_counters, sizeof(unsigned long long) * 4 * (size_t)nf, hipMemcpyDeviceToHost));
+  for (int k = 0; k < nf; ++k) {
+    if (n_iter) n_iter[k] = it[(size_t)k];
+    if (counters3) for (int j = 0; j < 3; ++j) counters3[3 * k + j] = (long long)c[4 * (size_t)k + j];
+  }
+  return IA3_OK;
+}
+const int* fit_fov_starts(const ia3_fitter* f) { return f->fov_start.data(); }
 }  // namespace ia3k
 
 extern "C" {
@@ -1387,34 +1525,50 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
 // voxels it loses.  Fields without ties — every isolated-spot field — never come here.
 static int resolve_ties(ia3_fitter* f) {
   hipStream_t st = stream();
-  const int n = f->n;
-  if (f->host_seeds.empty()) {   // the seed list never left the device: fetch it now
+  const int n = f->n, nf = (int)f->ims.size();
+  std::vector<int> flagged((size_t)nf, 1);
+  if (f->host_seeds.empty()) {   // the seed list never left the device: fetch it now, with the per-field tie flags
     f->host_seeds.resize(3 * (size_t)n);
     IA3_HIP(hipMemcpyAsync(f->host_seeds.data(), f->d_seeds, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipStreamSynchronize(st));
   }
-  std::vector<ia3::KdNode> nodes;
-  std::vector<int> perm;
-  KdTree t;
-  ia3k::kd_build(f->host_seeds.data(), n, nodes, perm, t.mins, t.maxes);
+  IA3_HIP(hipMemcpyAsync(flagged.data(), f->d_fov_ties, sizeof(int) * (size_t)nf, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  // one tree per field that has ties (cKDTree(self.centers) of that image, Fitting_v4.py:601)
+  struct Built { int fov; std::vector<ia3::KdNode> nodes; std::vector<int> perm; KdTree t; size_t off_nodes, off_perm; };
+  std::vector<Built> trees;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t bn = al(nodes.size() * sizeof(ia3::KdNode)), bi = al(perm.size() * sizeof(int));
+  size_t total = 0;
+  for (int k = 0; k < nf; ++k) {
+    const int s0 = f->fov_start[(size_t)k], nk = f->fov_start[(size_t)k + 1] - s0;
+    if (!flagged[(size_t)k] || nk == 0) continue;
+    trees.emplace_back();
+    Built& b = trees.back();
+    b.fov = k;
+    ia3k::kd_build(f->host_seeds.data() + 3 * (size_t)s0, nk, b.nodes, b.perm, b.t.mins, b.t.maxes);
+    b.off_nodes = total; total += al(b.nodes.size() * sizeof(ia3::KdNode));
+    b.off_perm = total; total += al(b.perm.size() * sizeof(int));
+  }
   if (f->kd_block) { ws_put(f->kd_block); f->kd_block = nullptr; }
-  f->kd_block = ws_get(bn + bi);
+  f->kd_block = ws_get(total ? total : 256);
   if (!f->kd_block) return IA3_ENOMEM;
-  f->kd_stage.resize(bn + bi);
-  memcpy(f->kd_stage.data(), nodes.data(), nodes.size() * sizeof(ia3::KdNode));
-  memcpy(f->kd_stage.data() + bn, perm.data(), perm.size() * sizeof(int));
-  IA3_HIP(hipMemcpyAsync(f->kd_block, f->kd_stage.data(), bn + bi, hipMemcpyHostToDevice, st));
-  t.nodes = (const ia3::KdNode*)f->kd_block;
-  t.indices = (const int*)((char*)f->kd_block + bn);
-  t.data = (const double*)f->d_seeds;
-  t.n = n;
+  f->kd_stage.assign(total, 0);
+  for (const Built& b : trees) {
+    memcpy(f->kd_stage.data() + b.off_nodes, b.nodes.data(), b.nodes.size() * sizeof(ia3::KdNode));
+    memcpy(f->kd_stage.data() + b.off_perm, b.perm.data(), b.perm.size() * sizeof(int));
+  }
+  if (total) IA3_HIP(hipMemcpyAsync(f->kd_block, f->kd_stage.data(), total, hipMemcpyHostToDevice, st));
   FitArgs a = make_args(f);
   {
     ProfScope ps("voronoi_ties");
-    hipLaunchKernelGGL(voronoi_ties_k, dim3((unsigned)n), dim3(64), 0, st, a, t, (const int*)f->d_tie_flag,
-                       (unsigned long long*)f->d_tie_lost, &((StageCtl*)f->d_ctl)->abort);
+    for (Built& b : trees) {
+      const int s0 = f->fov_start[(size_t)b.fov], nk = f->fov_start[(size_t)b.fov + 1] - s0;
+      b.t.nodes = (const ia3::KdNode*)((char*)f->kd_block + b.off_nodes);
+      b.t.indices = (const int*)((char*)f->kd_block + b.off_perm);
+      b.t.data = (const double*)f->d_seeds + 3 * (size_t)s0;
+      b.t.n = nk;
+      hipLaunchKernelGGL(voronoi_ties_k, dim3((unsigned)nk), dim3(64), 0, st, a, b.t, s0, (const int*)f->d_tie_flag,
+                         (unsigned long long*)f->d_tie_lost, &((StageCtl*)f->d_ctl)->abort);
+    }
   }
   IA3_KCHECK();
   f->ties_resolved = true;
@@ -1439,7 +1593,8 @@ static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
     int rc = launch_stages(f, stage, s1, fresh); if (rc) return rc;
     const bool with_first = stage == 0 && !f->ties_resolved;   // this launch may have left at once: exact Voronoi ties
     if (s1 >= last && !with_first) break;
-    rc = fetch_block(f, true); if (rc) return rc;
+    const bool rows_now = f->n <= 16384;   // a batch of fields: the (large) row table is fetched once, at the end
+    rc = fetch_block(f, rows_now); if (rc) return rc;
     StageCtl hc;
     memcpy(&hc, f->host_stage.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));
     if (hc.abort == 2 && with_first) {
@@ -1450,8 +1605,8 @@ static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
     rc = check_ctl(hc); if (rc) return rc;
     fresh = false;
     stage = s1;
-    if (stage >= last) { f->cached = true; break; }
-    if (hc.n_unconv <= 0) { f->cached = true; break; }
+    if (stage >= last) { f->cached = rows_now; break; }
+    if (hc.n_unconv <= 0) { f->cached = rows_now; break; }
   }
   return IA3_OK;
 }
@@ -1530,7 +1685,10 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
     }
     if (!have || nvox || success) IA3_HIP(hipStreamSynchronize(st));
     memcpy(f->host_counters, hb.data(), sizeof(f->host_counters));
-    if (n_iter) memcpy(n_iter, hb.data() + ((char*)f->d_niter - (char*)f->d_counters), sizeof(int));
+    if (n_iter) {   // the sweeps of the field that needed most (one field: its n_iter)
+      const int* it = (const int*)(hb.data() + ((char*)f->d_niter - (char*)f->d_counters));
+      for (size_t k = 0; k < f->ims.size(); ++k) if (it[k] > *n_iter) *n_iter = it[k];
+    }
     memcpy(&hc, hb.data() + ((char*)f->d_ctl - (char*)f->d_counters), sizeof(StageCtl));
     memcpy(&ovf, hb.data() + ((char*)f->d_nbr_overflow - (char*)f->d_counters), sizeof(int));
     if (rows) memcpy(ps, hb.data() + head, rows);

@@ -121,6 +121,14 @@ struct SeedDev {
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
 // fitter from centres that are already resident (n x 3 float64)
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
+// one fitter over several resident fields of view (same shape and dtype; at most fit_max_fovs()): seeds of field k =
+// n_seeds[k] x 3 float64 at d_centers_zxy[k].  fit_fov_results (after ia3_fit_results(_ex)): per field its sweep count and
+// its fits / evaluations / voxel evaluations; fit_fov_starts: n_fov + 1 row offsets of the fields in the row table
+int fit_max_fovs();
+int fit_create_multi(const ia3_stack* const* ims, const double* const* d_centers_zxy, const int* n_seeds, int n_fov,
+                     const ia3_fit_params* p, ia3_fitter** out);
+int fit_fov_results(ia3_fitter* f, int* n_iter, long long* counters3);
+const int* fit_fov_starts(const ia3_fitter* f);
 // fits run / model evaluations / voxel evaluations / shader cycles in dependency waits / wave cycles of a fitter, as of its
 // last ia3_fit_results(_ex)
 void fit_host_counters(const ia3_fitter* f, long long out[5]);

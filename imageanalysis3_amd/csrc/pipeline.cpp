@@ -141,10 +141,65 @@ void pool_run(int workers, const std::function<void()>& fn) {
 }  // namespace
 
 // A batch of independent FOVs from ONE caller thread.  The reference spreads its per-image tasks over an mp.Pool
-// (classes/field_of_view.py:1129-1142); here `in_flight` library threads take the jobs in order, each with its own pair
-// of HIP streams (runtime.cpp ThreadCtx) and its own pinned staging ring, so the upload of one FOV, the filters of
-// another and the long tail of a third one's fit kernel (uint16 stacks: a few plateau-duplicate seeds that run to
-// maxfev) overlap on the device.  Results are exactly those of ia3_fit_fov_dev job by job.
+// (classes/field_of_view.py:1129-1142).  Here the batch runs as a two-stage pipeline over groups of `in_flight` images:
+//   stage A  `in_flight` library threads, each with its own pair of HIP streams (runtime.cpp ThreadCtx) and its own
+//            pinned staging ring: upload (host jobs) and get_seeds of one image each; the seed list stays on the device;
+//   stage B  one more thread: ONE fitter over all the images of a group (fit.hip, FitArgs: the work list runs over the
+//            seeds of every field), while stage A is already seeding the next group.
+// What makes a lone image slow — a chain of dependent refits in a crowded territory, a plateau-duplicate seed that refits
+// noise to maxfev in every sweep — occupies one wave; in a group fit the other 2047 waves work on the other
+// images' seeds meanwhile.  Results are exactly those of ia3_fit_fov_dev job by job (same kernels, same per-seed
+// arithmetic; neighbours, Voronoi ties and sweep order never cross an image).
+namespace {
+struct Slot {
+  ia3_stack* up = nullptr;          // uploaded here (host jobs): freed after the group's fit
+  const ia3_stack* im = nullptr;
+  ia3k::SeedDev sd;
+  int n = 0;
+  bool seeded = false, fitted = false;
+};
+
+int fit_group(ia3_fov_job* jobs, std::vector<std::unique_ptr<Slot>>& slots, int lo, int hi, const ia3_fit_params* fp,
+              std::vector<std::string>& errs) {
+  std::vector<int> members;
+  for (int k = lo; k < hi; ++k)
+    if (!jobs[k].rc && !slots[(size_t)k]->fitted && slots[(size_t)k]->n > 0) members.push_back(k);
+  if (members.empty()) return IA3_OK;
+  std::vector<const ia3_stack*> ims;
+  std::vector<const double*> seeds;
+  std::vector<int> ns;
+  for (int k : members) { ims.push_back(slots[(size_t)k]->im); seeds.push_back(slots[(size_t)k]->sd.d_zxy); ns.push_back(slots[(size_t)k]->n); }
+  ia3_fitter* f = nullptr;
+  int rc = ia3k::fit_create_multi(ims.data(), seeds.data(), ns.data(), (int)members.size(), fp, &f);
+  std::vector<float> ps;
+  std::vector<int> iters(members.size());
+  std::vector<long long> cnt(3 * members.size());
+  if (!rc) rc = ia3_fit_run(f);
+  if (!rc) {
+    size_t tot = 0;
+    for (int v : ns) tot += (size_t)v;
+    ps.resize(tot * 11);
+    rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, nullptr);
+  }
+  if (!rc) rc = ia3k::fit_fov_results(f, iters.data(), cnt.data());
+  if (!rc) {
+    const int* st = ia3k::fit_fov_starts(f);
+    for (size_t m = 0; m < members.size(); ++m) {
+      ia3_fov_job& j = jobs[members[m]];
+      j.n_iter = iters[m];
+      j.fits = cnt[3 * m]; j.nfev = cnt[3 * m + 1]; j.voxel_evals = cnt[3 * m + 2];
+      const int r = filter_rows(ims[m], ps.data() + (size_t)st[m] * 11, ns[m], j.rows, j.capacity, &j.n_rows);
+      if (r) { j.rc = r; errs[(size_t)members[m]] = ia3_last_error(); }
+    }
+  } else {
+    const std::string msg = ia3_last_error();
+    for (int k : members) { jobs[k].rc = rc; errs[(size_t)k] = msg; }
+  }
+  ia3_fit_destroy(f);
+  return IA3_OK;
+}
+}  // namespace
+
 extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int X, int Y, const ia3_seed_params* sp,
                             const ia3_fit_params* fp, int in_flight) {
   int rc = ensure_init(); if (rc) return rc;
@@ -153,30 +208,94 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
     if (!jobs[k].host && !jobs[k].dev) return set_error(IA3_EINVAL, "job %d has neither a host nor a resident stack", k);
   if (n_jobs == 0) return IA3_OK;
   if (in_flight <= 0) in_flight = 4;
-  if (in_flight > 16) in_flight = 16;
+  if (in_flight > 64) in_flight = 64;
   if (in_flight > n_jobs) in_flight = n_jobs;
-  std::atomic<int> next{0};
   std::vector<std::string> errs((size_t)n_jobs);
-  auto worker = [&]() {
-    const int init_rc = ensure_init();   // this thread's streams
-    for (;;) {
-      const int k = next.fetch_add(1);
-      if (k >= n_jobs) break;
+  for (int k = 0; k < n_jobs; ++k) {
+    ia3_fov_job& j = jobs[k];
+    j.n_rows = j.n_seeds = j.n_iter = 0;
+    j.fits = j.nfev = j.voxel_evals = 0;
+    j.rc = 0;
+  }
+  if (in_flight <= 1) {   // one image at a time: the plain per-FOV path
+    for (int k = 0; k < n_jobs; ++k) {
       ia3_fov_job& j = jobs[k];
-      j.n_rows = j.n_seeds = j.n_iter = 0;
-      j.fits = j.nfev = j.voxel_evals = 0;
       ia3_stack* up = nullptr;
-      int r = init_rc;
-      if (!r && !j.dev) r = ia3_stack_upload(j.host, dtype, Z, X, Y, &up);
+      int r = IA3_OK;
+      if (!j.dev) r = ia3_stack_upload(j.host, dtype, Z, X, Y, &up);
       if (!r) r = ia3_fit_fov_dev(j.dev ? j.dev : up, sp, fp, j.rows, j.capacity, &j.n_rows, &j.n_seeds, &j.n_iter);
       if (!r) { j.fits = t_last_stats[0]; j.nfev = t_last_stats[1]; j.voxel_evals = t_last_stats[2]; }
       if (up) ia3_stack_free(up);
       j.rc = r;
       if (r) errs[(size_t)k] = ia3_last_error();
     }
-  };
-  if (in_flight <= 1) worker();
-  else pool_run(in_flight, worker);
+  } else {
+    const int G = in_flight < ia3k::fit_max_fovs() ? in_flight : ia3k::fit_max_fovs();   // images per group fit
+    const int W = in_flight < 16 ? in_flight : 16;                                       // seeding threads
+    const int groups = (n_jobs + G - 1) / G;
+    std::vector<std::unique_ptr<Slot>> slots((size_t)n_jobs);
+    for (auto& s : slots) s.reset(new Slot());
+    std::mutex mu;
+    std::condition_variable cv;
+    int groups_fitted = 0;                 // stage A runs at most two groups ahead of stage B (resident stacks)
+    std::atomic<int> next{0};
+    std::atomic<bool> fitter_taken{false};
+    auto stage_a = [&]() {
+      const int init_rc = ensure_init();   // this thread's streams
+      for (;;) {
+        const int k = next.fetch_add(1);
+        if (k >= n_jobs) break;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return k / G < groups_fitted + 2; });
+        }
+        ia3_fov_job& j = jobs[k];
+        Slot& s = *slots[(size_t)k];
+        int r = init_rc;
+        if (!r && !j.dev) r = ia3_stack_upload(j.host, dtype, Z, X, Y, &s.up);
+        s.im = j.dev ? j.dev : s.up;
+        if (!r) r = ia3k::dog_seed_dev(s.im, *sp, s.sd);
+        if (!r) {
+          s.n = s.sd.on_device ? s.sd.n : (int)(s.sd.host.zxyh.size() / 4);
+          j.n_seeds = s.n;
+          if (s.n > 0 && !s.sd.on_device) {   // the rare host-side seed finish (> 8192 candidates): fitted here, on its own
+            r = fit_known_seeds(s.im, s.sd, s.n, fp, j.rows, j.capacity, &j.n_rows, &j.n_iter);
+            if (!r) { j.fits = t_last_stats[0]; j.nfev = t_last_stats[1]; j.voxel_evals = t_last_stats[2]; }
+            s.fitted = true;
+          }
+        }
+        if (r) { j.rc = r; errs[(size_t)k] = ia3_last_error(); }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          s.seeded = true;
+        }
+        cv.notify_all();
+      }
+    };
+    auto stage_b = [&]() {
+      (void)ensure_init();
+      for (int g = 0; g < groups; ++g) {
+        const int lo = g * G, hi = lo + G < n_jobs ? lo + G : n_jobs;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { for (int k = lo; k < hi; ++k) if (!slots[(size_t)k]->seeded) return false; return true; });
+        }
+        fit_group(jobs, slots, lo, hi, fp, errs);
+        for (int k = lo; k < hi; ++k) {   // the group's stacks and seed lists go back to the scratch cache
+          Slot& s = *slots[(size_t)k];
+          if (s.up) { ia3_stack_free(s.up); s.up = nullptr; }
+          slots[(size_t)k].reset(new Slot());
+          slots[(size_t)k]->seeded = true;
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          ++groups_fitted;
+        }
+        cv.notify_all();
+      }
+    };
+    pool_run(W + 1, [&]() { if (!fitter_taken.exchange(true)) stage_b(); else stage_a(); });
+  }
   for (int k = 0; k < n_jobs; ++k)
     if (jobs[k].rc) return set_error(jobs[k].rc, "FOV %d: %s", k, errs[(size_t)k].c_str());
   return IA3_OK;

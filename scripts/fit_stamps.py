@@ -31,9 +31,14 @@ for waves in (1, 2):
         cnt = np.zeros(32, np.uint64)
         L.check(lib.ia3_fit_counters(hh, cnt.ctypes.data_as(C.c_void_p)))
         lib.ia3_fit_destroy(hh)
-    tot = float(cnt[8:].sum())
+    tot = float(cnt[8:].sum() - cnt[8 + 15] - cnt[8 + 16])
     nw = 4 * 256 * waves
     print("waves/SIMD %d: fits %d nfev %d; stamped cycles per wave %.0f (%.1f us at 2.4 GHz)" % (waves, cnt[0], cnt[1], tot / nw, tot / nw / 2400))
+    if cnt[8 + 16]:
+        print("  fits counted in the per-fit phases: %d with %d evaluations -> per evaluation: geometry %.0f, voxel slots %.0f, cross-lane sums %.0f, algebra %.0f cycles"
+              % (cnt[8 + 16], cnt[8 + 15], cnt[8 + 6] / cnt[8 + 15], cnt[8 + 7] / cnt[8 + 15], cnt[8 + 8] / cnt[8 + 15], cnt[8 + 9] / cnt[8 + 15]))
     for k in range(24):
+        if k in (15, 16):
+            continue
         if cnt[8 + k]:
             print("  %-16s %6.2f %%  %9.0f cycles per fit" % (names.get(k, str(k)), 100 * float(cnt[8 + k]) / tot, float(cnt[8 + k]) / float(cnt[0])))

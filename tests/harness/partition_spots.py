@@ -1,7 +1,7 @@
-"""Spot-to-label lookups the spot-calling path uses (interface of the reference's classes/partition_spots.py:113-157,
+"""TEST HARNESS (not part of the product package). Spot-to-label lookups the spot-calling path uses (interface of the reference's classes/partition_spots.py:113-157,
 :212-236).  The gene-count tables, plots and file merging of ``Spots_Partition`` are downstream analysis, out of scope."""
 import numpy as np
-from .preprocess import Spots3D  # noqa: F401  (the spot container these helpers take)
+from imageanalysis3_amd.classes.preprocess import Spots3D  # noqa: F401  (the spot container these helpers take)
 
 default_search_radius = 4
 default_pixel_sizes = [250, 108, 108]

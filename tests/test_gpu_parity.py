@@ -742,7 +742,7 @@ def test_correct_fov_image_translation_functions():
 @pytest.mark.parametrize("tag,rescale,illum64", [("a", True, False), ("b", False, True)])
 def test_daxprocesser_steps_golden_bit_exact(tag, rescale, illum64, tmp_path):
     from conftest import build_chain_case, write_dax
-    from imageanalysis3_amd.classes.preprocess import DaxProcesser
+    from harness.dax_processer import DaxProcesser
     case = build_chain_case()
     g = load_golden("daxp.npz")
     chs = case["chs"]
@@ -815,6 +815,38 @@ def test_fit_fov_images_concurrent_equals_sequential():
         assert len(par) == len(seq)
         for a, b in zip(par, seq):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_group_fit_of_several_fields_equals_one_by_one():
+    """ia3_fit_fovs fits a group of images with ONE fitter (the work list runs over the seeds of every field, so the
+    dependent chains and maxfev fits of one field overlap with the others' work): neighbours, Voronoi ties and sweep
+    order never cross an image, so every table equals the one ia3_fit_fov_dev makes — isolated, crowded (exact ties:
+    the per-field seed trees) and uint16 fields of one shape mixed in one batch, more images than one group."""
+    import np_oracle as O
+    from imageanalysis3_amd import synth, _lib as L
+    shape = (30, 160, 160)
+    ims = []
+    for k in range(7):
+        layout = "clustered" if k % 2 else "isolated"
+        im, c, h = synth.make_fov(shape, 60 if layout == "isolated" else 90, 20 + k, layout=layout, n_territories=5)
+        ims.append(im)
+    ims.append(np.zeros(shape, np.float32) + 400)          # a field without seeds
+    sp, keep = L.make_seed_params(600.0, max_num_seeds=None)
+    fp = L.make_fit_params()
+    one = [L.fit_fovs([im], sp, fp, in_flight=1) for im in ims]
+    assert sum(len(t[0][0]) for t in one) > 300
+    for dtype in (np.float32, np.uint16):
+        batch = [im.astype(dtype) for im in ims] if dtype != np.float32 else ims
+        ref = one if dtype == np.float32 else [L.fit_fovs([im], sp, fp, in_flight=1) for im in batch]
+        for depth in (3, 8):
+            tabs, info = L.fit_fovs(batch, sp, fp, in_flight=depth)
+            for k, (t, i) in enumerate(zip(tabs, info)):
+                assert np.array_equal(t, ref[k][0][0]), (dtype, depth, k)
+                for key in ("n_seeds", "n_iter", "fits", "nfev", "voxel_evals"):
+                    assert i[key] == ref[k][1][0][key], (dtype, depth, k, key)
+    # and against the oracle (the reference's cKDTree rule on the crowded ones)
+    o = O.fit_fov_image(ims[1], "647", th_seed=600, max_num_seeds=None)
+    assert_rows_close(one[1][0][0], o, rtol=1e-6)
 
 
 def _set_gauss_cert(v):
@@ -1027,8 +1059,8 @@ def test_daxprocesser_fit_spots_by_segmentation_golden(tmp_path):
     kept spots and their labels; a label whose box holds no seed contributes nothing."""
     import contextlib, io
     from conftest import seg_labels, build_chain_case, write_dax
-    from imageanalysis3_amd.classes.preprocess import DaxProcesser
-    from imageanalysis3_amd.segmentation_tools.cell import segmentation_mask_2_bounding_box
+    from harness.dax_processer import DaxProcesser
+    from harness.cell import segmentation_mask_2_bounding_box
     g = load_golden("seg.npz")
     case = build_chain_case()
     size = [case["Z"], case["X"], case["Y"]]
@@ -1062,7 +1094,7 @@ def test_profiles_read_from_correction_folder(tmp_path):
     import contextlib, io, pickle
     from conftest import build_chain_case, chain_kwargs, write_dax
     from imageanalysis3_amd.io_tools.load import correct_fov_image
-    from imageanalysis3_amd.classes.preprocess import DaxProcesser, batch_process_image_quick
+    from harness.dax_processer import DaxProcesser, batch_process_image_quick
     case = build_chain_case()
     g = load_golden("chain.npz")
     Z, X, Y = case["Z"], case["X"], case["Y"]

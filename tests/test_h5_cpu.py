@@ -219,9 +219,10 @@ def test_segmentation_helpers_host_side(tmp_path):
     """Label lookup around spots (classes/partition_spots.py:113-140, :212-236), the mask bounding box
     (segmentation_tools/cell.py:598-611) and DaxProcesser's label / stage-position readers (:1184-1255)."""
     import pickle as pk
-    from imageanalysis3_amd.classes.partition_spots import Spots_Partition, find_coordinate_intensities
-    from imageanalysis3_amd.classes.preprocess import DaxProcesser, Spots3D
-    from imageanalysis3_amd.segmentation_tools.cell import segmentation_mask_2_bounding_box
+    from harness.partition_spots import Spots_Partition, find_coordinate_intensities
+    from harness.dax_processer import DaxProcesser
+    from imageanalysis3_amd.classes.preprocess import Spots3D
+    from harness.cell import segmentation_mask_2_bounding_box
     lab = np.zeros((6, 20, 20), np.int32)
     lab[:, 2:8, 2:8] = 1
     lab[:, 10:18, 9:16] = 7
