@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
                                                    const int* __restrict__ ball, int nball, int Z, int X, int Y,
                                                    int* __restrict__ tie_flag, int* __restrict__ ctl_ties,
                                                    const int* __restrict__ fov_of, const int* __restrict__ fov_start,
-                                                   int* __restrict__ fov_ties) {
+                                                   int* __restrict__ fov_ties, int* __restrict__ ctl_with_nbr) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_all) return;   // whole wave leaves together
@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
     cnt[i] = c;
     tie_flag[i] = any_tie ? 1 : 0;
     if (any_tie) { atomicOr(ctl_ties, 1); atomicOr(&fov_ties[fov], 1); }
+    if (c > 0) atomicAdd(ctl_with_nbr, 1);
   }
 }
 
@@ -918,7 +919,10 @@ __device__ __forceinline__ bool run_position(const FitArgs& fa, IA3_LDS WaveLds*
 // and bounded the kernel from below (profiles/r03a/fit_stamps.log).
 //   claim[0 .. NCLAIM-1]  stage 0 (first fits; they wait for nothing): the seeds are split into NCLAIM ranges, a wave
 //                         starts with the range of its block index and goes on to the others when that one is empty
-//   claim[NCLAIM]         later stages, in UNITS of 64 consecutive positions (one lane looks at each: most are skips)
+//   claim[NCLAIM]         later stages, in UNITS of up to 64 consecutive positions (one lane looks at each: most are
+//                         skips).  A unit is worked through by ONE wave, in order, so its size is chosen such that a
+//                         unit is expected to hold less than one position that really needs a refit: 64 for a field
+//                         of isolated spots, 1 for a crowded one (unit_size below)
 // A wave draws from claim[NCLAIM] only after it has seen every stage-0 range exhausted, i.e. when every first fit is in the
 // hands of a running wave; units are drawn in list order and worked through in order.  So whatever a position waits
 // for is either a first fit (running or done) or an earlier position of an earlier-or-same unit (running or done): the
@@ -929,7 +933,8 @@ struct StageCtl {
   int abort;                // 1: a spin-wait exceeded its bound (never expected); 2: exact Voronoi ties exist and no tie masks
                             // were supplied (the host resolves them and launches again); 3: tie queue overflow
   int ties;                 // nbr_build_k: some ball voxel is equidistant from its seed and another one
-  int pad[29];
+  int n_with_nbr;           // nbr_build_k: seeds whose ball overlaps another seed's (they need a separate sweep 1)
+  int pad[28];
   struct Claim { unsigned int next; unsigned int pad[31]; } claim[NCLAIM + 1];
 };
 static_assert(sizeof(StageCtl) == 128 * (NCLAIM + 2), "one 128-byte line per counter");
@@ -1061,7 +1066,16 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
   // own range first; then the refit sweeps in units of 64 positions, list order, each unit worked through in index order
   const int home = (int)(blockIdx.x % NCLAIM);
   const int later0 = stage0 > 1 ? stage0 : 1;
-  const unsigned per_stage = (unsigned)((n + 63) / 64);
+  // positions per unit of the refit sweeps: a power of two with n / (2 U) >= the positions expected to need a refit —
+  // sweep 1 behind the first fits: the seeds with neighbours; later sweeps: the seeds not converged so far (both
+  // counts are final before this launch started: same value in every wave)
+  int unit_size = 64;
+  {
+    const int* src = stage0 == 0 ? &ctl->n_with_nbr : &ctl->n_unconv;
+    const int needed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    while (unit_size > 1 && (long long)needed * 2 * unit_size > (long long)n) unit_size >>= 1;
+  }
+  const unsigned per_stage = (unsigned)((n + unit_size - 1) / unit_size);
   const unsigned units = stage1 > later0 ? per_stage * (unsigned)(stage1 - later0) : 0u;
   int r = stage0 == 0 ? 0 : NCLAIM;   // next stage-0 range to try; NCLAIM: every first fit is in the hands of a running wave
   unsigned long long m = 0ull;        // positions of the current unit that still want a refit
@@ -1082,11 +1096,11 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
       unsigned u;
       if (!units || !draw(&ctl->claim[NCLAIM], units, u)) break;
       uk = later0 + (int)(u / per_stage);
-      ui0 = (int)(u % per_stage) * 64;
+      ui0 = (int)(u % per_stage) * unit_size;
       // every lane looks at one position of the unit: already made (a seed without neighbours gets sweep 1 with its
       // first fit) or skipped for good (converged, 1 << 20) -> nothing to do; the rest in index order
       bool need = false;
-      if (ui0 + lane < n) need = __hip_atomic_load(&done[ui0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < uk + 1;
+      if (lane < unit_size && ui0 + lane < n) need = __hip_atomic_load(&done[ui0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < uk + 1;
       m = __ballot(need);
       continue;
     }
@@ -1424,7 +1438,8 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
     hipLaunchKernelGGL(nbr_build_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)f->d_seeds, n, rr * rr,
                        (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow, (const int*)d_ball, nball,
                        im->Z, im->X, im->Y, (int*)f->d_tie_flag, &((StageCtl*)f->d_ctl)->ties,
-                       (const int*)f->d_fov_of, (const int*)f->d_fov_start, (int*)f->d_fov_ties);
+                       (const int*)f->d_fov_of, (const int*)f->d_fov_start, (int*)f->d_fov_ties,
+                       &((StageCtl*)f->d_ctl)->n_with_nbr);
   }
   {
     hipError_t le = hipGetLastError();
@@ -1490,13 +1505,15 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   hipStream_t st = stream();
   if (fresh) {
     if (!f->pristine) {   // fit_init_k has armed the control record of a new fitter already
+      // n_unconv = n, abort = 0; the findings of nbr_build_k (ties, n_with_nbr) stay
       memset(&f->host_ctl, 0, sizeof(StageCtl));
       f->host_ctl.n_unconv = f->n;
-      IA3_HIP(hipMemcpyAsync(f->d_ctl, &f->host_ctl, sizeof(StageCtl), hipMemcpyHostToDevice, st));
+      static_assert(offsetof(StageCtl, n_unconv) == 0 && offsetof(StageCtl, abort) == 4, "the first two words are re-armed together");
+      IA3_HIP(hipMemcpyAsync(f->d_ctl, &f->host_ctl, 2 * sizeof(int), hipMemcpyHostToDevice, st));
     }
-  } else {
-    IA3_HIP(hipMemsetAsync((char*)f->d_ctl + offsetof(StageCtl, claim), 0, sizeof(StageCtl) - offsetof(StageCtl, claim), st));   // the ticket counters
   }
+  if (!fresh || !f->pristine)
+    IA3_HIP(hipMemsetAsync((char*)f->d_ctl + offsetof(StageCtl, claim), 0, sizeof(StageCtl) - offsetof(StageCtl, claim), st));   // the ticket counters
   f->pristine = false;
   long long blocks = (long long)(stage1 - stage0) * f->n;   // work-list positions; waves draw them as tickets
   const long long simds = 4LL * num_cus() * g_fit_waves;
