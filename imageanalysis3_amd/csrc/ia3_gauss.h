@@ -78,8 +78,11 @@ template <> __device__ __forceinline__ void buf_st<uint16_t>(uint16_t v, __amdgp
 }  // namespace ia3g
 
 // stack depths the column kernel is instantiated for (the column lives in registers: one kernel per depth, dtype and
-// variant, ~12 s of compile time each — extend the list for other production depths up to ~60 planes)
-#define IA3_FOLD_DEPTHS(X) X(30) X(40) X(50)
+// variant; one translation unit per (dtype, depth), built in parallel).  The Makefile passes the list (FOLD_DEPTHS); this is
+// its default for a compile outside make.
+#ifndef IA3_FOLD_DEPTHS
+#define IA3_FOLD_DEPTHS(X) X(25) X(30) X(33) X(35) X(40) X(45) X(50) X(60)
+#endif
 namespace ia3g {
 inline bool fold_depth(int Z) {
   switch (Z) {
@@ -91,8 +94,7 @@ inline bool fold_depth(int Z) {
 }
 
 
-// entry points of gauss_col_f32.hip / gauss_col_u16.hip (one translation unit per dtype: the kernels are long straight-line
-// code and compile for ~12 s each).  Return 0, a (negative) IA3 error code, or FOLD_NOT_COVERED when the depth is not
+// entry points of gauss_col_dispatch.hip (which picks the translation unit of the depth).  Return 0, a (negative) IA3 error code, or FOLD_NOT_COVERED when the depth is not
 // instantiated.  IA3 error codes are negative, the two private "nothing wrong, take the other path" codes positive.
 constexpr int FOLD_NOT_COVERED = 1;   // this depth / these radii have no column kernel: nothing was queued
 constexpr int FOLD_NO_FORK = 2;       // dog_pair_t: no auxiliary stream, everything ran on the main one (nothing to join)

@@ -893,8 +893,8 @@ def test_gaussian_long_filter_certified_fused_path_bit_exact():
 
 
 def test_gaussian_axis0_folded_column_pass_bit_exact():
-    """Stacks of 30 / 40 / 50 planes run the axis-0 pass of a long filter with the whole column in registers and the
-    border folded into the weights (IA3_TUNE_GAUSS_FOLD, a different summation order, certified like the fused path).
+    """Stacks of the built depths (Makefile FOLD_DEPTHS: 25 30 33 35 40 45 50 60) run the axis-0 pass of a long filter with
+    the whole column in registers and the border folded into the weights (IA3_TUNE_GAUSS_FOLD, a different summation order, certified like the fused path).
     Same bits as SciPy for both border modes, with the default guard, with every output sent through the reference
     sequence, with the guard forced wide open and with the folded form off, on inputs that sit on quantisation
     boundaries (see the test above)."""
@@ -904,7 +904,7 @@ def test_gaussian_axis0_folded_column_pass_bit_exact():
     from imageanalysis3_amd.correction_tools.filter import gaussian_filter
     rng = np.random.RandomState(12)
     try:
-        for Z in (30, 40, 50):
+        for Z in (25, 30, 33, 35, 40, 45, 50, 60):
             shape = (Z, 96, 192)
             blocks = np.zeros(shape, np.uint16)
             for i in range(2):
@@ -936,7 +936,7 @@ def test_gaussian_axis0_folded_column_pass_bit_exact():
 
 
 def test_dog_filter_pair_shared_axis0_launch_bit_exact():
-    """ia3_dog_filters_dev: the seed detector's two filtered stacks.  On 30 / 40 / 50 planes the two axis-0 passes come
+    """ia3_dog_filters_dev: the seed detector's two filtered stacks.  On the built depths (25 ... 60) the two axis-0 passes come
     from one launch (column in registers) and the short filter's other axes from the plane-wise kernel; other depths
     run the separate filters.  front == scipy gaussian_filter(im, 0.75), back == gaussian_filter1d(im, 7.5, axis=0),
     bit for bit, on ragged plane sizes, with the guard at its default, off and wide open."""
@@ -946,7 +946,8 @@ def test_dog_filter_pair_shared_axis0_launch_bit_exact():
     lib = L.lib()
     rng = np.random.RandomState(13)
     try:
-        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120), (45, 20, 96)):
+        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120), (45, 20, 96), (25, 40, 64),
+                        (33, 33, 128), (35, 48, 200), (60, 24, 160)):
             shape = (Z, X, Y)
             pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
             pos[:, :20, :20] = 0
