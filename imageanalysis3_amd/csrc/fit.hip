@@ -1532,6 +1532,16 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
   const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_counters);
   const size_t rows = with_rows ? sizeof(float) * 11 * (size_t)f->n : 0;
   f->host_stage.resize(head + rows);
+  // through the thread's pinned block when it fits (a copy into pageable memory is staged by the runtime) and a spinning
+  // wait: the table is microseconds away and the next image's first kernels wait for this thread
+  void *mh = nullptr, *md = nullptr;
+  constexpr size_t MAIL_OFF = 4096;   // the first page holds the seed stage's control words
+  if (head + rows <= (1u << 20) - MAIL_OFF && host_mailbox(1u << 20, &mh, &md) == IA3_OK) {
+    IA3_HIP(hipMemcpyAsync((char*)mh + MAIL_OFF, f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
+    int rc = stream_wait_spin(st); if (rc) return rc;
+    memcpy(f->host_stage.data(), (char*)mh + MAIL_OFF, head + rows);
+    return IA3_OK;
+  }
   IA3_HIP(hipMemcpyAsync(f->host_stage.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
   IA3_HIP(hipStreamSynchronize(st));
   return IA3_OK;

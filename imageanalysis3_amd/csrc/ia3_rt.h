@@ -22,6 +22,10 @@ int set_error(int code, const char* fmt, ...);
 int ensure_init();
 hipStream_t stream();
 int num_cus();  // compute units of the selected device
+// pinned, device-mapped host block of the calling thread (>= bytes, zero-initialised when it is made) and a stream wait
+// that spins on an event: small results reach the host without a copy into pageable memory and a sleeping synchronise
+int host_mailbox(size_t bytes, void** host, void** dev);
+int stream_wait_spin(hipStream_t st);
 int set_upload_threads(int n);   // IA3_TUNE_UPLOAD_THREADS
 inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 

@@ -31,6 +31,10 @@ struct ThreadCtx {
   hipStream_t main = nullptr, aux = nullptr, cur = nullptr;   // cur: what stream() hands out (aux inside an AuxScope)
   hipEvent_t fork = nullptr, join = nullptr;
   std::vector<void*> deferred;   // scratch blocks released inside an AuxScope
+  void* mail_host = nullptr;     // pinned, device-mapped host block of this thread (host_mailbox)
+  void* mail_dev = nullptr;
+  size_t mail_bytes = 0;
+  hipEvent_t mail_ev = nullptr;  // for wait_event_spin
 };
 static thread_local ThreadCtx t_ctx;
 
@@ -98,6 +102,36 @@ int ensure_init() {
 }
 static void ws_flush_deferred();
 hipStream_t stream() { return t_ctx.cur ? t_ctx.cur : t_ctx.main; }
+
+// A pinned host block of the calling thread that kernels can write (host pointer + the device's view of it).  Small
+// results — the seed count between the detector and the fit, the row table at the end — land here without a copy
+// command: a few words written by a kernel are visible to a polling host thread microseconds after the store, where a
+// device-to-host copy into pageable memory followed by a stream synchronisation costs 30-50 us.
+int host_mailbox(size_t bytes, void** host, void** dev) {
+  ThreadCtx& c = t_ctx;
+  if (c.mail_bytes < bytes) {
+    if (c.mail_host) (void)hipHostFree(c.mail_host);
+    c.mail_host = c.mail_dev = nullptr; c.mail_bytes = 0;
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipHostMalloc(&c.mail_host, want, hipHostMallocMapped) != hipSuccess) return set_error(IA3_ENOMEM, "pinned mailbox");
+    if (hipHostGetDevicePointer(&c.mail_dev, c.mail_host, 0) != hipSuccess) { (void)hipHostFree(c.mail_host); c.mail_host = nullptr; return set_error(IA3_EHIP, "pinned mailbox mapping"); }
+    memset(c.mail_host, 0, want);
+    c.mail_bytes = want;
+  }
+  *host = c.mail_host; *dev = c.mail_dev;
+  return IA3_OK;
+}
+// hipStreamSynchronize that spins on an event instead of sleeping (the results it waits for are microseconds away)
+int stream_wait_spin(hipStream_t st) {
+  ThreadCtx& c = t_ctx;
+  if (!c.mail_ev && hipEventCreateWithFlags(&c.mail_ev, hipEventDisableTiming) != hipSuccess) { c.mail_ev = nullptr; IA3_HIP(hipStreamSynchronize(st)); return IA3_OK; }
+  IA3_HIP(hipEventRecord(c.mail_ev, st));
+  for (;;) {
+    const hipError_t e = hipEventQuery(c.mail_ev);
+    if (e == hipSuccess) return IA3_OK;
+    if (e != hipErrorNotReady) return set_error(IA3_EHIP, "stream wait failed: %s", hipGetErrorString(e));
+  }
+}
 
 // Everything launched while an AuxScope is alive goes to the thread's auxiliary stream, which first waits for the work
 // queued on its main stream so far; aux_join() makes the main stream wait for the auxiliary work (typically right

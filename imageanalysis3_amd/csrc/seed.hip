@@ -16,6 +16,7 @@
 // Otherwise, and as the fallback when the lazy form's candidate list overflows: both filtered stacks are read once
 // (8 B/voxel for f32) by an LDS-tiled kernel with a rolling three-plane register pipeline along z.
 #include "ia3_rt.h"
+#include <immintrin.h>
 #include <algorithm>
 #include <math.h>
 #include <string.h>
@@ -662,12 +663,20 @@ __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__
                                                      const FinCtl* fc, const unsigned* __restrict__ hotcnt,
                                                      int hot_th, const unsigned* __restrict__ rank, int max_num,
                                                      double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw,
-                                                     const SeedCtl* __restrict__ lazy, unsigned cap0) {
+                                                     const SeedCtl* __restrict__ lazy, unsigned cap0,
+                                                     volatile unsigned* __restrict__ mail, unsigned seq) {
   const unsigned n = fin_n(sctl);
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {   // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
-    fcw->n_cand = sctl->n_cand;
-    fcw->overflow = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
+    const unsigned nc = sctl->n_cand;
+    const unsigned ov = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
+    fcw->n_cand = nc;
+    fcw->overflow = ov;
+    if (mail) {   // the four control words straight into the host's pinned mailbox, then the sequence number it polls
+      mail[1] = fcw->n_alive; mail[2] = (unsigned)fcw->chosen; mail[3] = nc; mail[4] = ov;
+      __threadfence_system();
+      mail[0] = seq;
+    }
   }
   if (i >= n) return;
   const double th = lev.th[fc->chosen];
@@ -961,6 +970,10 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       unsigned* hot = (unsigned*)(fb + o_hot);
       unsigned* rank = (unsigned*)(fb + o_rank);
       const int hot_th = p.remove_hot_pixel ? p.hot_pixel_th : 0;
+      void *mail_host = nullptr, *mail_dev = nullptr;
+      static thread_local unsigned t_seq = 0;
+      const unsigned seq = ++t_seq ? t_seq : ++t_seq;   // never 0 (the mailbox starts zeroed)
+      if (host_mailbox(64, &mail_host, &mail_dev) != IA3_OK) { mail_host = mail_dev = nullptr; }
       {
         ProfScope pf("seed_finish");
         hipLaunchKernelGGL(fin_levels_k, dim3(1), dim3(1024), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, p.min_dynamic_seeds, fc);
@@ -969,12 +982,29 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
         hipLaunchKernelGGL(fin_rank_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, fc, (const unsigned*)hot, hot_th, rank);
         hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_CAP / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc,
                            (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h), fc,
-                           lazy ? (const SeedCtl*)dlazy : (const SeedCtl*)nullptr, LAZY_CAP);
+                           lazy ? (const SeedCtl*)dlazy : (const SeedCtl*)nullptr, LAZY_CAP, (volatile unsigned*)mail_dev, seq);
       }
       FinCtl hfc;
       fe = hipGetLastError();
-      if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
-      if (fe == hipSuccess) fe = hipStreamSynchronize(s);
+      if (fe == hipSuccess && mail_host) {
+        // the count arrives in the pinned mailbox microseconds after the kernel's store: poll it (a copy into pageable
+        // memory + a sleeping synchronise cost 30-50 us of idle device between the detector and the fit)
+        volatile unsigned* mb = (volatile unsigned*)mail_host;
+        unsigned long long spins = 0;
+        while (mb[0] != seq) {
+          __builtin_ia32_pause();
+          if ((++spins & 0xfffff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {   // the stream drained (or failed) without the word
+            if (mb[0] == seq) break;
+            fe = hipStreamSynchronize(s);
+            if (fe == hipSuccess && mb[0] != seq) fe = hipErrorUnknown;
+            break;
+          }
+        }
+        hfc.n_alive = mb[1]; hfc.chosen = (int)mb[2]; hfc.n_cand = mb[3]; hfc.overflow = mb[4];
+      } else {
+        if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
+        if (fe == hipSuccess) fe = hipStreamSynchronize(s);
+      }
       if (fe != hipSuccess) return set_error(IA3_EHIP, "seed finish failed: %s", hipGetErrorString(fe));
       if (hfc.overflow & 2u)     // more first-stage candidates than the lazy path is sized for: dense filter instead
         return dog_seed_impl(im, p, out, dev, true);
