@@ -2,6 +2,9 @@
 // (spot_tools/fitting.py:169-237 fit_fov_image without the optional intensity normalisation).
 #include "ia3_rt.h"
 #include <math.h>
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <thread>
@@ -45,13 +48,20 @@ static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, 
     for (int i = 0; i < n; ++i) { c[3 * i] = sd.host.zxyh[4 * i]; c[3 * i + 1] = sd.host.zxyh[4 * i + 1]; c[3 * i + 2] = sd.host.zxyh[4 * i + 2]; }
     rc = ia3_fit_create(im, c.data(), n, fp, &f); if (rc) return rc;
   }
+  static const bool dbg = getenv("IA3_DEBUG_TIMES") != nullptr;
+  auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  const double t0 = dbg ? now() : 0;
   std::vector<float> ps((size_t)n * 11);
   rc = ia3_fit_run(f);
+  const double t1 = dbg ? now() : 0;
   if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
   if (!rc) ia3k::fit_host_counters(f, t_last_stats);
+  const double t2 = dbg ? now() : 0;
   ia3_fit_destroy(f);
   if (rc) return rc;
-  return filter_rows(im, ps.data(), n, out_rows, capacity, n_rows);
+  rc = filter_rows(im, ps.data(), n, out_rows, capacity, n_rows);
+  if (dbg) fprintf(stderr, "fit_known_seeds: create->run done %.1f us, results %.1f us, destroy+filter %.1f us\n", t1 - t0, t2 - t1, now() - t2);
+  return rc;
 }
 
 extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
