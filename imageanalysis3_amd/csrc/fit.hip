@@ -84,7 +84,7 @@ struct FitArgs {
   unsigned char* conv;      // n
   int* n_iter;              // n_fov: sweeps made per field (max over its seeds)
   unsigned long long* counters;  // [0] fits run, [1] function evaluations, [2] voxel evaluations (sum of nfev x voxels)
-  unsigned long long* fov_counters;   // n_fov x 4: the same three per field
+  unsigned long long* fov_counters;   // n_fov x 4: the same three per field; [3]: its seeds with neighbours (nbr_build_k)
   double min_ws, max_ws, init_w, delta_first, delta_repeat, dist_th2;
   int n_max_iter;
   double ftol, xtol, gtol; int maxfev; double factor;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
                                                    const int* __restrict__ ball, int nball, int Z, int X, int Y,
                                                    int* __restrict__ tie_flag, int* __restrict__ ctl_ties,
                                                    const int* __restrict__ fov_of, const int* __restrict__ fov_start,
-                                                   int* __restrict__ fov_ties, int* __restrict__ ctl_with_nbr) {
+                                                   int* __restrict__ fov_ties, unsigned long long* __restrict__ fov_with_nbr) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_all) return;   // whole wave leaves together
@@ -644,8 +644,13 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
     if (c > MAXNB) atomicMax(overflow, c);   // statistics only: consumers fall back to each_neighbour's scan
     cnt[i] = c;
     tie_flag[i] = any_tie ? 1 : 0;
-    if (any_tie) { atomicOr(ctl_ties, 1); atomicOr(&fov_ties[fov], 1); }
-    if (c > 0) atomicAdd(ctl_with_nbr, 1);
+    // (flags: a look before the atomic — a crowded field would otherwise send thousands of them to one word; the count of
+    // seeds with neighbours goes to the seed's own field, fit_stages_k adds the fields up)
+    if (any_tie) {
+      if (!__hip_atomic_load(ctl_ties, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(ctl_ties, 1);
+      if (!__hip_atomic_load(&fov_ties[fov], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&fov_ties[fov], 1);
+    }
+    if (c > 0) atomicAdd(&fov_with_nbr[4 * (size_t)fov + 3], 1ull);
   }
 }
 
@@ -933,8 +938,7 @@ struct StageCtl {
   int abort;                // 1: a spin-wait exceeded its bound (never expected); 2: exact Voronoi ties exist and no tie masks
                             // were supplied (the host resolves them and launches again); 3: tie queue overflow
   int ties;                 // nbr_build_k: some ball voxel is equidistant from its seed and another one
-  int n_with_nbr;           // nbr_build_k: seeds whose ball overlaps another seed's (they need a separate sweep 1)
-  int pad[28];
+  int pad[29];
   struct Claim { unsigned int next; unsigned int pad[31]; } claim[NCLAIM + 1];
 };
 static_assert(sizeof(StageCtl) == 128 * (NCLAIM + 2), "one 128-byte line per counter");
@@ -1067,13 +1071,20 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
   const int home = (int)(blockIdx.x % NCLAIM);
   const int later0 = stage0 > 1 ? stage0 : 1;
   // positions per unit of the refit sweeps: a power of two with n / (2 U) >= the positions expected to need a refit —
-  // sweep 1 behind the first fits: the seeds with neighbours; later sweeps: the seeds not converged so far (both
-  // counts are final before this launch started: same value in every wave)
+  // sweep 1 behind the first fits: the seeds with neighbours (counted per field by nbr_build_k); later sweeps: the
+  // seeds not converged so far (all counts are final before this launch started: same value in every wave)
   int unit_size = 64;
   {
-    const int* src = stage0 == 0 ? &ctl->n_with_nbr : &ctl->n_unconv;
-    const int needed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    while (unit_size > 1 && (long long)needed * 2 * unit_size > (long long)n) unit_size >>= 1;
+    long long needed;
+    if (stage0 == 0) {   // seeds with neighbours, summed over the fields
+      needed = 0;
+      for (int f = 0; f < fa.n_fov; ++f) needed += (long long)fa.fov_counters[4 * (size_t)f + 3];
+      needed = (long long)__builtin_amdgcn_readfirstlane((int)needed);
+      if (!fa.fuse) needed = n;   // (test knob: every seed takes a separate sweep 1)
+    } else {
+      needed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    while (unit_size > 1 && needed * 2 * unit_size > (long long)n) unit_size >>= 1;
   }
   const unsigned per_stage = (unsigned)((n + unit_size - 1) / unit_size);
   const unsigned units = stage1 > later0 ? per_stage * (unsigned)(stage1 - later0) : 0u;
@@ -1439,7 +1450,7 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
                        (int*)f->d_nbr_cnt, (int*)f->d_nbr_idx, (int*)f->d_nbr_overflow, (const int*)d_ball, nball,
                        im->Z, im->X, im->Y, (int*)f->d_tie_flag, &((StageCtl*)f->d_ctl)->ties,
                        (const int*)f->d_fov_of, (const int*)f->d_fov_start, (int*)f->d_fov_ties,
-                       &((StageCtl*)f->d_ctl)->n_with_nbr);
+                       (unsigned long long*)f->d_fov_counters);
   }
   {
     hipError_t le = hipGetLastError();
@@ -1505,7 +1516,7 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   hipStream_t st = stream();
   if (fresh) {
     if (!f->pristine) {   // fit_init_k has armed the control record of a new fitter already
-      // n_unconv = n, abort = 0; the findings of nbr_build_k (ties, n_with_nbr) stay
+      // n_unconv = n, abort = 0; the finding of nbr_build_k (ties) stays
       memset(&f->host_ctl, 0, sizeof(StageCtl));
       f->host_ctl.n_unconv = f->n;
       static_assert(offsetof(StageCtl, n_unconv) == 0 && offsetof(StageCtl, abort) == 4, "the first two words are re-armed together");

@@ -70,17 +70,21 @@ def test_bench_fov_window_vs_oracle(dtype):
     finite = ~np.isnan(po).any(1)
     slow = ~stuck & finite & (fo.nfev_peak >= 100)
     ok = ~stuck & finite & ~slow
-    assert ok.sum() >= 0.995 * len(so) - stuck.sum()
+    # every carve-out states how many rows it covers
+    cover = "rows %d: 1e-4 bar %d, slow (nfev >= 100, 2e-2 bar) %d, stuck (maxfev in the oracle) %d, NaN %d" % (
+        len(so), ok.sum(), slow.sum(), stuck.sum(), (~finite).sum())
+    print(cover)
+    assert ok.sum() >= 0.995 * len(so) - stuck.sum(), cover
     if slow.any():
-        assert _rel(pw[slow], po[slow]).max() <= 2e-2
+        assert _rel(pw[slow], po[slow]).max() <= 2e-2, cover
     assert np.isnan(pw).any(1).sum() == np.isnan(po).any(1).sum()
     rel = _rel(pw[ok], po[ok])
     if rel.max() > 1e-4:   # leave the evidence where gpurun collects it
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         np.savez(os.path.join(ROOT, "gpurun_out", "window_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw,
                  nfev_peak=fo.nfev_peak, nfev_last=fo.nfev_last, stuck=stuck)
-    assert rel.max() <= 1e-4, rel.max()
-    assert stuck.sum() <= (0 if dtype == np.float32 else 60)
+    assert rel.max() <= 1e-4, (rel.max(), cover)
+    assert stuck.sum() <= (0 if dtype == np.float32 else 60), cover
     # ---- device on the whole FOV: production-size launches ----------------------------------------------------------
     sf = get_seeds(im, th_seed=600.0, return_h=True)
     in_f = (sf[:, 1] < INNER) & (sf[:, 2] < INNER)
@@ -104,16 +108,18 @@ def test_bench_fov_window_vs_oracle(dtype):
     tied = np.zeros(len(so), dtype=bool)
     for i_, nb in enumerate(tree.query_ball_point(so[:, :3], 10.0 + 1e-9)):
         tied[i_] = any(k_ != i_ and so[k_, 3] == so[i_, 3] for k_ in nb)
-    assert tied.sum() <= (0 if dtype == np.float32 else 0.03 * len(so))
+    cover_t = "equal-height overlapping pairs left out: %d of %d rows" % (tied.sum(), len(so))
+    print(cover_t)
+    assert tied.sum() <= (0 if dtype == np.float32 else 0.03 * len(so)), cover_t
     sel = np.where(ok & ~tied & in_o & (so[:, 1] < INNER - 16) & (so[:, 2] < INNER - 16))[0]
     d, j = cKDTree(t[:, 1:4]).query(po[sel, 1:4])
     if d.max() >= 1e-3:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         np.savez(os.path.join(ROOT, "gpurun_out", "fullfov_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw, t=t, sf=sf,
                  sel=sel, nfev_peak=fo.nfev_peak, stuck=stuck)
-    assert len(sel) > 1000 and d.max() < 1e-3, d.max()
+    assert len(sel) > 1000 and d.max() < 1e-3, (d.max(), len(sel), cover_t)
     rel = _rel(t[j], po[sel])
-    assert rel.max() <= 1e-4, rel.max()
+    assert rel.max() <= 1e-4, (rel.max(), "compared rows %d" % len(sel), cover, cover_t)
 
 
 def test_drift_crops_full_size_vs_oracle():
