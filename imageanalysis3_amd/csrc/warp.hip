@@ -21,6 +21,12 @@ using namespace ia3rt;
 namespace {
 
 constexpr int NPAD = 12;
+// stack depths with an axis-0 pass of their own (the depths the column kernels of the filters are built for)
+#ifdef IA3_FOLD_DEPTHS
+#define IA3_WARP_DEPTHS(X) IA3_FOLD_DEPTHS(X)
+#else
+#define IA3_WARP_DEPTHS(X) X(25) X(30) X(33) X(35) X(40) X(45) X(50) X(60)
+#endif
 #define IA3_POLE3 (-0.26794919243112270647)
 
 template <class T> __device__ __forceinline__ T out_cvt(double t);
@@ -56,10 +62,39 @@ __global__ void spline_pad_k(const T* __restrict__ im, int Z, int X, int Y, doub
 }
 
 // start-of-line value of the causal recursion for the 'nearest'/'reflect' boundary (see header)
+// The sum runs over the whole line in SciPy.  When z^n underflows to zero (n >= 566) the mirror terms vanish exactly and
+// the sum is cut where the rest provably cannot change it: every remaining term is at most |z|^i * bound in magnitude
+// (bound = gain * largest |sample| the pass can meet), and an addend below a quarter ulp of the running sum leaves it
+// unchanged under round-to-nearest, so once |sum| * 2^-55 > |z|^i * bound all further additions are no-ops.  The test
+// is made after 64 terms and every 64 terms from there; a line whose leading samples are zero simply reads on.  The
+// largest sample is 65535 for uint16 sources and is measured for float32 ones (absmax_f32_k); each pass of the
+// prefilter can raise it by at most a factor 3 (the absolute sum of its impulse response).
 struct IirInit {
   double z, gain, zn, scale;  // zn = z^n ; scale = z / (1 - zn*zn)
-  int full;                   // 1: sum all n terms incl. the zn mirror terms; 0: first 64 terms (zn == 0 or negligible)
+  int full;                   // 1: zn != 0: sum all n terms incl. the mirror terms; 0: zn == 0, provable cut as above
+  double bound;               // 1.001 * gain * (largest |sample|, or 3^k when amax_bits holds the source's)
+  const unsigned* amax_bits;  // float32 sources: bits of max |im| (inf / NaN compare above every finite value)
 };
+
+__device__ __forceinline__ double iir_bound(const IirInit& q) {
+  return q.amax_bits ? q.bound * (double)__uint_as_float(*q.amax_bits) : q.bound;
+}
+// true when no later term of the start sum can change `s` (see IirInit); NaN / inf bounds never pass
+__device__ __forceinline__ bool iir_sum_settled(double s, double zi, double bound) {
+  return fabs(s) * 0x1p-55 > fabs(zi) * bound || (zi == 0.0 && bound < INFINITY);
+}
+
+// bits of max |im| over a float32 stack: |x| as an unsigned integer orders finite < inf < NaN
+__global__ __launch_bounds__(256) void absmax_f32_k(const float* __restrict__ im, size_t n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(im[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)m, o); m = v > m ? v : m; }
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+}
 
 // IIR along a strided axis: line p (lane along the contiguous axis), element i at base + i*stride
 __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__ P, int inner, size_t stride, int n,
@@ -78,16 +113,20 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
       zi *= z;
     }
   } else {
+    const double bound = iir_bound(q);
     s = c0;
     double zi = z;
-    const int m = n < 64 ? n : 64;
-    for (int i = 1; i < m; ++i) { s += zi * (c[(size_t)i * stride] * g); zi *= z; }
+    for (int i = 1; i < n;) {
+      const int e = i + 63 < n ? i + 63 : n;
+      for (; i < e; ++i) { s += zi * (c[(size_t)i * stride] * g); zi *= z; }
+      if (iir_sum_settled(s, zi, bound)) break;
+    }
   }
   s *= q.scale;
   s += c0;
   // The recursions are serial in `prev`, their loads are not: eight samples are fetched ahead of the eight dependent
   // updates, so a thread keeps eight loads in flight instead of one (the kernel ran at 1.6 TB/s, latency-bound).
-  constexpr int B = 8;
+  constexpr int B = 8;   // 16 in flight: no faster (2.36 against 2.25 ms)
   double prev = s;
   c[0] = prev;
   int i = 1;
@@ -169,20 +208,68 @@ __global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict_
   for (int i = 0; i < ZMAX; ++i) if (i < n) P[(size_t)i * plane + p] = c[i];
 }
 
-// IIR along the contiguous axis: every wave owns 64 lines (lane = line) and marches them in TW-element tiles that
-// are transposed through a wave-private LDS tile (row pieces of TW doubles = one 128-B line for TW = 16); narrow
-// tiles keep the LDS footprint at 8.7 KB per wave, so 16 waves per CU hide the latency of the serial recursion.
-template <int TW>
-__global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
+// The same pass for a padded depth N known at compile time (N = Z + 24 for the depths of IA3_WARP_DEPTHS): the line is
+// loaded once, all N loads in flight together, and the start sum runs on registers.  The generic kernel above walks the
+// source three times and its start-sum loop (trip count unknown to the compiler) waits for one load per term: 2.1 ms
+// of memory latency on a 50 x 2048 x 2048 stack.
+template <class T, int N>
+__global__ __launch_bounds__(256, 2) void spline_pad_iir0_n_k(const T* __restrict__ im, int X, int Y, double* __restrict__ P,
+                                                           IirInit q) {
+  constexpr int Z = N - 2 * NPAD;
+  const int Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
+  const size_t plane = (size_t)Xp * Yp;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= plane) return;
+  const int x = (int)(p / Yp), y = (int)(p - (size_t)x * Yp);
+  const T* col = im + (size_t)clampi(x - NPAD, X) * Y + clampi(y - NPAD, Y);
+  const double z = q.z, g = q.gain;
+  const size_t zs = (size_t)X * Y;
+  T raw[Z];
+#pragma unroll
+  for (int i = 0; i < Z; ++i) raw[i] = col[(size_t)i * zs];
+  double c[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) c[i] = (double)raw[i < NPAD ? 0 : (i - NPAD >= Z ? Z - 1 : i - NPAD)] * g;
+  const double c0 = c[0];
+  double s = c0 + q.zn * c[N - 1], zi = z;
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    s += zi * (c[i] + q.zn * c[N - 1 - i]);
+    zi *= z;
+  }
+  s *= q.scale;
+  s += c0;
+  double prev = s;
+  c[0] = prev;
+#pragma unroll
+  for (int i = 1; i < N; ++i) { const double v = c[i] + z * prev; c[i] = v; prev = v; }
+  prev = prev * (z / (z - 1.0));
+  c[N - 1] = prev;
+#pragma unroll
+  for (int i = N - 2; i >= 0; --i) { const double v = z * (prev - c[i]); c[i] = v; prev = v; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) P[(size_t)i * plane + p] = c[i];
+}
+
+// IIR along the contiguous axis: every wave owns LPW lines (lanes 0..LPW-1 run the recursions) and marches them in
+// TW-element tiles that are transposed through a wave-private LDS tile.  One wave instruction moves 64/TW row pieces of
+// TW doubles.  Measured on 74 x 2072 x 2072 (10 GB moved): 64 lines x 16 samples 3.10 ms, the same with the chain in
+// registers 2.9, 16 lines x 64 samples 2.5, 8 lines x 64 samples at four waves per SIMD 2.3 (4.3 TB/s of mixed reads
+// and writes): the pass wants many small waves with whole 512-byte pieces of a line per access, not wide tiles.
+template <int TW, int LPW, int OCC>
+__global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
   constexpr int RPI = 64 / TW;   // rows moved per wave instruction
-  __shared__ double tile[4][64][TW + 1];
+  constexpr int NR = LPW / RPI;  // wave instructions per tile
+  constexpr int SC = 16;         // samples of a line in registers at a time
+  static_assert(64 % TW == 0 && LPW % RPI == 0 && LPW <= 64, "tile shape");
+  __shared__ double tile[4][LPW][TW + 1];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
-  const size_t l0 = ((size_t)blockIdx.x * 4 + wv) * 64;
+  const size_t l0 = ((size_t)blockIdx.x * 4 + wv) * LPW;
   if (l0 >= n_lines) return;                 // whole wave
-  const bool mine = l0 + t < n_lines;
+  const bool mine = t < LPW && l0 + t < n_lines;
+  const int lt = t < LPW ? t : 0;            // row of the tile this lane's recursion runs on
   const int col = t % TW, rsub = t / TW;
   const double z = q.z, g = q.gain;
-  constexpr int NR = 64 / RPI;   // tile rows per lane (= TW)
   double pre[NR];                // next tile on its way from HBM while the current one is processed
   auto fetch = [&](int y0, int w, double scale) {
 #pragma unroll
@@ -196,16 +283,16 @@ __global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ 
     for (int j = 0; j < NR; ++j) tile[wv][j * RPI + rsub][col] = pre[j];
   };
   auto store_tile = [&](int y0, int w) {
-#pragma unroll 4
-    for (int r0 = 0; r0 < 64; r0 += RPI) {
-      const int r = r0 + rsub;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int r = j * RPI + rsub;
       if (l0 + r < n_lines && col < w) P[(l0 + r) * (size_t)n + y0 + col] = tile[wv][r][col];
     }
   };
   const int ntile = (n + TW - 1) / TW;
   // start value of the causal recursion (see make_init)
   double prev = 0.0;
-  if (q.full) {   // short lines (n <= 64): the sum needs the line from both ends, read it directly
+  if (q.full) {   // short lines: the sum needs the line from both ends, read it directly
     if (mine) {
       const double* line = P + (l0 + t) * (size_t)n;
       const double c0 = line[0] * g;
@@ -216,20 +303,24 @@ __global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ 
       s += c0;
       prev = s;
     }
-  } else {        // first 64 samples, through coalesced tiles (a lane reading its own line touches 64 cache lines per load)
-    const int m = n < 64 ? n : 64;
+  } else {        // until the sum is settled (IirInit), through coalesced tiles (a lane reading its own line touches 64 cache lines per load)
+    static_assert(64 % TW == 0, "the settled test is made at multiples of 64 terms");
+    const double bound = iir_bound(q);
     double s = 0.0, c0 = 0.0, zi = z;
-    for (int y0 = 0; y0 < m; y0 += TW) {
-      const int w = m - y0 < TW ? m - y0 : TW;
+    bool open = mine;   // this lane's sum can still change
+    for (int y0 = 0; y0 < n; y0 += TW) {
+      const int w = n - y0 < TW ? n - y0 : TW;
       fetch(y0, w, g);
       stash();
       __builtin_amdgcn_wave_barrier();
-      if (mine) {
+      if (open) {
         int i0 = 0;
-        if (y0 == 0) { c0 = tile[wv][t][0]; s = c0; i0 = 1; }
-        for (int i = i0; i < w; ++i) { s += zi * tile[wv][t][i]; zi *= z; }
+        if (y0 == 0) { c0 = tile[wv][lt][0]; s = c0; i0 = 1; }
+        for (int i = i0; i < w; ++i) { s += zi * tile[wv][lt][i]; zi *= z; }
+        if ((y0 + TW) % 64 == 0 && iir_sum_settled(s, zi, bound)) open = false;
       }
       __builtin_amdgcn_wave_barrier();
+      if (!__any(open)) break;
     }
     s *= q.scale;
     s += c0;
@@ -242,9 +333,22 @@ __global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ 
     __builtin_amdgcn_wave_barrier();
     if (k + 1 < ntile) fetch(y0 + TW, n - y0 - TW < TW ? n - y0 - TW : TW, g);
     if (mine) {
-      int i0 = 0;
-      if (k == 0) { tile[wv][t][0] = prev; i0 = 1; }
-      for (int i = i0; i < w; ++i) { const double v = tile[wv][t][i] + z * prev; tile[wv][t][i] = v; prev = v; }
+      if (w == TW && k > 0) {    // whole tile: the line's samples in registers, one dependent chain, no LDS in it
+#pragma unroll 1
+        for (int b = 0; b < TW; b += SC) {
+          double r[SC];
+#pragma unroll
+          for (int i = 0; i < SC; ++i) r[i] = tile[wv][lt][b + i];
+#pragma unroll
+          for (int i = 0; i < SC; ++i) { const double v = r[i] + z * prev; r[i] = v; prev = v; }
+#pragma unroll
+          for (int i = 0; i < SC; ++i) tile[wv][lt][b + i] = r[i];
+        }
+      } else {
+        int i0 = 0;
+        if (k == 0) { tile[wv][lt][0] = prev; i0 = 1; }
+        for (int i = i0; i < w; ++i) { const double v = tile[wv][lt][i] + z * prev; tile[wv][lt][i] = v; prev = v; }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     store_tile(y0, w);
@@ -260,9 +364,22 @@ __global__ __launch_bounds__(256) void spline_iir_contig_k(double* __restrict__ 
     __builtin_amdgcn_wave_barrier();
     if (k > 0) fetch(y0 - TW, TW, 1.0);
     if (mine) {
-      int i1 = w - 1;
-      if (k == ntile - 1) { prev = tile[wv][t][w - 1] * (z / (z - 1.0)); tile[wv][t][w - 1] = prev; i1 = w - 2; }
-      for (int i = i1; i >= 0; --i) { const double v = z * (prev - tile[wv][t][i]); tile[wv][t][i] = v; prev = v; }
+      if (w == TW && k < ntile - 1) {
+#pragma unroll 1
+        for (int b = TW - SC; b >= 0; b -= SC) {
+          double r[SC];
+#pragma unroll
+          for (int i = 0; i < SC; ++i) r[i] = tile[wv][lt][b + i];
+#pragma unroll
+          for (int i = SC - 1; i >= 0; --i) { const double v = z * (prev - r[i]); r[i] = v; prev = v; }
+#pragma unroll
+          for (int i = 0; i < SC; ++i) tile[wv][lt][b + i] = r[i];
+        }
+      } else {
+        int i1 = w - 1;
+        if (k == ntile - 1) { prev = tile[wv][lt][w - 1] * (z / (z - 1.0)); tile[wv][lt][w - 1] = prev; i1 = w - 2; }
+        for (int i = i1; i >= 0; --i) { const double v = z * (prev - tile[wv][lt][i]); tile[wv][lt][i] = v; prev = v; }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     store_tile(y0, w);
@@ -365,14 +482,21 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, (int)((size_t)Zp * Xp * Yp * sizeof(double)), 0x00020000);
+    const bool small = Xp < (1 << 24) && (unsigned)Yp * 8u < (1u << 24);
     const bool contig = idx[2][1] == idx[2][0] + 1 && idx[2][2] == idx[2][0] + 2 && idx[2][3] == idx[2][0] + 3;
     if (__all(contig)) {
       const unsigned y0 = (unsigned)idx[2][0] * 8u;
+      // row offsets as sums of two products instead of 16 full 32-bit multiplies (quarter rate): z*(plane bytes) is
+      // one such multiply per z tap, x*(row bytes) fits the 24-bit multiplier (x < Xp, row bytes < 2^24: checked)
+      const unsigned rowb = (unsigned)Yp * 8u, planeb = (unsigned)Xp * rowb;
+      unsigned zo[4], xo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { zo[i] = (unsigned)idx[0][i] * planeb + y0; xo[i] = small ? __umul24((unsigned)idx[1][i], rowb) : (unsigned)idx[1][i] * rowb; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const unsigned off = ((unsigned)idx[0][i] * (unsigned)Xp + (unsigned)idx[1][j]) * (unsigned)Yp * 8u + y0;
+          const unsigned off = zo[i] + xo[j];
           const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
           const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
           const double cv[4] = {__hiloint2double((int)lo.y, (int)lo.x), __hiloint2double((int)lo.w, (int)lo.z),
@@ -419,13 +543,16 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
   out[o] = out_cvt<T>(t);
 }
 
-IirInit make_init(int n) {
+// pass: 0, 1, 2 = how many passes of the prefilter the samples have been through; amax_bits: see IirInit
+IirInit make_init(int n, int pass, double src_max, const unsigned* amax_bits) {
   IirInit q;
   q.z = IA3_POLE3;
   q.gain = (1.0 - q.z) * (1.0 - 1.0 / q.z);
   q.zn = pow(q.z, (double)n);
   q.scale = q.z / (1.0 - q.zn * q.zn);
-  q.full = n <= 64 ? 1 : 0;  // else: first 64 terms, mirror terms (|z^n| < 4e-37) dropped
+  q.full = q.zn != 0.0 ? 1 : 0;
+  q.bound = 1.001 * q.gain * pow(3.0, (double)pass) * (amax_bits ? 1.0 : src_max);
+  q.amax_bits = amax_bits;
   return q;
 }
 
@@ -443,15 +570,37 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     return IA3_OK;
   }
   const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
-  Scratch P((size_t)Zp * Xp * Yp * sizeof(double));
+  const size_t coef_bytes = (size_t)Zp * Xp * Yp * sizeof(double);
+  Scratch P(coef_bytes + 256);
   if (!P.p) return IA3_ENOMEM;
   {
     ProfScope ps("spline_prefilter");
     const size_t plane = (size_t)Xp * Yp;
+    // largest |sample| of the source, for the cut of the start sums along long axes (IirInit)
+    const unsigned* amax = nullptr;
+    if (sizeof(T) == 4) {
+      unsigned* slot = (unsigned*)((char*)P.p + coef_bytes);
+      IA3_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
+      hipLaunchKernelGGL(absmax_f32_k, dim3(2048), dim3(256), 0, st, (const float*)im->d, (size_t)Z * X * Y, slot);
+      amax = slot;
+    }
     // axis 0: lines = (x,y) columns, stride = plane
-    IirInit qz = make_init(Zp);
+    IirInit qz = make_init(Zp, 0, 65535.0, amax);
     qz.full = 1;  // the faithful start sum is always affordable along the short z axis
-    if (Zp <= 80) {   // padded line fits in registers: pad + axis-0 recursion in one pass
+    bool done0 = false;
+    switch (Z) {
+#define IA3_WARP_DEPTH(D)                                                                                              \
+      case D:                                                                                                          \
+        hipLaunchKernelGGL((spline_pad_iir0_n_k<T, D + 2 * NPAD>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, \
+                           (const T*)im->d, X, Y, P.as<double>(), qz);                                                 \
+        done0 = true;                                                                                                  \
+        break;
+      IA3_WARP_DEPTHS(IA3_WARP_DEPTH)
+#undef IA3_WARP_DEPTH
+      default: break;
+    }
+    if (done0) {
+    } else if (Zp <= 80) {   // padded line fits in registers: pad + axis-0 recursion in one pass
       hipLaunchKernelGGL((spline_pad_iir0_k<T, 80>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const T*)im->d, Z, X, Y,
                          P.as<double>(), qz);
     } else {
@@ -461,14 +610,14 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
                          (int)plane, plane, Zp, (size_t)0, qz);
     }
     // axis 1: lines = (z,y), stride = Yp
-    IirInit qx = make_init(Xp);
-    if (Xp <= 256) qx.full = 1;
+    IirInit qx = make_init(Xp, 1, 65535.0, amax);
     hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
                        Yp, (size_t)Yp, Xp, plane, qx);
     // axis 2: contiguous lines (z,x)
-    IirInit qy = make_init(Yp);
+    IirInit qy = make_init(Yp, 2, 65535.0, amax);
     const size_t nl = (size_t)Zp * Xp;
-    hipLaunchKernelGGL((spline_iir_contig_k<16>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, P.as<double>(), nl, Yp, qy);
+    hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 4>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,
+                       Yp, qy);
   }
   {
     ProfScope ps("warp_cubic");

@@ -443,6 +443,43 @@ def test_warp_identity_and_integer_shift():
         warp_3d_image(im, [0, 0, 0], warp_order=3, border_mode="constant")
 
 
+def _start_sum_cases():
+    """Stacks whose long lines (> 566 padded samples: z^n underflows, the start sum of the prefilter is cut) begin with
+    samples that contribute nothing, so that terms far down the line decide the first coefficient."""
+    rng = np.random.RandomState(11)
+    Z, X, Y = 5, 600, 580
+    a = np.zeros((Z, X, Y), np.float32)                    # 150 zero rows / columns, then data
+    a[:, 150:, 150:] = rng.uniform(100, 4000, size=(Z, X - 150, Y - 150))
+    b = np.zeros((Z, X, Y), np.float32)                    # zeros, then values of 1e30: the tail dwarfs the head
+    b[:, 70:, 66:] = rng.uniform(1e29, 1e30, size=(Z, X - 70, Y - 66))
+    c = rng.uniform(1e-30, 1e-28, size=(Z, X, Y)).astype(np.float32)   # tiny head, huge tail
+    c[:, 200:, 130:] = rng.uniform(1e20, 1e24, size=(Z, X - 200, Y - 130))
+    d = np.zeros((Z, X, Y), np.uint16)                     # uint16 with a dark border
+    d[:, 90:-40, 120:-64] = rng.randint(200, 60000, size=(Z, X - 130, Y - 184))
+    e = np.zeros((Z, X, Y), np.float32)                    # nothing but zeros and one far sample per line
+    e[:, -1, :] = 3.0
+    e[:, :, -1] = 7.0
+    return dict(zero_border=a, huge_tail=b, tiny_head=c, dark_border_u16=d, far_sample=e)
+
+
+@pytest.mark.parametrize("name", ["zero_border", "huge_tail", "tiny_head", "dark_border_u16", "far_sample"])
+def test_warp_cubic_start_sums_of_long_lines(name):
+    """The causal start value of SciPy's spline prefilter sums the whole line; the kernels stop where the rest
+    provably cannot change the sum (csrc/warp.hip, IirInit).  Lines that begin with zeros or with samples 50 orders of
+    magnitude below their tail are where the sum has to read on (a fixed 64-term cut moves the float64 coefficients
+    there by 1e-12 relative at the edge of the 12-sample pad; float32 outputs round that away almost always, which
+    is not a proof): bit for bit against scipy."""
+    import np_oracle as O
+    from imageanalysis3_amd.correction_tools.translate import warp_3d_image
+    im = _start_sum_cases()[name]
+    drift = [0.3, 1.7, -2.2]
+    w = warp_3d_image(im, drift, warp_order=3, border_mode="nearest")
+    ref = O.warp_3d_image(im, drift, None, 3, "nearest")
+    assert w.dtype == ref.dtype
+    assert np.array_equal(w.view(np.uint32 if im.dtype == np.float32 else np.uint16),
+                          ref.view(np.uint32 if im.dtype == np.float32 else np.uint16))
+
+
 def test_gaussianfit_class_vs_oracle():
     """(a3) standalone GaussianFit on explicit voxel lists (Voronoi cells of the golden case)."""
     import np_oracle as O
