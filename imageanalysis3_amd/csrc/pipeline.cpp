@@ -240,6 +240,20 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
       if (r) errs[(size_t)k] = ia3_last_error();
     }
   } else {
+    // Resident stacks may still be in production on the CALLER's stream (a correction chain queued just before this
+    // call); the seeding threads have streams of their own, so each of them first waits for what the caller has queued
+    // up to here.  (Without this a caller had to ia3_sync() first; one that did not seeded half-warped images as soon
+    // as another host thread kept the device busy.)
+    hipEvent_t caller_done = nullptr;
+    bool any_resident = false;
+    for (int k = 0; k < n_jobs; ++k) any_resident = any_resident || jobs[k].dev;
+    if (any_resident) {
+      IA3_HIP(hipEventCreateWithFlags(&caller_done, hipEventDisableTiming));
+      if (hipEventRecord(caller_done, stream()) != hipSuccess) {
+        (void)hipEventDestroy(caller_done);
+        return set_error(IA3_EHIP, "event record on the caller's stream failed");
+      }
+    }
     const int G = in_flight < ia3k::fit_max_fovs() ? in_flight : ia3k::fit_max_fovs();   // images per group fit
     const int W = in_flight < 16 ? in_flight : 16;                                       // seeding threads
     const int groups = (n_jobs + G - 1) / G;
@@ -251,7 +265,9 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
     std::atomic<int> next{0};
     std::atomic<bool> fitter_taken{false};
     auto stage_a = [&]() {
-      const int init_rc = ensure_init();   // this thread's streams
+      int init_rc = ensure_init();   // this thread's streams
+      if (!init_rc && caller_done && hipStreamWaitEvent(stream(), caller_done, 0) != hipSuccess)
+        init_rc = set_error(IA3_EHIP, "wait for the caller's stream failed");
       for (;;) {
         const int k = next.fetch_add(1);
         if (k >= n_jobs) break;
@@ -305,6 +321,7 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
       }
     };
     pool_run(W + 1, [&]() { if (!fitter_taken.exchange(true)) stage_b(); else stage_a(); });
+    if (caller_done) (void)hipEventDestroy(caller_done);
   }
   for (int k = 0; k < n_jobs; ++k)
     if (jobs[k].rc) return set_error(jobs[k].rc, "FOV %d: %s", k, errs[(size_t)k].c_str());

@@ -573,11 +573,11 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   const size_t coef_bytes = (size_t)Zp * Xp * Yp * sizeof(double);
   Scratch P(coef_bytes + 256);
   if (!P.p) return IA3_ENOMEM;
+  const size_t plane = (size_t)Xp * Yp;
+  const unsigned* amax = nullptr;
   {
-    ProfScope ps("spline_prefilter");
-    const size_t plane = (size_t)Xp * Yp;
+    ProfScope ps("spline_axis0");
     // largest |sample| of the source, for the cut of the start sums along long axes (IirInit)
-    const unsigned* amax = nullptr;
     if (sizeof(T) == 4) {
       unsigned* slot = (unsigned*)((char*)P.p + coef_bytes);
       IA3_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), st));
@@ -609,11 +609,15 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
       hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(),
                          (int)plane, plane, Zp, (size_t)0, qz);
     }
-    // axis 1: lines = (z,y), stride = Yp
+  }
+  {   // axis 1: lines = (z,y), stride = Yp
+    ProfScope ps("spline_axis1");
     IirInit qx = make_init(Xp, 1, 65535.0, amax);
     hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
                        Yp, (size_t)Yp, Xp, plane, qx);
-    // axis 2: contiguous lines (z,x)
+  }
+  {   // axis 2: contiguous lines (z,x)
+    ProfScope ps("spline_axis2");
     IirInit qy = make_init(Yp, 2, 65535.0, amax);
     const size_t nl = (size_t)Zp * Xp;
     hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 4>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,

@@ -11,7 +11,13 @@
  *     the message of the last failure on the calling thread;
  *   - device state is created lazily by the first call in a process (safe after fork);
  *   - `ia3_stack` handles keep a stack resident in HBM so filter -> seed -> fit chain without
- *     host round trips.
+ *     host round trips;
+ *   - threads and streams: every host thread that calls the library gets HIP streams of its own; `_dev` entry
+ *     points queue their kernels on the calling thread's stream and may return before they have run, calls of one
+ *     thread execute in the order they were made, and anything that returns data to the host (downloads, seed and
+ *     spot tables, drifts) waits for what it needs.  A resident stack is handed to ANOTHER host thread only after
+ *     ia3_sync() on the thread that produced it; ia3_fit_fovs, which works on threads of its own, orders them after
+ *     the calling thread's stream by itself.
  */
 #ifndef IA3_H
 #define IA3_H
@@ -299,7 +305,8 @@ int ia3_fit_fov_wait_share(int64_t* wait_cycles, int64_t* wave_cycles);
 /* A batch of independent FOVs in one call: the per-image tasks the reference spreads over an mp.Pool
  * (classes/field_of_view.py:1129-1142, worker classes/batch_functions.py:60).  Each job is either a host stack
  * (uploaded here through pinned staging buffers while other jobs compute) or a resident one; `in_flight` jobs
- * (<= 0: 4, at most 16) are processed side by side on library-owned threads and streams.  Per job the outputs are those
+ * (<= 0: 4, at most 64) are seeded side by side on library-owned threads and streams (at most 16) and fitted in groups
+ * by one more.  Resident jobs may still be in production on the calling thread's stream: the batch waits for it.  Per job the outputs are those
  * of ia3_fit_fov_dev; the call returns the first failing job's code (every job's own code is in `rc`). */
 typedef struct ia3_fov_job {
   const void* host;       /* (Z,X,Y) stack of `dtype` in host memory, or NULL */

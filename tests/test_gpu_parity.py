@@ -886,6 +886,35 @@ def test_group_fit_of_several_fields_equals_one_by_one():
     assert_rows_close(one[1][0][0], o, rtol=1e-6)
 
 
+def test_fit_fovs_waits_for_stacks_still_in_production_on_the_callers_stream():
+    """A resident stack handed to ia3_fit_fovs may still be in production on the caller's stream (the correction chain
+    is asynchronous); the batch seeds on streams of its own.  Here the stack holds zeros until a copy that is queued
+    behind some 50 ms of other work on the caller's stream: seeding that does not order itself after the caller's
+    queue sees the zeros (no seeds).  No ia3_sync() anywhere before the call."""
+    import ctypes as C
+    from imageanalysis3_amd import synth, _lib as L
+    lib = L.lib()
+    shape = (30, 200, 200)
+    im, c, h = synth.make_fov(shape, 80, 31)
+    sp, keep = L.make_seed_params(600.0, max_num_seeds=None)
+    fp = L.make_fit_params()
+    ref = L.fit_fovs([im, im], sp, fp, in_flight=1)[0]
+    assert len(ref[0]) > 60
+    big = np.random.RandomState(2).uniform(100, 900, size=(40, 1024, 1024)).astype(np.float32)
+    zero = np.zeros(3)
+    with L.DeviceStack.upload(big) as a, L.DeviceStack.empty(big.shape, big.dtype) as b, \
+            L.DeviceStack.upload(im) as src, L.DeviceStack.upload(np.zeros(shape, np.float32)) as t1, \
+            L.DeviceStack.upload(np.zeros(shape, np.float32)) as t2:
+        L.check(lib.ia3_sync())
+        for _ in range(12):   # cubic warps of a 168 MB stack: a few ms each
+            L.check(lib.ia3_warp3d_dev(a._h, L.dptr(np.array([0.3, 0.4, 0.5])), None, 0, 3, L.MODE_NEAREST, C.c_double(0.0), b._h))
+        for t in (t1, t2):    # zero shift, order 1: a copy
+            L.check(lib.ia3_warp3d_dev(src._h, L.dptr(zero), None, 0, 1, L.MODE_NEAREST, C.c_double(0.0), t._h))
+        tabs, info = L.fit_fovs([t1, t2], sp, fp, in_flight=2)
+    for t in tabs:
+        assert np.array_equal(t, ref[0])
+
+
 def _set_gauss_cert(v):
     import ctypes as C
     from imageanalysis3_amd import _lib as L
