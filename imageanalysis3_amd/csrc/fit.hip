@@ -938,22 +938,33 @@ struct StageCtl {
   int abort;                // 1: a spin-wait exceeded its bound (never expected); 2: exact Voronoi ties exist and no tie masks
                             // were supplied (the host resolves them and launches again); 3: tie queue overflow
   int ties;                 // nbr_build_k: some ball voxel is equidistant from its seed and another one
-  int pad[29];
+  int stage_reached;        // the stage this launch ran up to (a launch from stage 0 decides that itself, see fit_stages_k)
+  int pad[28];
   struct Claim { unsigned int next; unsigned int pad[31]; } claim[NCLAIM + 1];
 };
 static_assert(sizeof(StageCtl) == 128 * (NCLAIM + 2), "one 128-byte line per counter");
 
 // wave-uniform poll: every lane issues the (same-address) load, lane 0's value decides for the whole wave
 __device__ __forceinline__ bool wait_done(const int* done, int j, int need, StageCtl* ctl) {
+  // An ordinary refit is over in tens of microseconds and its successor should notice at once; a wave that holds a later
+  // sweep of a seed whose fit runs for milliseconds (thousands of them in a batch of uint16 fields) must not keep two
+  // memory-side loads per 0.4 us going for all that time: the naps grow with the wait, the abort word — one address for
+  // every waiting wave of the launch — is looked at every 16th time.
   long long spins = 0;
   for (;;) {
     const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (v >= need) return true;
-    __builtin_amdgcn_s_sleep(16);
-    const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (++spins > (1LL << 24) || ab) {
-      __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
+    if (v >= need) { if (spins) __builtin_amdgcn_s_setprio(3); return true; }
+    if (spins == 0) __builtin_amdgcn_s_setprio(0);   // a waiting wave takes no issue slot from the fits beside it
+    if (spins < 256) __builtin_amdgcn_s_sleep(16);                                          // 0.4 us: the first 0.1 ms
+    else if (spins < 1024) __builtin_amdgcn_s_sleep(64);                                    // 1.7 us: up to 1.4 ms
+    else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }                  // 6.8 us
+    ++spins;
+    if ((spins & 15) == 0) {
+      const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (spins > (1LL << 22) || ab) {   // 28 s of waiting: never expected
+        __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
     }
   }
 }
@@ -1042,6 +1053,10 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
   __shared__ WaveLds wl;
   IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
   const int lane = threadIdx.x & 63;
+  // A fit is one wave working through dependent float64 chains: whenever it is ready it should issue.  Beside the
+  // streaming kernels of other host threads (seven filter or warp waves on the same SIMD, round-robin) a fit that runs
+  // to maxfev took three times as long as on an idle device, and every refit that waits for it waited with it.
+  __builtin_amdgcn_s_setprio(3);
   // exact Voronoi ties in this field and no tie masks yet: nothing is fitted; the host builds the seed tree, resolves the
   // ties (voronoi_ties_k) and launches again
   // (the legacy model's driver, Fitting_v3.py:39-46, takes cdist + argmin instead of a tree: lowest index, no masks)
@@ -1085,6 +1100,15 @@ __global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int sta
       needed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->n_unconv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     while (unit_size > 1 && needed * 2 * unit_size > (long long)n) unit_size >>= 1;
+    // A launch from stage 0 is handed every sweep and keeps them all when a few seeds overlap others and most do not
+    // (uint16 fields: the twin seeds of DoG plateaus, of which one refits noise for hundreds of evaluations in every
+    // sweep): the work list orders the refits by their dependencies alone, so such a seed goes from sweep to sweep
+    // without a launch boundary — a barrier over the whole batch — in between, and walking the positions of the
+    // converged seeds, 64 at a time, costs microseconds.  Without overlaps (everything converges with sweep 1, the
+    // walk would be pure cost) and in crowded fields (the walk goes position by position) it keeps the first two
+    // stages, and the host sends the later sweeps in pairs while seeds are left.
+    if (stage0 == 0 && stage1 > 2 && !(needed > 0 && needed * 64 <= (long long)n)) stage1 = 2;
+    if (stage0 == 0 && blockIdx.x == 0 && lane == 0) ctl->stage_reached = stage1;
   }
   const unsigned per_stage = (unsigned)((n + unit_size - 1) / unit_size);
   const unsigned units = stage1 > later0 ? per_stage * (unsigned)(stage1 - later0) : 0u;
@@ -1262,6 +1286,7 @@ int g_nb_cap = MAXNB;   // IA3_TUNE_FIT_NBLIST
 int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets its first fit and sweep 1 from one wave
 int g_fit_maxfev = 0;   // IA3_DEBUG_FIT_MAXFEV: profiling only (splits the kernel time into a fixed and a per-evaluation part)
 int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the kernel's 256 registers allow two)
+int g_fit_merge = 1;    // IA3_TUNE_FIT_MERGE: sweeps after the first pair in one launch when few seeds are left (run_sweeps)
 
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
@@ -1474,6 +1499,7 @@ void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : c
 void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
 void set_fit_maxfev(int n) { g_fit_maxfev = n; }
 void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
+void set_fit_merge(int on) { g_fit_merge = on != 0; }
 void fit_host_counters(const ia3_fitter* f, long long out[5]) {
   for (int k = 0; k < 5; ++k) out[k] = (long long)f->host_counters[k];
 }
@@ -1537,22 +1563,54 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   return IA3_OK;
 }
 
-// [counters | n_iter | stage control | overflow flag | rows] -> f->host_stage in one copy, one synchronisation
+// [counters | n_iter | stage control | overflow flag | rows] -> f->host_stage, one wait.
+// The block is written into the thread's pinned, device-mapped mailbox by a KERNEL queued behind the fit, followed by
+// a sequence word the host polls.  A hipMemcpyAsync queued behind the fit parks a barrier on a copy engine's ring
+// until the fit kernel has ended, and every other stream's device-to-host copy that lands on that ring waits with it:
+// a field with plateau twins (a 30 ms launch) held up the seed read-backs of the images seeded beside it, so three
+// images "in flight" were fitted one after the other (rocprofv3 API + kernel trace of the movie leg, profiles/r03d).
+
+__global__ __launch_bounds__(1024) void mail_copy_k(const unsigned* __restrict__ src, unsigned* __restrict__ dst, size_t n4,
+                                                    volatile unsigned* seq_word, unsigned seq) {
+  const size_t n16 = n4 / 4;
+  for (size_t i = threadIdx.x; i < n16; i += 1024) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+  for (size_t i = 4 * n16 + threadIdx.x; i < n4; i += 1024) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *seq_word = seq;
+}
 static int fetch_block(ia3_fitter* f, bool with_rows) {
   hipStream_t st = stream();
   const size_t head = (size_t)((char*)f->d_ps - (char*)f->d_counters);
   const size_t rows = with_rows ? sizeof(float) * 11 * (size_t)f->n : 0;
   f->host_stage.resize(head + rows);
-  // through the thread's pinned block when it fits (a copy into pageable memory is staged by the runtime) and a spinning
-  // wait: the table is microseconds away and the next image's first kernels wait for this thread
   void *mh = nullptr, *md = nullptr;
-  constexpr size_t MAIL_OFF = 4096;   // the first page holds the seed stage's control words
-  if (head + rows <= (1u << 20) - MAIL_OFF && host_mailbox(1u << 20, &mh, &md) == IA3_OK) {
-    IA3_HIP(hipMemcpyAsync((char*)mh + MAIL_OFF, f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
-    int rc = stream_wait_spin(st); if (rc) return rc;
+  constexpr size_t MAIL_OFF = 4096;   // the first page holds the control words: the seed stage's at 0, the fit's sequence word at 2048
+  constexpr size_t SEQ_OFF = 2048;
+  static_assert(sizeof(uint4) == 16, "");
+  if (head + rows <= (1u << 20) - MAIL_OFF && (head + rows) % 4 == 0 && ((size_t)f->d_counters & 15) == 0 &&
+      host_mailbox(1u << 20, &mh, &md) == IA3_OK) {
+    static thread_local unsigned t_seq = 0;
+    const unsigned seq = ++t_seq ? t_seq : ++t_seq;   // never 0 (the mailbox starts zeroed)
+    hipLaunchKernelGGL(mail_copy_k, dim3(1), dim3(1024), 0, st, (const unsigned*)f->d_counters, (unsigned*)((char*)md + MAIL_OFF),
+                       (head + rows) / 4, (volatile unsigned*)((char*)md + SEQ_OFF), seq);
+    IA3_KCHECK();
+    volatile unsigned* mb = (volatile unsigned*)((char*)mh + SEQ_OFF);
+    unsigned long long spins = 0;
+    while (*mb != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {   // the stream drained (or failed) without the word
+        if (*mb == seq) break;
+        IA3_HIP(hipStreamSynchronize(st));
+        if (*mb != seq) return set_error(IA3_EHIP, "fit results did not reach the host mailbox");
+        break;
+      }
+    }
     memcpy(f->host_stage.data(), (char*)mh + MAIL_OFF, head + rows);
     return IA3_OK;
   }
+  // too large for the mailbox: wait for the fit first, copy afterwards (nothing parked on a copy engine meanwhile)
+  { int rc = stream_wait_spin(st); if (rc) return rc; }
   IA3_HIP(hipMemcpyAsync(f->host_stage.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));
   IA3_HIP(hipStreamSynchronize(st));
   return IA3_OK;
@@ -1626,11 +1684,18 @@ static int check_ctl(const StageCtl& hc) {
 static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
   if (last < 0) last = f->prm.n_max_iter + 2;   // sweeps 1 .. n_max_iter+1 (Fitting_v4.py:683)
   f->cached = false;
+  bool few_left = false;   // after the first pair: a handful of seeds still move (plateau twins that refit noise, a few chains)
   while (stage < last) {
-    const int s1 = stage + 2 < last ? stage + 2 : last;
+    // ... then every remaining sweep goes out in ONE launch: the work list orders the refits by their true dependencies,
+    // so a seed's sweep k+1 follows its own sweep k instead of the slowest fit of sweep k anywhere in the batch (a launch
+    // boundary is a barrier over all fields; three uint16 fields took 83 ms in pairs of sweeps).  The positions of
+    // converged seeds are skipped 64 at a time (unit_size in fit_stages_k), which is only cheap while few seeds are left:
+    // crowded fields keep the pairs.
+    const bool kernel_decides = stage == 0 && g_fit_merge && last > 2;   // (fit_stages_k: all sweeps, or the first two stages)
+    int s1 = few_left || kernel_decides ? last : (stage + 2 < last ? stage + 2 : last);
     int rc = launch_stages(f, stage, s1, fresh); if (rc) return rc;
     const bool with_first = stage == 0 && !f->ties_resolved;   // this launch may have left at once: exact Voronoi ties
-    if (s1 >= last && !with_first) break;
+    if (s1 >= last && !with_first && !kernel_decides) break;
     const bool rows_now = f->n <= 16384;   // a batch of fields: the (large) row table is fetched once, at the end
     rc = fetch_block(f, rows_now); if (rc) return rc;
     StageCtl hc;
@@ -1642,9 +1707,11 @@ static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
     }
     rc = check_ctl(hc); if (rc) return rc;
     fresh = false;
+    if (kernel_decides) s1 = hc.stage_reached;
     stage = s1;
     if (stage >= last) { f->cached = rows_now; break; }
     if (hc.n_unconv <= 0) { f->cached = rows_now; break; }
+    few_left = g_fit_merge && (long long)hc.n_unconv * 64 <= (long long)f->n;
   }
   return IA3_OK;
 }
@@ -1712,6 +1779,9 @@ int ia3_fit_results_ex(ia3_fitter* f, float* ps, uint8_t* success, int* nvox, in
     const size_t rows = ps ? sizeof(float) * 11 * (size_t)f->n : 0;
     std::vector<char>& hb = f->host_stage;
     const bool have = f->cached && hb.size() >= head + rows;
+    // the fit may still be running: wait for it BEFORE queueing copies (see fetch_block: a copy queued behind a long
+    // kernel holds a copy engine's ring for every other stream)
+    if (!have || nvox || success) { const int rcw = stream_wait_spin(st); if (rcw) return rcw; }
     if (!have) {
       hb.resize(head + rows);
       IA3_HIP(hipMemcpyAsync(hb.data(), f->d_counters, head + rows, hipMemcpyDeviceToHost, st));

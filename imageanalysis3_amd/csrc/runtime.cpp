@@ -582,6 +582,9 @@ int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out
 }
 int ia3_stack_download(const ia3_stack* s, void* host) {
   if (!s || !host) return set_error(IA3_EINVAL, "null argument");
+  // what produces the stack first, the copy afterwards: a copy queued behind kernels waits for them on a copy engine's
+  // ring, and with it every other host thread's device-to-host copy that shares the ring
+  IA3_HIP(hipStreamSynchronize(stream()));
   IA3_HIP(hipMemcpyAsync(host, s->d, s->bytes, hipMemcpyDeviceToHost, stream()));
   IA3_HIP(hipStreamSynchronize(stream()));
   return IA3_OK;

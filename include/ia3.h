@@ -93,6 +93,11 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
 /* IA3_TUNE_FIT_WAVES: persistent wavefronts of the fit kernel per SIMD, 1 or 2 (default 2: the kernel is built for 256
  * registers).  Tables are identical bit for bit. */
 #define IA3_TUNE_FIT_WAVES 10
+/* IA3_TUNE_FIT_MERGE: 1 (default) = once the first launch (first fits + sweep 1) has left fewer than 1 seed in 64
+ * unconverged, all remaining sweeps go out in one launch, ordered by the work list's dependencies alone (a seed's
+ * sweep k+1 no longer waits for the slowest fit of sweep k anywhere in the batch); 0 = two sweeps per launch throughout.
+ * Tables are identical bit for bit. */
+#define IA3_TUNE_FIT_MERGE 11
 /* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
  * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */
 #define IA3_DEBUG_FIT_MAXFEV 100

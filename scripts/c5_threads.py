@@ -34,6 +34,8 @@ fp = L.make_fit_params()
 dref = L.DeviceStack.upload(ims[3])
 
 
+INFO = []
+THREADS = tuple(int(x) for x in os.environ.get("C5_THREADS", "1,2,3").split(","))
 ROWS = []   # rows per channel of every movie run (they must all be equal: same input)
 
 
@@ -50,6 +52,7 @@ def movie(_=None):
         for s in out:
             s.free()
     ROWS.append(tuple(len(t) for t in tabs))
+    INFO.append([(i["n_seeds"], i["n_iter"], i["fits"], i["nfev"]) for i in info])
     return t_b - t_a, time.perf_counter() - t_b, sum(len(t) for t in tabs)
 
 
@@ -57,7 +60,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     movie()
     res = []
     for rep in range(2):
-        for thr in (1, 2, 3):
+        for thr in THREADS:
             n = 2 * thr if thr > 1 else 3
             with ThreadPoolExecutor(max_workers=thr) as pool:
                 list(pool.map(movie, range(thr)))
@@ -75,4 +78,5 @@ with contextlib.redirect_stdout(io.StringIO()):
 for r in res:
     print(json.dumps(r))
 import collections
+print("(seeds, sweeps, fits, evaluations) per channel of one movie:", INFO[1])
 print("rows per channel over %d movies:" % len(ROWS), dict(collections.Counter(ROWS)))
