@@ -898,6 +898,7 @@ int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_FIT_FUSE) { ia3k::set_fit_fuse(value); return 0; }
   if (key == IA3_TUNE_FIT_WAVES) { ia3k::set_fit_waves(value); return 0; }
   if (key == IA3_TUNE_FIT_MERGE) { ia3k::set_fit_merge(value); return 0; }
+  if (key == IA3_TUNE_WARP_ONEPASS) { ia3k::set_warp_onepass(value); return 0; }
   if (key == IA3_DEBUG_FIT_MAXFEV) { ia3k::set_fit_maxfev(value); return 0; }
   return set_error(IA3_EINVAL, "unknown tuning key");
 }

@@ -96,12 +96,8 @@ __global__ __launch_bounds__(256) void absmax_f32_k(const float* __restrict__ im
   if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
-// IIR along a strided axis: line p (lane along the contiguous axis), element i at base + i*stride
-__global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__ P, int inner, size_t stride, int n,
-                                                            size_t outer_stride, IirInit q) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= inner) return;
-  double* c = P + (size_t)blockIdx.y * outer_stride + p;
+// start value of the causal recursion of a strided line (element i at c + i*stride), see IirInit
+__device__ __forceinline__ double iir_start_strided(const double* __restrict__ c, size_t stride, int n, const IirInit& q) {
   const double z = q.z, g = q.gain;
   const double c0 = c[0] * g;
   double s;
@@ -124,12 +120,19 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
   }
   s *= q.scale;
   s += c0;
-  // The recursions are serial in `prev`, their loads are not: eight samples are fetched ahead of the eight dependent
-  // updates, so a thread keeps eight loads in flight instead of one (the kernel ran at 1.6 TB/s, latency-bound).
+  return s;
+}
+
+// Two sweeps over a strided line, in place, from sample `from` (whose causal value `first` is known) to the end and
+// back: [from, n) holds raw samples on entry and coefficients on exit.
+// The recursions are serial in `prev`, their loads are not: eight samples are fetched ahead of the eight dependent
+// updates, so a thread keeps eight loads in flight instead of one (the kernel ran at 1.6 TB/s, latency-bound).
+__device__ __forceinline__ void iir_two_sweeps_strided(double* __restrict__ c, size_t stride, int from, int n, double first,
+                                                       double z, double g) {
   constexpr int B = 8;   // 16 in flight: no faster (2.36 against 2.25 ms)
-  double prev = s;
-  c[0] = prev;
-  int i = 1;
+  double prev = first;
+  c[(size_t)from * stride] = prev;
+  int i = from + 1;
   for (; i + B <= n; i += B) {
     double in[B];
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
   prev = prev * (z / (z - 1.0));
   c[(size_t)(n - 1) * stride] = prev;
   i = n - 2;
-  for (; i - (B - 1) >= 0; i -= B) {
+  for (; i - (B - 1) >= from; i -= B) {
     double in[B];
 #pragma unroll
     for (int k = 0; k < B; ++k) in[k] = c[(size_t)(i - k) * stride];
@@ -160,10 +163,89 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
       prev = v;
     }
   }
-  for (; i >= 0; --i) {
+  for (; i >= from; --i) {
     double v = z * (prev - c[(size_t)i * stride]);
     c[(size_t)i * stride] = v;
     prev = v;
+  }
+}
+
+// IIR along a strided axis: line p (lane along the contiguous axis), element i at base + i*stride
+__global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__ P, int inner, size_t stride, int n,
+                                                            size_t outer_stride, IirInit q) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= inner) return;
+  double* c = P + (size_t)blockIdx.y * outer_stride + p;
+  iir_two_sweeps_strided(c, stride, 0, n, iir_start_strided(c, stride, n, q), q.z, q.gain);
+}
+
+// The same pass with every sample read once and written once (the two sweeps above move the float64 coefficient stack
+// through HBM twice).  The anticausal recursion  v[i] = z * (v[i+1] - c[i])  of a tile [a, a+T) needs v[a+T], which the
+// two-sweep form knows only after it has been to the end of the line.  Here it is CERTIFIED from the K causal values
+// behind the tile: two chains run the same recursion down from a+T+K-1, one started at +bound, one at -bound, where
+// |v| <= bound on the whole line (IirInit: v is at most three times the largest sample of the pass).  Rounded
+// subtraction is non-decreasing in v[i+1] and the rounded product with z < 0 non-increasing, so by induction the true
+// value lies between the two chains at every index; their distance shrinks by |z| = 0.268 per sample, and once both
+// hold the same bit pattern the true value has that bit pattern too.  After K = 48 steps they agree unless the line's
+// values sit ~20 orders of magnitude below the bound (exact zeros: dark borders) or, with probability ~1e-9 per
+// tile, the chains keep straddling rounding boundaries; a thread whose chains disagree finishes ITS line with the two
+// sweeps from where it stands (the rest of that line is still raw).  The causal recursion needs no certificate: the
+// thread marches along the line.  The window of T + K causal values lives in registers.
+template <int T, int K, int OCC>
+__global__ __launch_bounds__(64, OCC) void spline_iir_strided_1p_k(double* __restrict__ P, int inner, size_t stride, int n,
+                                                                 size_t outer_stride, IirInit q, int warm) {
+  constexpr int W = T + K;
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= inner) return;
+  double* c = P + (size_t)blockIdx.y * outer_stride + p;
+  const double z = q.z, g = q.gain;
+  const double bound = iir_bound(q);
+  double w[W];                       // causal values of [a, a + W)
+  w[0] = iir_start_strided(c, stride, n, q);
+#pragma unroll
+  for (int j = 1; j < W; ++j) w[j] = c[(size_t)j * stride];          // n >= 2 W (host)
+#pragma unroll
+  for (int j = 1; j < W; ++j) w[j] = w[j] * g + z * w[j - 1];
+  int a = 0;
+  bool slow = false;
+  while (a + W < n) {
+    double pu = bound, pl = -bound;   // stand for v[a + W]
+#pragma unroll
+    for (int j = W - 1; j >= T; --j)
+      if (j - T < warm) { pu = z * (pu - w[j]); pl = z * (pl - w[j]); }
+    if (__double_as_longlong(pu) != __double_as_longlong(pl)) { slow = true; break; }
+    double v = pu;
+    double* ca = c + (size_t)a * stride;
+#pragma unroll
+    for (int j = T - 1; j >= 0; --j) { v = z * (v - w[j]); ca[(size_t)j * stride] = v; }
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = w[j + T];
+    const int e = a + W;
+    const double* ce = c + (size_t)e * stride;
+    if (e + T <= n) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) w[K + j] = ce[(size_t)j * stride];
+#pragma unroll
+      for (int j = 0; j < T; ++j) w[K + j] = w[K + j] * g + z * w[K + j - 1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < T; ++j) if (e + j < n) w[K + j] = ce[(size_t)j * stride];
+#pragma unroll
+      for (int j = 0; j < T; ++j) if (e + j < n) w[K + j] = w[K + j] * g + z * w[K + j - 1];
+    }
+    a += T;
+  }
+  if (!slow) {      // the window reaches the end of the line: K < n - a <= W samples, exact from the last one down
+    const int m = n - a;
+    double* ca = c + (size_t)a * stride;
+    double v = 0.0;
+#pragma unroll
+    for (int j = W - 1; j >= 0; --j) {
+      if (j == m - 1) { v = w[j] * (z / (z - 1.0)); ca[(size_t)j * stride] = v; }
+      else if (j < m - 1) { v = z * (v - w[j]); ca[(size_t)j * stride] = v; }
+    }
+  } else {          // [0, a) is final, [a, n) raw, w[0] the causal value of sample a
+    iir_two_sweeps_strided(c, stride, a, n, w[0], z, g);
   }
 }
 
@@ -252,17 +334,23 @@ __global__ __launch_bounds__(256, 2) void spline_pad_iir0_n_k(const T* __restric
 }
 
 // IIR along the contiguous axis: every wave owns LPW lines (lanes 0..LPW-1 run the recursions) and marches them in
-// TW-element tiles that are transposed through a wave-private LDS tile.  One wave instruction moves 64/TW row pieces of
-// TW doubles.  Measured on 74 x 2072 x 2072 (10 GB moved): 64 lines x 16 samples 3.10 ms, the same with the chain in
-// registers 2.9, 16 lines x 64 samples 2.5, 8 lines x 64 samples at four waves per SIMD 2.3 (4.3 TB/s of mixed reads
-// and writes): the pass wants many small waves with whole 512-byte pieces of a line per access, not wide tiles.
+// TW-element tiles that are transposed through wave-private LDS tiles.  One wave instruction moves 64/TW row pieces of
+// TW doubles.  Measured on 74 x 2072 x 2072 (10 GB moved by the two-sweep form): 64 lines x 16 samples 3.10 ms, the same
+// with the chain in registers 2.9, 16 lines x 64 samples 2.5, 8 lines x 64 samples at four waves per SIMD 2.3 (4.3 TB/s
+// of mixed reads and writes): the pass wants many small waves with whole 512-byte pieces of a line per access, not
+// wide tiles.
+// warm > 0 and at least three tiles per line: ONE pass (see spline_iir_strided_1p_k for the argument): a tile gets its
+// causal recursion, the two bounding chains run back through it (a whole tile: 64 samples), and when they meet in every
+// line of the wave the tile before it can have its exact anticausal recursion and be stored — each sample is read once
+// and written once.  If the chains of any line disagree the wave finishes its lines with the two sweeps from the
+// first tile that is still raw in memory.
 template <int TW, int LPW, int OCC>
-__global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q) {
+__global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q, int warm) {
   constexpr int RPI = 64 / TW;   // rows moved per wave instruction
   constexpr int NR = LPW / RPI;  // wave instructions per tile
   constexpr int SC = 16;         // samples of a line in registers at a time
-  static_assert(64 % TW == 0 && LPW % RPI == 0 && LPW <= 64, "tile shape");
-  __shared__ double tile[4][LPW][TW + 1];
+  static_assert(64 % TW == 0 && LPW % RPI == 0 && LPW <= 64 && TW % SC == 0, "tile shape");
+  __shared__ double tiles[4][3][LPW][TW + 1];
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   const size_t l0 = ((size_t)blockIdx.x * 4 + wv) * LPW;
   if (l0 >= n_lines) return;                 // whole wave
@@ -278,16 +366,55 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
       pre[j] = (l0 + r < n_lines && col < w) ? P[(l0 + r) * (size_t)n + y0 + col] * scale : 0.0;
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](int b) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) tile[wv][j * RPI + rsub][col] = pre[j];
+    for (int j = 0; j < NR; ++j) tiles[wv][b][j * RPI + rsub][col] = pre[j];
   };
-  auto store_tile = [&](int y0, int w) {
+  auto store_tile = [&](int b, int y0, int w) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int r = j * RPI + rsub;
-      if (l0 + r < n_lines && col < w) P[(l0 + r) * (size_t)n + y0 + col] = tile[wv][r][col];
+      if (l0 + r < n_lines && col < w) P[(l0 + r) * (size_t)n + y0 + col] = tiles[wv][b][r][col];
     }
+  };
+  // causal recursion over row[i0 .. w) continuing from prev; whole tiles keep SC samples in registers: one dependent
+  // chain, no LDS in it
+  auto causal_row = [&](int bf, int i0, int w, double prev) {
+    double* row = &tiles[wv][bf][lt][0];
+    if (i0 == 0 && w == TW) {
+#pragma unroll 1
+      for (int b = 0; b < TW; b += SC) {
+        double r[SC];
+#pragma unroll
+        for (int i = 0; i < SC; ++i) r[i] = row[b + i];
+#pragma unroll
+        for (int i = 0; i < SC; ++i) { const double v = r[i] + z * prev; r[i] = v; prev = v; }
+#pragma unroll
+        for (int i = 0; i < SC; ++i) row[b + i] = r[i];
+      }
+    } else {
+      for (int i = i0; i < w; ++i) { const double v = row[i] + z * prev; row[i] = v; prev = v; }
+    }
+    return prev;
+  };
+  // anticausal recursion over row[w-1 .. 0] continuing from v (the value behind the tile)
+  auto anti_row = [&](int bf, int w, double v) {
+    double* row = &tiles[wv][bf][lt][0];
+    if (w == TW) {
+#pragma unroll 1
+      for (int b = TW - SC; b >= 0; b -= SC) {
+        double r[SC];
+#pragma unroll
+        for (int i = 0; i < SC; ++i) r[i] = row[b + i];
+#pragma unroll
+        for (int i = SC - 1; i >= 0; --i) { const double u = z * (v - r[i]); r[i] = u; v = u; }
+#pragma unroll
+        for (int i = 0; i < SC; ++i) row[b + i] = r[i];
+      }
+    } else {
+      for (int i = w - 1; i >= 0; --i) { const double u = z * (v - row[i]); row[i] = u; v = u; }
+    }
+    return v;
   };
   const int ntile = (n + TW - 1) / TW;
   // start value of the causal recursion (see make_init)
@@ -311,12 +438,12 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
     for (int y0 = 0; y0 < n; y0 += TW) {
       const int w = n - y0 < TW ? n - y0 : TW;
       fetch(y0, w, g);
-      stash();
+      stash(0);
       __builtin_amdgcn_wave_barrier();
       if (open) {
         int i0 = 0;
-        if (y0 == 0) { c0 = tile[wv][lt][0]; s = c0; i0 = 1; }
-        for (int i = i0; i < w; ++i) { s += zi * tile[wv][lt][i]; zi *= z; }
+        if (y0 == 0) { c0 = tiles[wv][0][lt][0]; s = c0; i0 = 1; }
+        for (int i = i0; i < w; ++i) { s += zi * tiles[wv][0][lt][i]; zi *= z; }
         if ((y0 + TW) % 64 == 0 && iir_sum_settled(s, zi, bound)) open = false;
       }
       __builtin_amdgcn_wave_barrier();
@@ -326,65 +453,261 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
     s += c0;
     prev = s;
   }
-  fetch(0, n < TW ? n : TW, g);
-  for (int k = 0; k < ntile; ++k) {  // causal
+  int k0 = 0;                    // the two sweeps below start at this tile, with `prev` the causal value entering it
+  if (warm > 0 && ntile >= 3) {
+    // Lanes 0..LPW-1 own the lines (group 0).  The backward recursion of the certificate and the backward recursion
+    // of a tile's exact pass are the same operation on different rows, so they share one instruction stream: in the
+    // backward pass of step j, group 0 runs the chain from +bound and group 1 (lanes LPW..2 LPW-1) the chain from
+    // -bound through tile j, while group 2 runs the exact anticausal pass of tile j-2 from the value step j-1
+    // certified.  Three tiles are resident per wave; a full tile costs one forward and one backward pass of 64 steps.
+    static_assert(3 * LPW <= 64, "three lane groups");
+    const double bound = iir_bound(q);
+    const int L = ntile - 1, wlast = n - L * TW;
+    const int grp = t / LPW, ln = t % LPW;
+    const bool lane_on = grp < 3 && l0 + ln < n_lines;
+    const int wsteps = ((warm < TW ? warm : TW) + SC - 1) / SC * SC;   // warm-up in whole register chunks
+    // backward recursion over the whole tile in buffer bf, row ln; chains of groups 0 / 1 (re)start from `init` at
+    // sample wsteps - 1 (the shortened warm-ups of the tests); wr: the lane keeps its results
+    auto back_pass = [&](int bf, double v, double init, bool chain, bool wr) {
+      double* row = &tiles[wv][bf][ln][0];
+#pragma unroll 1
+      for (int b = TW - SC; b >= 0; b -= SC) {
+        if (chain && b + SC == wsteps) v = init;
+        double r[SC];
+#pragma unroll
+        for (int i = 0; i < SC; ++i) r[i] = row[b + i];
+#pragma unroll
+        for (int i = SC - 1; i >= 0; --i) { const double u = z * (v - r[i]); r[i] = u; v = u; }
+        if (wr) {
+#pragma unroll
+          for (int i = 0; i < SC; ++i) row[b + i] = r[i];
+        }
+      }
+      return v;
+    };
+    fetch(0, TW, g);
+    stash(0);
+    __builtin_amdgcn_wave_barrier();
+    fetch(TW, TW, g);
+    double cin_prev = prev, cin_cur = prev;   // causal values entering tiles j - 1 and j (tile 0: the start value itself)
+    double cprev = prev;
+    if (mine) { tiles[wv][0][lt][0] = prev; cprev = causal_row(0, 1, TW, prev); }
+    double vcert = 0.0;                       // group 2: the value behind the tile it finishes next
+    bool failed = false;
+    for (int j = 1; j < L; ++j) {             // full tiles; pre: raw tile j
+      const int bj = j % 3, bjm2 = (j + 1) % 3;
+      stash(bj);
+      __builtin_amdgcn_wave_barrier();
+      fetch((j + 1) * TW, j + 1 == L ? wlast : TW, g);
+      cin_prev = cin_cur;
+      cin_cur = cprev;
+      if (mine) cprev = causal_row(bj, 0, TW, cprev);
+      __builtin_amdgcn_wave_barrier();
+      double v = grp == 0 ? bound : (grp == 1 ? -bound : vcert);
+      const bool fin = grp == 2 && j >= 2;    // tile j - 2 gets its exact pass
+      if (lane_on && (grp < 2 || fin)) v = back_pass(grp == 2 ? bjm2 : bj, v, v, grp < 2, fin);
+      const double vl = __shfl(v, (t + LPW) & 63);          // group 0 looks at group 1's chain
+      const double vu = __shfl(v, (t + 64 - 2 * LPW) & 63); // group 2 takes group 0's
+      const bool fail = mine && __double_as_longlong(v) != __double_as_longlong(vl);
+      vcert = vu;
+      __builtin_amdgcn_wave_barrier();
+      if (j >= 2) store_tile(bjm2, (j - 2) * TW, TW);
+      __builtin_amdgcn_wave_barrier();
+      if (__any(fail)) { failed = true; k0 = j - 1; prev = cin_prev; break; }
+    }
+    if (!failed) {
+      // the last tile (wlast samples) ends the line: exact from its last sample; tiles L-1 (from the value the last tile
+      // hands down, group 0) and L-2 (from the certified value, group 2) follow in one backward pass
+      const int bL = L % 3, bLm1 = (L + 2) % 3, bLm2 = (L + 1) % 3;
+      stash(bL);
+      __builtin_amdgcn_wave_barrier();
+      double v = vcert;
+      if (mine) {
+        causal_row(bL, 0, wlast, cprev);
+        v = tiles[wv][bL][lt][wlast - 1] * (z / (z - 1.0));
+        tiles[wv][bL][lt][wlast - 1] = v;
+        v = anti_row(bL, wlast - 1, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+      store_tile(bL, L * TW, wlast);
+      const bool fin2 = grp == 2 && L >= 2;
+      if (lane_on && (grp == 0 || fin2)) back_pass(grp == 2 ? bLm2 : bLm1, v, v, false, true);
+      __builtin_amdgcn_wave_barrier();
+      store_tile(bLm1, (L - 1) * TW, TW);
+      store_tile(bLm2, (L - 2) * TW, TW);
+      return;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // two sweeps from tile k0 on: [k0 * TW, n) is raw
+  fetch(k0 * TW, n - k0 * TW < TW ? n - k0 * TW : TW, g);
+  for (int k = k0; k < ntile; ++k) {  // causal
     const int y0 = k * TW, w = n - y0 < TW ? n - y0 : TW;
-    stash();
+    stash(0);
     __builtin_amdgcn_wave_barrier();
     if (k + 1 < ntile) fetch(y0 + TW, n - y0 - TW < TW ? n - y0 - TW : TW, g);
     if (mine) {
-      if (w == TW && k > 0) {    // whole tile: the line's samples in registers, one dependent chain, no LDS in it
-#pragma unroll 1
-        for (int b = 0; b < TW; b += SC) {
-          double r[SC];
-#pragma unroll
-          for (int i = 0; i < SC; ++i) r[i] = tile[wv][lt][b + i];
-#pragma unroll
-          for (int i = 0; i < SC; ++i) { const double v = r[i] + z * prev; r[i] = v; prev = v; }
-#pragma unroll
-          for (int i = 0; i < SC; ++i) tile[wv][lt][b + i] = r[i];
-        }
-      } else {
-        int i0 = 0;
-        if (k == 0) { tile[wv][lt][0] = prev; i0 = 1; }
-        for (int i = i0; i < w; ++i) { const double v = tile[wv][lt][i] + z * prev; tile[wv][lt][i] = v; prev = v; }
-      }
+      if (k == 0) { tiles[wv][0][lt][0] = prev; prev = causal_row(0, 1, w, prev); }
+      else prev = causal_row(0, 0, w, prev);
     }
     __builtin_amdgcn_wave_barrier();
-    store_tile(y0, w);
+    store_tile(0, y0, w);
     __builtin_amdgcn_wave_barrier();
   }
   {
     const int y0 = (ntile - 1) * TW;
     fetch(y0, n - y0, 1.0);   // written just above by this wave: program order, same addresses
   }
-  for (int k = ntile - 1; k >= 0; --k) {  // anticausal
+  for (int k = ntile - 1; k >= k0; --k) {  // anticausal
     const int y0 = k * TW, w = n - y0 < TW ? n - y0 : TW;
-    stash();
+    stash(0);
     __builtin_amdgcn_wave_barrier();
-    if (k > 0) fetch(y0 - TW, TW, 1.0);
+    if (k > k0) fetch(y0 - TW, TW, 1.0);
     if (mine) {
-      if (w == TW && k < ntile - 1) {
-#pragma unroll 1
-        for (int b = TW - SC; b >= 0; b -= SC) {
-          double r[SC];
-#pragma unroll
-          for (int i = 0; i < SC; ++i) r[i] = tile[wv][lt][b + i];
-#pragma unroll
-          for (int i = SC - 1; i >= 0; --i) { const double v = z * (prev - r[i]); r[i] = v; prev = v; }
-#pragma unroll
-          for (int i = 0; i < SC; ++i) tile[wv][lt][b + i] = r[i];
-        }
-      } else {
-        int i1 = w - 1;
-        if (k == ntile - 1) { prev = tile[wv][lt][w - 1] * (z / (z - 1.0)); tile[wv][lt][w - 1] = prev; i1 = w - 2; }
-        for (int i = i1; i >= 0; --i) { const double v = z * (prev - tile[wv][lt][i]); tile[wv][lt][i] = v; prev = v; }
-      }
+      if (k == ntile - 1) {
+        prev = tiles[wv][0][lt][w - 1] * (z / (z - 1.0));
+        tiles[wv][0][lt][w - 1] = prev;
+        prev = anti_row(0, w - 1, prev);
+      } else prev = anti_row(0, w, prev);
     }
     __builtin_amdgcn_wave_barrier();
-    store_tile(y0, w);
+    store_tile(0, y0, w);
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// One-pass form of the contiguous axis with the recursions of spline_iir_strided_1p_k: every lane owns a line and keeps
+// its window of T + K causal values in registers (the tile kernel above has 8 lanes of 64 at work and as many lines in
+// flight per CU as LDS holds tiles for: 100; here 64 per wave, 768 per CU).  Only the way samples reach the lanes
+// differs: a wave instruction moves 16-byte pieces of 64 / (T/2) lines (whole 64- or 128-byte runs of a line) and an LDS
+// tile of 64 lines x T samples turns them into one line per lane and back.  A lane whose certificate fails goes on as
+// a passenger — it keeps taking part in the cooperative loads and stores, which leave its line alone from that tile on
+// — and finishes its line with the two sweeps at the end.
+template <int T, int K, int OCC>
+__global__ __launch_bounds__(64, OCC) void spline_iir_contig_1p_k(double* __restrict__ P, size_t n_lines, int n, IirInit q, int warm) {
+  constexpr int W = T + K, PITCH = T + 2, CPL = T / 2, LPI = 64 / CPL, NI = 64 / LPI, NW = W / T;
+  static_assert(T % 2 == 0 && 64 % CPL == 0 && W % T == 0 && W >= 64, "tile shape");
+  __shared__ double2 buf2[64 * PITCH / 2];
+  double* buf = (double*)buf2;
+  const int t = threadIdx.x;
+  const size_t l0 = (size_t)blockIdx.x * 64;
+  const bool have = l0 + t < n_lines;
+  const int cr = t / CPL, cc = t % CPL;
+  const double z = q.z, g = q.gain;
+  const double bound = iir_bound(q);
+  // samples [y0, y0 + T) of the wave's lines -> buf[line][0..T)
+  auto coop_load = [&](int y0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = j * LPI + cr;
+      const int y = y0 + 2 * cc;
+      double2 v = make_double2(0.0, 0.0);
+      if (l0 + r < n_lines) {
+        const double* src = P + (l0 + r) * (size_t)n + y;
+        if (y + 1 < n) v = *(const double2*)src;
+        else if (y < n) v.x = src[0];
+      }
+      buf2[(r * PITCH) / 2 + cc] = v;
+    }
+  };
+  // buf[line][0..T) -> samples [y0, y0 + T) of the lines whose bit in `skip` is clear
+  auto coop_store = [&](int y0, unsigned long long skip) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = j * LPI + cr;
+      const int y = y0 + 2 * cc;
+      if (l0 + r < n_lines && !((skip >> r) & 1ull)) {
+        const double2 v = buf2[(r * PITCH) / 2 + cc];
+        double* dst = P + (l0 + r) * (size_t)n + y;
+        if (y + 1 < n) *(double2*)dst = v;
+        else if (y < n) dst[0] = v.x;
+      }
+    }
+  };
+  double w[W];                       // causal values of [a, a + W)
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {     // n >= 2 W (host)
+    coop_load(s * T);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < T; i += 2) {
+      const double2 v = buf2[(t * PITCH + i) / 2];
+      w[s * T + i] = v.x * g; w[s * T + i + 1] = v.y * g;
+    }
+    __syncthreads();
+  }
+  {   // start value of the causal recursion (IirInit): the terms of the window from registers, more of the line only
+      // where the sum is not settled by then (lines that begin with zeros)
+    const double c0 = w[0];
+    double s = c0, zi = z;
+#pragma unroll
+    for (int i = 1; i < W; ++i) { s += zi * w[i]; zi *= z; }
+    if (have && !iir_sum_settled(s, zi, bound)) {
+      const double* line = P + (l0 + t) * (size_t)n;
+      for (int i = W; i < n;) {
+        const int e = i + 64 < n ? i + 64 : n;
+        for (; i < e; ++i) { s += zi * (line[i] * g); zi *= z; }
+        if (iir_sum_settled(s, zi, bound)) break;
+      }
+    }
+    s *= q.scale;
+    s += c0;
+    w[0] = s;
+  }
+#pragma unroll
+  for (int j = 1; j < W; ++j) w[j] = w[j] + z * w[j - 1];
+  int a = 0, a_fail = 0;
+  double cfirst = 0.0;
+  bool slow = false;
+  while (a + W < n) {                // uniform: n is
+    double pu = bound, pl = -bound;   // stand for v[a + W]
+#pragma unroll
+    for (int j = W - 1; j >= T; --j)
+      if (j - T < warm) { pu = z * (pu - w[j]); pl = z * (pl - w[j]); }
+    if (!slow && __double_as_longlong(pu) != __double_as_longlong(pl)) { slow = true; a_fail = a; cfirst = w[0]; }
+    double v = pu;
+#pragma unroll
+    for (int j = T - 1; j >= 0; --j) { v = z * (v - w[j]); w[j] = v; }
+#pragma unroll
+    for (int i = 0; i < T; i += 2) buf2[(t * PITCH + i) / 2] = make_double2(w[i], w[i + 1]);
+    __syncthreads();
+    coop_store(a, __ballot(slow || !have));
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = w[j + T];
+    coop_load(a + W);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < T; i += 2) {
+      const double2 u = buf2[(t * PITCH + i) / 2];
+      w[K + i] = u.x * g; w[K + i + 1] = u.y * g;
+    }
+    __syncthreads();
+    const int e = a + W;
+#pragma unroll
+    for (int j = 0; j < T; ++j) if (e + j < n) w[K + j] = w[K + j] + z * w[K + j - 1];
+    a += T;
+  }
+  {   // the window reaches the end of the line: K < n - a <= W samples, exact from the last one down
+    const int m = n - a;
+    double v = 0.0;
+#pragma unroll
+    for (int j = W - 1; j >= 0; --j) {
+      if (j == m - 1) { v = w[j] * (z / (z - 1.0)); w[j] = v; }
+      else if (j < m - 1) { v = z * (v - w[j]); w[j] = v; }
+    }
+    const unsigned long long skip = __ballot(slow || !have);
+#pragma unroll
+    for (int s = 0; s < NW; ++s) {
+#pragma unroll
+      for (int i = 0; i < T; i += 2) buf2[(t * PITCH + i) / 2] = make_double2(w[s * T + i], w[s * T + i + 1]);
+      __syncthreads();
+      coop_store(a + s * T, skip);
+      __syncthreads();
+    }
+  }
+  if (slow && have)   // [0, a_fail) is final, the rest of the line raw, cfirst the causal value of sample a_fail
+    iir_two_sweeps_strided(P + (l0 + t) * (size_t)n, 1, a_fail, n, cfirst, z, g);
 }
 
 __device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
@@ -543,6 +866,152 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
   out[o] = out_cvt<T>(t);
 }
 
+// order 3, four consecutive outputs of a row per thread.  warp_cubic_k reads 64 coefficients (512 bytes) per output and
+// is bound by the L1 rate those loads are served at.  Neighbouring outputs of a row share three of their four taps in
+// every one of the 16 (z, x) rows whenever their coordinates fall into consecutive cells — the normal case for a drift
+// plus a smooth field — so a thread that makes four outputs loads a run of seven coefficients per row (56 bytes, four
+// load instructions) instead of 4 x 4: 224 bytes per output.  Every output still sums ITS 64 products in SciPy's
+// order with its own weights.  An output whose cell does not line up with the first one's (a coordinate crosses an
+// integer inside the group), or a run that would leave the padded row, takes the per-tap loads of warp_cubic_k.
+template <class T>
+__global__ __launch_bounds__(256) void warp_cubic4_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
+                                                     double dy, const void* __restrict__ field, int fdt,
+                                                     T* __restrict__ out, int rows_per) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  // Block order: an output row needs 4 x 4 coefficient rows, and its neighbours along z and x need mostly the same ones.
+  // Blocks go to the eight XCDs in turn and every XCD has an L2 of its own, so XCD c takes the rows of slab c
+  // (X / 8 consecutive rows), walks them with z fastest, then x, then the piece of the row: what the blocks in flight
+  // on an XCD need (two or three rows x all planes, ~3 MB) stays in its L2, and a coefficient comes from HBM about once
+  // (the plain (y, x, z) order fetched 2.8 x the coefficient stack).
+  const unsigned b = blockIdx.x, xcd = b & 7u, bi = b >> 3;
+  const unsigned zq_u = bi % (unsigned)Z, r1 = bi / (unsigned)Z;
+  const unsigned xl = r1 % (unsigned)rows_per, h = r1 / (unsigned)rows_per;
+  const int x = (int)(xcd * (unsigned)rows_per + xl), zq = (int)zq_u;
+  const int y0 = (int)(h * 256u + threadIdx.x) * 4;
+  if (x >= X || y0 >= Y) return;       // Y % 4 == 0 (host)
+  const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
+  const size_t o = ((size_t)zq * X + x) * Y + y0, V = (size_t)Z * X * Y;
+  double f[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) f[a][v] = 0.0;
+  if (field) {
+    if ((fdt & 3) == 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float4 q = *(const float4*)((const float*)field + (size_t)a * V + o);
+        f[a][0] = (double)q.x; f[a][1] = (double)q.y; f[a][2] = (double)q.z; f[a][3] = (double)q.w;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double2 q0 = *(const double2*)((const double*)field + (size_t)a * V + o);
+        const double2 q1 = *(const double2*)((const double*)field + (size_t)a * V + o + 2);
+        f[a][0] = q0.x; f[a][1] = q0.y; f[a][2] = q1.x; f[a][3] = q1.y;
+      }
+    }
+  }
+  const int dims[3] = {Zp, Xp, Yp};
+  const double dr[3] = {dz, dx, dy};
+  double w[4][3][4];     // [output][axis][tap]
+  int st[4][3];          // first tap (before clamping)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double cc[3] = {(double)zq, (double)x, (double)(y0 + v)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (fdt & 16) { cc[a] = cc[a] - dr[a]; if (field) cc[a] = cc[a] + f[a][v]; }   // (grid - drift) + field
+      else { if (field) cc[a] = cc[a] + f[a][v]; cc[a] = cc[a] - dr[a]; }            // (grid + field) - drift
+      const double c = cc[a] + (double)NPAD;
+      const double fl = floor(c);
+      const double yv = c - fl, zv = 1.0 - yv;
+      w[v][a][1] = div6(yv * yv * (yv - 2.0) * 3.0 + 4.0);
+      w[v][a][2] = div6(zv * zv * (zv - 2.0) * 3.0 + 4.0);
+      w[v][a][0] = div6(zv * zv * zv);
+      w[v][a][3] = 1.0 - w[v][a][0] - w[v][a][1] - w[v][a][2];
+      const double f2 = fl < -8.0 ? -8.0 : (fl > (double)dims[a] + 8.0 ? (double)dims[a] + 8.0 : fl);
+      st[v][a] = (int)f2 - 1;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, (int)((size_t)Zp * Xp * Yp * sizeof(double)), 0x00020000);
+  const unsigned rowb = (unsigned)Yp * 8u, planeb = (unsigned)Xp * rowb;
+  double t[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool run_ok = st[0][2] >= 0 && st[0][2] + 6 <= Yp - 1;
+  if (run_ok) {
+    unsigned zo[4], xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      zo[i] = (unsigned)clampi(st[0][0] + i, Zp) * planeb + (unsigned)st[0][2] * 8u;
+      xo[i] = (unsigned)clampi(st[0][1] + i, Xp) * rowb;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned off = zo[i] + xo[j];
+        const v4u q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        const v4u q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
+        const v4u q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+        const v2u q3 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 48u, 0, 0);
+        const double r[7] = {__hiloint2double((int)q0.y, (int)q0.x), __hiloint2double((int)q0.w, (int)q0.z),
+                             __hiloint2double((int)q1.y, (int)q1.x), __hiloint2double((int)q1.w, (int)q1.z),
+                             __hiloint2double((int)q2.y, (int)q2.x), __hiloint2double((int)q2.w, (int)q2.z),
+                             __hiloint2double((int)q3.y, (int)q3.x)};
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double c = r[v + k];
+            c = c * w[v][0][i]; c = c * w[v][1][j]; c = c * w[v][2][k];
+            t[v] = t[v] + c;
+          }
+      }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const bool lined_up = run_ok && st[v][0] == st[0][0] && st[v][1] == st[0][1] && st[v][2] == st[0][2] + v;
+    if (!lined_up) {
+      unsigned yoff[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yoff[k] = (unsigned)clampi(st[v][2] + k, Yp) * 8u;
+      double tv = 0.0;
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const unsigned zoff = (unsigned)clampi(st[v][0] + i, Zp) * planeb;
+        const double wz = i == 0 ? w[v][0][0] : (i == 1 ? w[v][0][1] : (i == 2 ? w[v][0][2] : w[v][0][3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned roff = zoff + (unsigned)clampi(st[v][1] + j, Xp) * rowb;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const v2u q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, roff + yoff[k], 0, 0);
+            double c = __hiloint2double((int)q.y, (int)q.x);
+            c = c * wz; c = c * w[v][1][j]; c = c * w[v][2][k];
+            tv = tv + c;
+          }
+        }
+      }
+      t[v] = tv;
+    }
+  }
+  if (sizeof(T) == 2) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    us4 r;
+    r.x = (unsigned short)out_cvt<T>(t[0]); r.y = (unsigned short)out_cvt<T>(t[1]);
+    r.z = (unsigned short)out_cvt<T>(t[2]); r.w = (unsigned short)out_cvt<T>(t[3]);
+    *(us4*)(out + o) = r;
+  } else {
+    float4 r;
+    r.x = (float)out_cvt<T>(t[0]); r.y = (float)out_cvt<T>(t[1]); r.z = (float)out_cvt<T>(t[2]); r.w = (float)out_cvt<T>(t[3]);
+    *(float4*)(out + o) = r;
+  }
+}
+
+int g_warp_warm = 64;   // IA3_TUNE_WARP_ONEPASS
+
 // pass: 0, 1, 2 = how many passes of the prefilter the samples have been through; amax_bits: see IirInit
 IirInit make_init(int n, int pass, double src_max, const unsigned* amax_bits) {
   IirInit q;
@@ -613,26 +1082,72 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   {   // axis 1: lines = (z,y), stride = Yp
     ProfScope ps("spline_axis1");
     IirInit qx = make_init(Xp, 1, 65535.0, amax);
-    hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
-                       Yp, (size_t)Yp, Xp, plane, qx);
+    constexpr int T1 = 32, K1 = 64;
+    static const int t1v = getenv("IA3_WARP_T1") ? atoi(getenv("IA3_WARP_T1")) : 16;   // EXPERIMENT
+    if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 16)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 64, 2>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 48)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 48, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 48 ? g_warp_warm : 48);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 8)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<8, 64, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 856)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<8, 56, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 56 ? g_warp_warm : 56);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 1656)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 56, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 56 ? g_warp_warm : 56);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 1252)
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<12, 52, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 52 ? g_warp_warm : 52);
+    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1))
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<T1, K1, 2>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
+    else
+      hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
+                         Yp, (size_t)Yp, Xp, plane, qx);
   }
   {   // axis 2: contiguous lines (z,x)
     ProfScope ps("spline_axis2");
     IirInit qy = make_init(Yp, 2, 65535.0, amax);
     const size_t nl = (size_t)Zp * Xp;
-    hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 4>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,
-                       Yp, qy);
+    static const int lpw = getenv("IA3_WARP_LPW") ? atoi(getenv("IA3_WARP_LPW")) : 8;   // EXPERIMENT
+    const unsigned nb64 = (unsigned)((nl + 63) / 64);
+    const bool onep = g_warp_warm > 0 && !qy.full && Yp >= 2 * 96;
+    if (lpw == 864 && onep)
+      hipLaunchKernelGGL((spline_iir_contig_1p_k<8, 64, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 64 ? g_warp_warm : 64);
+    else if (lpw == 856 && onep)
+      hipLaunchKernelGGL((spline_iir_contig_1p_k<8, 56, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 56 ? g_warp_warm : 56);
+    else if (lpw == 1664 && onep)
+      hipLaunchKernelGGL((spline_iir_contig_1p_k<16, 64, 2>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 64 ? g_warp_warm : 64);
+    else if (lpw == 1648 && onep)
+      hipLaunchKernelGGL((spline_iir_contig_1p_k<16, 48, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 48 ? g_warp_warm : 48);
+    else
+    hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 3>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,
+                       Yp, qy, g_warp_warm);
   }
   {
     ProfScope ps("warp_cubic");
-    hipLaunchKernelGGL((warp_cubic_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
-                       drift[2], field, fdt, (T*)out->d);
+    const bool aligned = Y % 4 == 0 && ((uintptr_t)out->d & 15) == 0 && ((uintptr_t)field & 15) == 0;
+    if (aligned && coef_bytes < 0xffffffffull && g_warp_warm >= 0)
+    {
+      const int rows_per = (X + 7) / 8, nh = (Y / 4 + 255) / 256;
+      hipLaunchKernelGGL((warp_cubic4_k<T>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
+                         (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per);
+    }
+    else
+      hipLaunchKernelGGL((warp_cubic_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
+                         drift[2], field, fdt, (T*)out->d);
   }
   IA3_KCHECK();
   return IA3_OK;
 }
 
 }  // namespace
+
+namespace ia3k { void set_warp_onepass(int v) { g_warp_warm = v; } }
 
 extern "C" {
 

@@ -98,6 +98,13 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * sweep k+1 no longer waits for the slowest fit of sweep k anywhere in the batch); 0 = two sweeps per launch throughout.
  * Tables are identical bit for bit. */
 #define IA3_TUNE_FIT_MERGE 11
+/* IA3_TUNE_WARP_ONEPASS: the cubic warp's spline prefilter along the two long axes.  64 (default) = every sample read
+ * once and written once: the anticausal recursion of a tile starts from a value certified by two bounding chains over
+ * the samples behind it (warp.hip), with the two-sweep recursion over the rest of the line where the chains do not
+ * meet; 1..63 = the same with that many warm-up samples (tests: short warm-ups fail often and drive lines through the
+ * fallback); 0 = two sweeps over whole lines; -1 = two sweeps and the one-output-per-thread gather.  Results are
+ * identical bit for bit. */
+#define IA3_TUNE_WARP_ONEPASS 12
 /* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
  * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */
 #define IA3_DEBUG_FIT_MAXFEV 100

@@ -14,3 +14,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT" -o warp_fetch -- python
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT" -o warp_write -- python3 "$REPO/scripts/time_warp.py" > /dev/null 2> "$OUT/warp_write.err"
 echo "write done"
+if [ "$2" = "sq" ]; then
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT" -o warp_sqa -- python3 "$REPO/scripts/time_warp.py" > /dev/null 2> "$OUT/warp_sqa.err"
+  echo "sq a done"
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT" -o warp_sqb -- python3 "$REPO/scripts/time_warp.py" > /dev/null 2> "$OUT/warp_sqb.err"
+  echo "sq b done"
+fi

@@ -17,6 +17,9 @@ smooth = np.stack([0.3 * np.sin(xx / 300.0) * np.cos(yy / 400.0), 0.8 * (xx / X 
 field = np.ascontiguousarray(smooth[:, None].astype(np.float32) * np.ones((1, Z, 1, 1), np.float32))
 drift = np.array([-0.6, 3.4, -5.17])
 lib = L.lib()
+for a_ in sys.argv[1:]:
+    if a_.startswith("knob="):
+        L.check(lib.ia3_set_tuning(12, int(a_[5:])))   # IA3_TUNE_WARP_ONEPASS
 fp = C.c_void_p()
 L.check(lib.ia3_buffer_upload(L.ptr(field), C.c_size_t(field.nbytes), C.byref(fp)))
 with L.DeviceStack.upload(im) as src, L.DeviceStack.empty(im.shape, im.dtype) as dst:

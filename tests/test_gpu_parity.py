@@ -480,6 +480,40 @@ def test_warp_cubic_start_sums_of_long_lines(name):
                           ref.view(np.uint32 if im.dtype == np.float32 else np.uint16))
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
+    """The spline prefilter along the long axes reads and writes every sample once: the anticausal recursion of a tile
+    starts from a value certified by two bounding chains (csrc/warp.hip, spline_iir_strided_1p_k), lines whose chains do
+    not meet fall back to two sweeps; the gather makes four outputs per thread from shared coefficient runs and sends
+    outputs whose cells do not line up through per-tap loads.  IA3_TUNE_WARP_ONEPASS: default, warm-ups of 1, 3 and 9 samples
+    (almost every / many / some tiles fail their certificate, at different places in a line), two sweeps, and two
+    sweeps with the one-output gather — all bit for bit equal to scipy, with a field whose components cross
+    integers inside rows, a drift beyond the padding on one axis (runs leave the padded row), and stretches of zeros."""
+    import np_oracle as O
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.correction_tools.translate import warp_3d_image
+    rng = np.random.RandomState(5)
+    Z, X, Y = 4, 300, 420
+    im = rng.randint(90, 5000, size=(Z, X, Y)).astype(dtype)
+    im[:, 40:44, :] = 0                    # short runs of zeros: the chains meet later there
+    im[:, :, 200:260] = 0                  # a stretch longer than any warm-up
+    im[1, 100:140, 300:380] = 60000
+    zz, xx, yy = np.meshgrid(np.arange(Z), np.arange(X), np.arange(Y), indexing="ij")
+    field = np.stack([0.4 * np.sin(yy / 17.0), 1.3 * np.cos(yy / 23.0) + 0.01 * xx, 0.9 * np.sin(yy / 9.0) + 0.004 * xx]).astype(np.float32)
+    view = np.uint32 if dtype == np.float32 else np.uint16
+    for drift, fld in (([0.3, 1.7, -2.2], field), ([0.3, 1.7, -2.2], None), ([-0.4, 2.5, 14.6], field),
+                       ([0.2, -15.3, 0.7], field.astype(np.float64))):
+        ref = O.warp_3d_image(im, drift, fld, 3, "nearest")
+        try:
+            for knob in (64, 1, 3, 9, 0, -1):
+                L.check(L.lib().ia3_set_tuning(12, knob))      # IA3_TUNE_WARP_ONEPASS
+                w = warp_3d_image(im, drift, fld, 3, "nearest")
+                assert w.dtype == ref.dtype
+                assert np.array_equal(w.view(view), ref.view(view)), (drift, fld is not None, knob)
+        finally:
+            L.check(L.lib().ia3_set_tuning(12, 64))
+
+
 def test_gaussianfit_class_vs_oracle():
     """(a3) standalone GaussianFit on explicit voxel lists (Voronoi cells of the golden case)."""
     import np_oracle as O
