@@ -186,14 +186,17 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
 // |v| <= bound on the whole line (IirInit: v is at most three times the largest sample of the pass).  Rounded
 // subtraction is non-decreasing in v[i+1] and the rounded product with z < 0 non-increasing, so by induction the true
 // value lies between the two chains at every index; their distance shrinks by |z| = 0.268 per sample, and once both
-// hold the same bit pattern the true value has that bit pattern too.  After K = 48 steps they agree unless the line's
-// values sit ~20 orders of magnitude below the bound (exact zeros: dark borders) or, with probability ~1e-9 per
-// tile, the chains keep straddling rounding boundaries; a thread whose chains disagree finishes ITS line with the two
+// hold the same bit pattern the true value has that bit pattern too.  The distance falls below an ulp of a value v
+// after log(bound / ulp(v)) / log(1 / 0.268) steps — 33 for bound / |v| = 1000, five more per decade — and then the
+// chains coincide or sit on neighbouring doubles and merge with probability ~0.73 per further step.  With K = 52 they
+// agree unless |v| is six orders of magnitude below the bound (exact zeros: dark borders) or, with probability
+// ~1e-7 per tile, keep straddling rounding boundaries; K = 32 fails on most lines of a noise image, K = 48 is at the edge
+// for a dim uint16 background under the 65535 bound.  A thread whose chains disagree finishes ITS line with the two
 // sweeps from where it stands (the rest of that line is still raw).  The causal recursion needs no certificate: the
 // thread marches along the line.  The window of T + K causal values lives in registers.
 template <int T, int K, int OCC>
 __global__ __launch_bounds__(64, OCC) void spline_iir_strided_1p_k(double* __restrict__ P, int inner, size_t stride, int n,
-                                                                 size_t outer_stride, IirInit q, int warm) {
+                                                                   size_t outer_stride, IirInit q, int warm) {
   constexpr int W = T + K;
   const int p = blockIdx.x * 64 + threadIdx.x;
   if (p >= inner) return;
@@ -222,6 +225,8 @@ __global__ __launch_bounds__(64, OCC) void spline_iir_strided_1p_k(double* __res
     for (int j = 0; j < K; ++j) w[j] = w[j + T];
     const int e = a + W;
     const double* ce = c + (size_t)e * stride;
+    // (fetching these a step ahead into registers of their own was measured: 1.37 - 1.40 ms at T = 8 / 10 against 1.34 for
+    // this form at T = 12, which then spills; three waves per SIMD already keep loads in flight while one computes)
     if (e + T <= n) {
 #pragma unroll
       for (int j = 0; j < T; ++j) w[K + j] = ce[(size_t)j * stride];
@@ -358,17 +363,30 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
   const int lt = t < LPW ? t : 0;            // row of the tile this lane's recursion runs on
   const int col = t % TW, rsub = t / TW;
   const double z = q.z, g = q.gain;
-  double pre[NR];                // next tile on its way from HBM while the current one is processed
-  auto fetch = [&](int y0, int w, double scale) {
+  // Tiles on their way from HBM while the current one is processed.  Raw values: the gain is applied when a tile is
+  // put into LDS (a multiplication at the load would make the wave wait for the load it has just issued).  The pass is
+  // bound by the bytes it keeps in flight: at ~5 us of loaded memory latency, one 4 KB tile per wave and 12 waves per
+  // CU are 2.5 TB/s; DEPTH tiles ahead lift that above what HBM delivers.
+  constexpr int DEPTH = 3;
+  double pre[DEPTH][NR];
+  double pre_scale = 1.0;
+  auto fetch_to = [&](int d, int y0, int w) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int r = j * RPI + rsub;
-      pre[j] = (l0 + r < n_lines && col < w) ? P[(l0 + r) * (size_t)n + y0 + col] * scale : 0.0;
+      pre[d][j] = (l0 + r < n_lines && col < w) ? P[(l0 + r) * (size_t)n + y0 + col] : 0.0;
     }
   };
+  auto fetch = [&](int y0, int w, double scale) { fetch_to(0, y0, w); pre_scale = scale; };
   auto stash = [&](int b) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) tiles[wv][b][j * RPI + rsub][col] = pre[j];
+    for (int j = 0; j < NR; ++j) tiles[wv][b][j * RPI + rsub][col] = pre[0][j] * pre_scale;
+  };
+  auto shift_pre = [&]() {
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) pre[d][j] = pre[d + 1][j];
   };
   auto store_tile = [&](int b, int y0, int w) {
 #pragma unroll
@@ -488,7 +506,9 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
     fetch(0, TW, g);
     stash(0);
     __builtin_amdgcn_wave_barrier();
-    fetch(TW, TW, g);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)       // tiles 1 .. DEPTH
+      if (1 + d <= L) fetch_to(d, (1 + d) * TW, 1 + d == L ? wlast : TW);
     double cin_prev = prev, cin_cur = prev;   // causal values entering tiles j - 1 and j (tile 0: the start value itself)
     double cprev = prev;
     if (mine) { tiles[wv][0][lt][0] = prev; cprev = causal_row(0, 1, TW, prev); }
@@ -498,7 +518,8 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
       const int bj = j % 3, bjm2 = (j + 1) % 3;
       stash(bj);
       __builtin_amdgcn_wave_barrier();
-      fetch((j + 1) * TW, j + 1 == L ? wlast : TW, g);
+      shift_pre();
+      if (j + DEPTH <= L) fetch_to(DEPTH - 1, (j + DEPTH) * TW, j + DEPTH == L ? wlast : TW);
       cin_prev = cin_cur;
       cin_cur = cprev;
       if (mine) cprev = causal_row(bj, 0, TW, cprev);
@@ -574,140 +595,6 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
     store_tile(0, y0, w);
     __builtin_amdgcn_wave_barrier();
   }
-}
-
-// One-pass form of the contiguous axis with the recursions of spline_iir_strided_1p_k: every lane owns a line and keeps
-// its window of T + K causal values in registers (the tile kernel above has 8 lanes of 64 at work and as many lines in
-// flight per CU as LDS holds tiles for: 100; here 64 per wave, 768 per CU).  Only the way samples reach the lanes
-// differs: a wave instruction moves 16-byte pieces of 64 / (T/2) lines (whole 64- or 128-byte runs of a line) and an LDS
-// tile of 64 lines x T samples turns them into one line per lane and back.  A lane whose certificate fails goes on as
-// a passenger — it keeps taking part in the cooperative loads and stores, which leave its line alone from that tile on
-// — and finishes its line with the two sweeps at the end.
-template <int T, int K, int OCC>
-__global__ __launch_bounds__(64, OCC) void spline_iir_contig_1p_k(double* __restrict__ P, size_t n_lines, int n, IirInit q, int warm) {
-  constexpr int W = T + K, PITCH = T + 2, CPL = T / 2, LPI = 64 / CPL, NI = 64 / LPI, NW = W / T;
-  static_assert(T % 2 == 0 && 64 % CPL == 0 && W % T == 0 && W >= 64, "tile shape");
-  __shared__ double2 buf2[64 * PITCH / 2];
-  double* buf = (double*)buf2;
-  const int t = threadIdx.x;
-  const size_t l0 = (size_t)blockIdx.x * 64;
-  const bool have = l0 + t < n_lines;
-  const int cr = t / CPL, cc = t % CPL;
-  const double z = q.z, g = q.gain;
-  const double bound = iir_bound(q);
-  // samples [y0, y0 + T) of the wave's lines -> buf[line][0..T)
-  auto coop_load = [&](int y0) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int r = j * LPI + cr;
-      const int y = y0 + 2 * cc;
-      double2 v = make_double2(0.0, 0.0);
-      if (l0 + r < n_lines) {
-        const double* src = P + (l0 + r) * (size_t)n + y;
-        if (y + 1 < n) v = *(const double2*)src;
-        else if (y < n) v.x = src[0];
-      }
-      buf2[(r * PITCH) / 2 + cc] = v;
-    }
-  };
-  // buf[line][0..T) -> samples [y0, y0 + T) of the lines whose bit in `skip` is clear
-  auto coop_store = [&](int y0, unsigned long long skip) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int r = j * LPI + cr;
-      const int y = y0 + 2 * cc;
-      if (l0 + r < n_lines && !((skip >> r) & 1ull)) {
-        const double2 v = buf2[(r * PITCH) / 2 + cc];
-        double* dst = P + (l0 + r) * (size_t)n + y;
-        if (y + 1 < n) *(double2*)dst = v;
-        else if (y < n) dst[0] = v.x;
-      }
-    }
-  };
-  double w[W];                       // causal values of [a, a + W)
-#pragma unroll
-  for (int s = 0; s < NW; ++s) {     // n >= 2 W (host)
-    coop_load(s * T);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < T; i += 2) {
-      const double2 v = buf2[(t * PITCH + i) / 2];
-      w[s * T + i] = v.x * g; w[s * T + i + 1] = v.y * g;
-    }
-    __syncthreads();
-  }
-  {   // start value of the causal recursion (IirInit): the terms of the window from registers, more of the line only
-      // where the sum is not settled by then (lines that begin with zeros)
-    const double c0 = w[0];
-    double s = c0, zi = z;
-#pragma unroll
-    for (int i = 1; i < W; ++i) { s += zi * w[i]; zi *= z; }
-    if (have && !iir_sum_settled(s, zi, bound)) {
-      const double* line = P + (l0 + t) * (size_t)n;
-      for (int i = W; i < n;) {
-        const int e = i + 64 < n ? i + 64 : n;
-        for (; i < e; ++i) { s += zi * (line[i] * g); zi *= z; }
-        if (iir_sum_settled(s, zi, bound)) break;
-      }
-    }
-    s *= q.scale;
-    s += c0;
-    w[0] = s;
-  }
-#pragma unroll
-  for (int j = 1; j < W; ++j) w[j] = w[j] + z * w[j - 1];
-  int a = 0, a_fail = 0;
-  double cfirst = 0.0;
-  bool slow = false;
-  while (a + W < n) {                // uniform: n is
-    double pu = bound, pl = -bound;   // stand for v[a + W]
-#pragma unroll
-    for (int j = W - 1; j >= T; --j)
-      if (j - T < warm) { pu = z * (pu - w[j]); pl = z * (pl - w[j]); }
-    if (!slow && __double_as_longlong(pu) != __double_as_longlong(pl)) { slow = true; a_fail = a; cfirst = w[0]; }
-    double v = pu;
-#pragma unroll
-    for (int j = T - 1; j >= 0; --j) { v = z * (v - w[j]); w[j] = v; }
-#pragma unroll
-    for (int i = 0; i < T; i += 2) buf2[(t * PITCH + i) / 2] = make_double2(w[i], w[i + 1]);
-    __syncthreads();
-    coop_store(a, __ballot(slow || !have));
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; ++j) w[j] = w[j + T];
-    coop_load(a + W);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < T; i += 2) {
-      const double2 u = buf2[(t * PITCH + i) / 2];
-      w[K + i] = u.x * g; w[K + i + 1] = u.y * g;
-    }
-    __syncthreads();
-    const int e = a + W;
-#pragma unroll
-    for (int j = 0; j < T; ++j) if (e + j < n) w[K + j] = w[K + j] + z * w[K + j - 1];
-    a += T;
-  }
-  {   // the window reaches the end of the line: K < n - a <= W samples, exact from the last one down
-    const int m = n - a;
-    double v = 0.0;
-#pragma unroll
-    for (int j = W - 1; j >= 0; --j) {
-      if (j == m - 1) { v = w[j] * (z / (z - 1.0)); w[j] = v; }
-      else if (j < m - 1) { v = z * (v - w[j]); w[j] = v; }
-    }
-    const unsigned long long skip = __ballot(slow || !have);
-#pragma unroll
-    for (int s = 0; s < NW; ++s) {
-#pragma unroll
-      for (int i = 0; i < T; i += 2) buf2[(t * PITCH + i) / 2] = make_double2(w[s * T + i], w[s * T + i + 1]);
-      __syncthreads();
-      coop_store(a + s * T, skip);
-      __syncthreads();
-    }
-  }
-  if (slow && have)   // [0, a_fail) is final, the rest of the line raw, cfirst the causal value of sample a_fail
-    iir_two_sweeps_strided(P + (l0 + t) * (size_t)n, 1, a_fail, n, cfirst, z, g);
 }
 
 __device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
@@ -1082,28 +969,12 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   {   // axis 1: lines = (z,y), stride = Yp
     ProfScope ps("spline_axis1");
     IirInit qx = make_init(Xp, 1, 65535.0, amax);
-    constexpr int T1 = 32, K1 = 64;
-    static const int t1v = getenv("IA3_WARP_T1") ? atoi(getenv("IA3_WARP_T1")) : 16;   // EXPERIMENT
-    if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 16)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 64, 2>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 48)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 48, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 48 ? g_warp_warm : 48);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 8)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<8, 64, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 856)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<8, 56, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 56 ? g_warp_warm : 56);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 1656)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<16, 56, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 56 ? g_warp_warm : 56);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1) && t1v == 1252)
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<12, 52, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < 52 ? g_warp_warm : 52);
-    else if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1))
-      hipLaunchKernelGGL((spline_iir_strided_1p_k<T1, K1, 2>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
+    // T = 12 samples per step, K = 52 of warm-up: 64 doubles of window, three waves per SIMD without spills (measured on
+    // 74 x 2072 x 2072: <16,48> 1.22 ms but its chains meet too late for dim uint16 backgrounds, <12,52> 1.34, <8,56> 1.35,
+    // <16,64> at two waves per SIMD 1.43, <8,64> 1.70 and <32,64> 1.70 with spills; two sweeps 2.28)
+    constexpr int T1 = 12, K1 = 52;
+    if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1))
+      hipLaunchKernelGGL((spline_iir_strided_1p_k<T1, K1, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
                          P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
     else
       hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
@@ -1113,18 +984,6 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     ProfScope ps("spline_axis2");
     IirInit qy = make_init(Yp, 2, 65535.0, amax);
     const size_t nl = (size_t)Zp * Xp;
-    static const int lpw = getenv("IA3_WARP_LPW") ? atoi(getenv("IA3_WARP_LPW")) : 8;   // EXPERIMENT
-    const unsigned nb64 = (unsigned)((nl + 63) / 64);
-    const bool onep = g_warp_warm > 0 && !qy.full && Yp >= 2 * 96;
-    if (lpw == 864 && onep)
-      hipLaunchKernelGGL((spline_iir_contig_1p_k<8, 64, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 64 ? g_warp_warm : 64);
-    else if (lpw == 856 && onep)
-      hipLaunchKernelGGL((spline_iir_contig_1p_k<8, 56, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 56 ? g_warp_warm : 56);
-    else if (lpw == 1664 && onep)
-      hipLaunchKernelGGL((spline_iir_contig_1p_k<16, 64, 2>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 64 ? g_warp_warm : 64);
-    else if (lpw == 1648 && onep)
-      hipLaunchKernelGGL((spline_iir_contig_1p_k<16, 48, 3>), dim3(nb64), dim3(64), 0, st, P.as<double>(), nl, Yp, qy, g_warp_warm < 48 ? g_warp_warm : 48);
-    else
     hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 3>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,
                        Yp, qy, g_warp_warm);
   }

@@ -486,7 +486,7 @@ def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
     starts from a value certified by two bounding chains (csrc/warp.hip, spline_iir_strided_1p_k), lines whose chains do
     not meet fall back to two sweeps; the gather makes four outputs per thread from shared coefficient runs and sends
     outputs whose cells do not line up through per-tap loads.  IA3_TUNE_WARP_ONEPASS: default, warm-ups of 1, 3 and 9 samples
-    (almost every / many / some tiles fail their certificate, at different places in a line), two sweeps, and two
+    (almost every / many / some tiles fail their certificate, at different places in a line) and of 32 (a mixture), two sweeps, and two
     sweeps with the one-output gather — all bit for bit equal to scipy, with a field whose components cross
     integers inside rows, a drift beyond the padding on one axis (runs leave the padded row), and stretches of zeros."""
     import np_oracle as O
@@ -505,7 +505,7 @@ def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
                        ([0.2, -15.3, 0.7], field.astype(np.float64))):
         ref = O.warp_3d_image(im, drift, fld, 3, "nearest")
         try:
-            for knob in (64, 1, 3, 9, 0, -1):
+            for knob in (64, 1, 3, 9, 32, 0, -1):
                 L.check(L.lib().ia3_set_tuning(12, knob))      # IA3_TUNE_WARP_ONEPASS
                 w = warp_3d_image(im, drift, fld, 3, "nearest")
                 assert w.dtype == ref.dtype
