@@ -760,8 +760,8 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
 // load instructions) instead of 4 x 4: 224 bytes per output.  Every output still sums ITS 64 products in SciPy's
 // order with its own weights.  An output whose cell does not line up with the first one's (a coordinate crosses an
 // integer inside the group), or a run that would leave the padded row, takes the per-tap loads of warp_cubic_k.
-template <class T>
-__global__ __launch_bounds__(256) void warp_cubic4_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
+template <class T, int OCC>
+__global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
                                                      double dy, const void* __restrict__ field, int fdt,
                                                      T* __restrict__ out, int rows_per) {
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -993,7 +993,8 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     if (aligned && coef_bytes < 0xffffffffull && g_warp_warm >= 0)
     {
       const int rows_per = (X + 7) / 8, nh = (Y / 4 + 255) / 256;
-      hipLaunchKernelGGL((warp_cubic4_k<T>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
+      // (forced to 128 registers for a fourth wave per SIMD the kernel spills 25 and takes 5.7 ms instead of 4.0)
+      hipLaunchKernelGGL((warp_cubic4_k<T, 3>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
                          (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per);
     }
     else
