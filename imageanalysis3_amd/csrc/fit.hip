@@ -1224,6 +1224,9 @@ struct InitArgs {
   int* niter; StageCtl* ctl; int* ovf;
   double* seeds; const double* src;     // optional device-to-device copy of 3 n doubles
   int n;
+  // one field of view: its three small tables are written here instead of uploaded (a copy from pageable memory in
+  // front of the first fit launch costs the host ~20 us while the device idles)
+  const void** ims; int* fov_start; int* fov_of; const void* im0;
 };
 __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
   const int n = a.n;
@@ -1235,6 +1238,12 @@ __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
   if (t >= 128 && t < 192) a.niter[t - 128] = 0;   // one sweep counter per field (<= 64 fields per fitter)
   for (size_t k = t; k < sizeof(StageCtl) / 4; k += step) ((int*)a.ctl)[k] = k == 0 ? n : 0;   // n_unconv = n, all else 0
   if (t == 35) *a.ovf = 0;
+  if (a.ims) {
+    if (t == 36) a.ims[0] = a.im0;
+    if (t == 37) a.fov_start[0] = 0;
+    if (t == 38) a.fov_start[1] = n;
+    for (size_t i = t; i < (size_t)n; i += step) a.fov_of[i] = 0;
+  }
 }
 
 }  // namespace
@@ -1354,6 +1363,7 @@ struct FovSeeds { const ia3_stack* im; const double* host_zxy; const double* dev
 
 static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params* p, ia3_fitter** out) {
   int rc = ensure_init(); if (rc) return rc;
+  dbg_stamp("fit_create enter");
   if (!fovs || n_fov < 1 || n_fov > MAX_FOV || !p || !out) return set_error(IA3_EINVAL, "bad argument");
   if (p->radius_fit < 1) return set_error(IA3_EINVAL, "radius_fit must be >= 1");
   long long ntot = 0;
@@ -1422,7 +1432,7 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
   hipStream_t st = stream();
   hipError_t e = hipSuccess;
   // the three small tables: stack pointers, seed ranges, field of every seed
-  {
+  if (n_fov > 1) {
     std::vector<char>& m = f->meta_stage;
     m.assign(b_ims + b_fstart + b_fof, 0);
     for (int k = 0; k < n_fov; ++k) { const void* d = fovs[k].im->d; memcpy(m.data() + sizeof(void*) * (size_t)k, &d, sizeof(void*)); }
@@ -1461,11 +1471,15 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
     ia.ovf = (int*)f->d_nbr_overflow;
     ia.seeds = (double*)f->d_seeds; ia.src = (n_fov == 1 && !fovs[0].host_zxy) ? fovs[0].dev_zxy : nullptr;
     ia.n = n;
+    ia.ims = n_fov == 1 ? (const void**)f->d_ims : nullptr;
+    ia.fov_start = (int*)f->d_fov_start; ia.fov_of = (int*)f->d_fov_of; ia.im0 = fovs[0].im->d;
     size_t words = ia.zero_words > ia.row_words ? ia.zero_words : ia.row_words;
     unsigned blocks = (unsigned)((words + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
+    dbg_stamp("fit_init launch");
     hipLaunchKernelGGL(fit_init_k, dim3(blocks), dim3(256), 0, st, ia);
+    dbg_stamp("fit_init launched");
   }
   f->pristine = true;
   if (n > 0) {
@@ -1559,6 +1573,8 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   ProfScope ps(stage0 == 0 ? "fit_first" : "fit_repeat");
   hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
                      (int*)f->d_done);
+  dbg_stamp("fit_stages launched");
+  ws_put_deferred_now();   // scratch of the seed stage (PutDefer in ia3_fit_fov_dev): returned while the fit runs
   IA3_KCHECK();
   return IA3_OK;
 }

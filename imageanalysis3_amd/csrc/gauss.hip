@@ -625,7 +625,7 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
     else rc = folded_pair_u16(src, Z, plane, bt, dst_zp, ft, tmp, s, cert, smin, sabs, Y);
   }
   if (rc) return rc;   // FOLD_NOT_COVERED, or an error (negative)
-  // axes 1 and 2 of the short filter: tmp -> dst_front, on the auxiliary stream (the caller goes on with dst_zp)
+  // axes 1 and 2 of the short filter: tmp -> dst_front (the caller goes on with dst_zp on the auxiliary stream)
   int TY, ntile;
   ia3k::dog_pair_tiles(X, Y, &TY, &ntile, nullptr);
   const int xseg = 128;   // a multiple of the 16-row step: steps start on multiples of 16
@@ -636,15 +636,20 @@ int dog_pair_t(const T* src, int Z, int X, int Y, const Taps& ft, const Taps& bt
   const int* mx = cached_border_map(cx, RF, X, IA3_MODE_REFLECT);
   const int* my = cached_border_map(cy, RF, Y, IA3_MODE_REFLECT);
   if (!mx || !my) return ia3rt::set_error(IA3_ENOMEM, "border maps");
-  ia3rt::AuxScope aux;
-  hipStream_t sa = ia3rt::stream();
+  // Fork point: what the caller queues on the auxiliary stream (buffer clears, the bound of the lazy background filter)
+  // may start behind the column kernel.  The plane-wise filter itself — the long one of the two branches — stays on
+  // the MAIN stream, back to back with the column kernel: a launch that waits for another stream's event starts ~20 us
+  // later than one that follows its predecessor in the same queue, and the detector behind the join no longer waits
+  // for the branch that ends last (rocprofv3 kernel trace of a bench step: 24 + 23 us of idle device -> 5 + 10).
+  bool forked;
+  { ia3rt::AuxScope aux; forked = aux.ok; }
   {
     ia3rt::ProfScope ps("gauss_xy_R3");
     const unsigned tiles = (unsigned)ntile * (unsigned)((X + xseg - 1) / xseg);
     dim3 g(8 * ((tiles + 7) / 8), 1, (unsigned)Z);   // tiles, XCD-grouped inside the kernel
-    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, sa, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg, tmax);
+    hipLaunchKernelGGL((gauss_xy_short<T, RF>), g, dim3(256), 0, s, (const T*)tmp, dst_front, X, Y, ft, mx, my, TY, xseg, tmax);
   }
-  return aux.ok ? 0 : FOLD_NO_FORK;
+  return forked ? 0 : FOLD_NO_FORK;
 }
 
 // axes: bit 0 = the axis-0 pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst)

@@ -68,7 +68,22 @@ struct AuxScope {
   AuxScope();
   ~AuxScope();
 };
+// back onto the auxiliary stream behind an earlier AuxScope of the same fork (no new fork point on the main stream)
+struct AuxResume {
+  bool ok;
+  AuxResume();
+  ~AuxResume();
+};
 int aux_join();
+// see runtime.cpp: blocks handed to ws_put inside the scope go back to the cache later (ws_put_deferred_now / scope end)
+struct PutDefer {
+  bool outer;
+  PutDefer();
+  ~PutDefer();
+};
+void ws_put_deferred_now();
+// developer aid: with IA3_DEBUG_TIMES set, prints a monotonic time stamp (us) and the label to stderr
+void dbg_stamp(const char* what);
 
 // Optional per-kernel timing with HIP events on the library stream (ia3_profile_*): bench.py
 // derives roofline.achieved from these, rocprofv3 must agree.

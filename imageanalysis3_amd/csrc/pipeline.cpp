@@ -75,8 +75,11 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   // (Leaving the seed COUNT on the device as well — fitter sized for the finish capacity, kernels reading the count —
   // was measured: no gain for one stream, since the host already queues ahead of the device, and 12 % slower with twelve
   // images in flight because every fit launch then carries 16 k mostly empty blocks; profiles/r02b/ab_sync.log.)
+  PutDefer defer_puts;   // the seed stage's scratch goes back to the cache behind the first fit launch, not in front of it
   ia3k::SeedDev sd;
+  dbg_stamp("fit_fov_dev enter");
   rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
+  dbg_stamp("seed stage returned");
   const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
   if (n_seeds) *n_seeds = n;
   if (n == 0) return IA3_OK;  // fitting.py:206-207

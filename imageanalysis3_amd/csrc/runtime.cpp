@@ -1,5 +1,6 @@
 // libia3.so runtime: context, errors, scratch cache, stack handles (host side of the C ABI).
 #include "ia3_rt.h"
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +30,7 @@ static std::mutex g_mu;
 struct ThreadCtx {
   pid_t pid = 0;
   hipStream_t main = nullptr, aux = nullptr, cur = nullptr;   // cur: what stream() hands out (aux inside an AuxScope)
+  bool defer_puts = false;   // PutDefer: ws_put only queues
   hipEvent_t fork = nullptr, join = nullptr;
   std::vector<void*> deferred;   // scratch blocks released inside an AuxScope
   void* mail_host = nullptr;     // pinned, device-mapped host block of this thread (host_mailbox)
@@ -149,6 +151,13 @@ AuxScope::AuxScope() : ok(false) {
   ok = true;
 }
 AuxScope::~AuxScope() { t_ctx.cur = nullptr; }
+AuxResume::AuxResume() : ok(false) {
+  ThreadCtx& c = t_ctx;
+  if (!c.main || !c.aux) return;
+  c.cur = c.aux;
+  ok = true;
+}
+AuxResume::~AuxResume() { t_ctx.cur = nullptr; }
 int aux_join() {
   ThreadCtx& c = t_ctx;
   if (!c.aux) return IA3_OK;
@@ -156,6 +165,12 @@ int aux_join() {
     return set_error(IA3_EHIP, "stream join failed");
   ws_flush_deferred();
   return IA3_OK;
+}
+void dbg_stamp(const char* what) {
+  static const bool on = getenv("IA3_DEBUG_TIMES") != nullptr;
+  if (!on) return;
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  fprintf(stderr, "[%.1f us] %s\n", ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3, what);
 }
 int num_cus() { return g_cus; }
 
@@ -220,14 +235,31 @@ static void ws_release_locked(void* p, hipStream_t on) {
 // A block returned while an AuxScope is open may still be in use by the auxiliary stream: it stays busy until
 // aux_join() has put the join into the main queue.
 void ws_put(void* p) {
-  if (t_ctx.cur) { t_ctx.deferred.push_back(p); return; }
+  if (t_ctx.cur || t_ctx.defer_puts) { t_ctx.deferred.push_back(p); return; }
   std::lock_guard<std::mutex> lk(g_mu);
   ws_release_locked(p, t_ctx.main ? t_ctx.main : g_stream);
 }
 static void ws_flush_deferred() {
+  if (t_ctx.defer_puts) return;   // a PutDefer is open: its owner decides when
   std::lock_guard<std::mutex> lk(g_mu);
   for (void* p : t_ctx.deferred) ws_release_locked(p, t_ctx.main);
   t_ctx.deferred.clear();
+}
+// Returning a block to the cache records an event on the stream (ws_release_locked): ~2.5 us of host time each, ten
+// blocks at the end of the seed stage — 25 us during which the device has nothing to do, because the host has just
+// learnt the seed count and has not launched the fit yet.  Inside a PutDefer the blocks are only queued; they go back
+// when the owner says so (the fit launches call ws_put_deferred_now) or when the scope ends.
+PutDefer::PutDefer() : outer(t_ctx.defer_puts) { t_ctx.defer_puts = true; }
+PutDefer::~PutDefer() {
+  t_ctx.defer_puts = outer;
+  if (!outer && !t_ctx.cur) ws_flush_deferred();
+}
+void ws_put_deferred_now() {
+  if (t_ctx.cur || t_ctx.deferred.empty()) return;
+  const bool d = t_ctx.defer_puts;
+  t_ctx.defer_puts = false;
+  ws_flush_deferred();
+  t_ctx.defer_puts = d;
 }
 void ws_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -16,6 +16,7 @@
 // Otherwise, and as the fallback when the lazy form's candidate list overflows: both filtered stacks are read once
 // (8 B/voxel for f32) by an LDS-tiled kernel with a rolling three-plane register pipeline along z.
 #include "ia3_rt.h"
+#include <memory>
 #include <immintrin.h>
 #include <algorithm>
 #include <math.h>
@@ -869,8 +870,9 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   auto clear_buffers = [&]() -> int {
     if (cleared) return IA3_OK;
     cleared = true;
-    IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, s));
-    if (fin) IA3_HIP(hipMemsetAsync(fin, 0, o_zxy, s));
+    const hipStream_t cs = stream();   // the auxiliary stream inside an AuxResume
+    IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, cs));
+    if (fin) IA3_HIP(hipMemsetAsync(fin, 0, o_zxy, cs));
     return IA3_OK;
   };
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
@@ -896,7 +898,6 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       rc = gauss_dog_pair(im->d, im->dtype, Z, X, Y, w.data(), R, wb.data(), Rb, a.p, b.p, tmp2.p, &fk, smaxbuf.as<float>(), smin_d, sabs_d);
       if (rc == 0) { paired = true; forked = fk != 0; }
       else if (rc != 1) { if (fk) aux_join(); return rc; }
-      if (paired) { rc = clear_buffers(); if (rc) { if (forked) aux_join(); return rc; } }
     }
     if (!paired) {
       {
@@ -910,16 +911,21 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   }
   if (paired) {
     minim = b.p;
+    // beside the plane-wise filter (main stream): the clears and the bound, on the auxiliary stream when there is one
+    std::unique_ptr<AuxResume> ar(forked ? new AuxResume() : nullptr);
+    const hipStream_t bs = stream();
+    rc = clear_buffers();
+    if (rc) { ar.reset(); if (forked) aux_join(); return rc; }
     if (n_strip && g_strip_bound) {   // the bound from the column kernel's strip minima: no pass over the axis-0 result
       ProfScope ps("seed_blockmin");
       const int nbx = (X + 31) / 32, nby = Y / 32;
       const size_t nb = (size_t)Z * nbx * nby;
       double* lb = lazy_bound_ptr(bnd.p, nb);   // as launch_lazy lays the block out
       const size_t nt = (size_t)DOG_PAIR_ZGROUPS * nbx * nby;
-      hipLaunchKernelGGL(stripbound_k, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, (const float*)smin_d, (const float*)sabs_d, Z, X,
+      hipLaunchKernelGGL(stripbound_k, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, bs, (const float*)smin_d, (const float*)sabs_d, Z, X,
                          nbx, nby, (int)DOG_PAIR_ZGROUPS, (int)(im->dtype == IA3_U16), lb);
-    } else if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
-    else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, s, 0);
+    } else if (im->dtype == IA3_F32) launch_lazy<float>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, bs, 0);
+    else launch_lazy<uint16_t>(nullptr, b.p, Z, X, Y, wb.data(), Rb, 0, 0, bnd.p, nullptr, nullptr, nullptr, 0, nullptr, bs, 0);
   } else if (p.background_gfilt_size > 0) {
     rc = gaussian3d(im->d, im->dtype, Z, X, Y, wb.data(), Rb, IA3_MODE_REFLECT, b.p, tmp.p, lazy ? 1 : 3);
     if (rc) { if (forked) aux_join(); return rc; }
@@ -937,7 +943,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   // in ONE copy (the common case: a few thousand seeds), the rest only if there are more
   constexpr unsigned FIRST = 8192;
   std::vector<Cand> cand;
-  std::vector<char> hbuf(HDR + (size_t)FIRST * sizeof(Cand));
+  std::vector<char> hbuf;   // host path only (131 KB: above malloc's mmap threshold, so allocating it costs page faults)
   SeedCtl hctl, hlazy;
   for (int attempt = 0; attempt < 2; ++attempt) {
     Scratch buf(attempt == 0 ? 0 : HDR + (size_t)capacity * sizeof(Cand));
@@ -986,6 +992,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       }
       FinCtl hfc;
       fe = hipGetLastError();
+      dbg_stamp("seed stage queued");
       if (fe == hipSuccess && mail_host) {
         // the count arrives in the pinned mailbox microseconds after the kernel's store: poll it (a copy into pageable
         // memory + a sleeping synchronise cost 30-50 us of idle device between the detector and the fit)
@@ -1001,6 +1008,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
           }
         }
         hfc.n_alive = mb[1]; hfc.chosen = (int)mb[2]; hfc.n_cand = mb[3]; hfc.overflow = mb[4];
+        dbg_stamp("seed count seen");
       } else {
         if (fe == hipSuccess) fe = hipMemcpyAsync(&hfc, fc, sizeof(FinCtl), hipMemcpyDeviceToHost, s);
         if (fe == hipSuccess) fe = hipStreamSynchronize(s);
@@ -1025,6 +1033,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       ws_put(fin);   // too many candidates: the host path below takes over (the detector's output is still in buf)
       fin = nullptr;
     }
+    hbuf.resize(HDR + (size_t)FIRST * sizeof(Cand));
     IA3_HIP(hipMemcpyAsync(hbuf.data(), bp, hbuf.size(), hipMemcpyDeviceToHost, s));
     IA3_HIP(hipStreamSynchronize(s));
     memcpy(&hctl, hbuf.data(), sizeof(SeedCtl));
