@@ -1574,7 +1574,6 @@ static int launch_stages(ia3_fitter* f, int stage0, int stage1, bool fresh) {
   hipLaunchKernelGGL(fit_stages_k, dim3((unsigned)blocks), dim3(64), 0, st, a, f->n, stage0, stage1, (StageCtl*)f->d_ctl,
                      (int*)f->d_done);
   dbg_stamp("fit_stages launched");
-  ws_put_deferred_now();   // scratch of the seed stage (PutDefer in ia3_fit_fov_dev): returned while the fit runs
   IA3_KCHECK();
   return IA3_OK;
 }
@@ -1611,6 +1610,9 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
     hipLaunchKernelGGL(mail_copy_k, dim3(1), dim3(1024), 0, st, (const unsigned*)f->d_counters, (unsigned*)((char*)md + MAIL_OFF),
                        (head + rows) / 4, (volatile unsigned*)((char*)md + SEQ_OFF), seq);
     IA3_KCHECK();
+    // scratch of the seed stage (PutDefer in ia3_fit_fov_dev) goes back to the cache now: its event records queue up
+    // behind the copy the host is about to wait for, not in front of it
+    ws_put_deferred_now();
     volatile unsigned* mb = (volatile unsigned*)((char*)mh + SEQ_OFF);
     unsigned long long spins = 0;
     while (*mb != seq) {

@@ -753,19 +753,26 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
   out[o] = out_cvt<T>(t);
 }
 
-// order 3, four consecutive outputs of a row per thread.  warp_cubic_k reads 64 coefficients (512 bytes) per output and
-// is bound by the L1 rate those loads are served at.  Neighbouring outputs of a row share three of their four taps in
-// every one of the 16 (z, x) rows whenever their coordinates fall into consecutive cells — the normal case for a drift
-// plus a smooth field — so a thread that makes four outputs loads a run of seven coefficients per row (56 bytes, four
-// load instructions) instead of 4 x 4: 224 bytes per output.  Every output still sums ITS 64 products in SciPy's
-// order with its own weights.  An output whose cell does not line up with the first one's (a coordinate crosses an
+// order 3, NV (2 or 4) consecutive outputs of a row per thread.  warp_cubic_k reads 64 coefficients (512 bytes) per
+// output.  Neighbouring outputs of a row share three of their four taps in every one of the 16 (z, x) rows whenever their
+// coordinates fall into consecutive cells — the normal case for a drift plus a smooth field — so a thread that makes
+// NV outputs loads a run of NV + 3 coefficients per row instead of NV x 4: 320 (NV = 2) or 224 (NV = 4) bytes per
+// output.  Every output still sums ITS 64 products in SciPy's order with its own weights.  An output whose cell does not line up with the first one's (a coordinate crosses an
 // integer inside the group), or a run that would leave the padded row, takes the per-tap loads of warp_cubic_k.
-template <class T, int OCC>
+template <class T, int NV, int OCC>
 __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
                                                      double dy, const void* __restrict__ field, int fdt,
-                                                     T* __restrict__ out, int rows_per) {
+                                                     T* __restrict__ out, int rows_per, double guard) {
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  // uint16 outputs: the last multiplication of a tap and its addition as ONE fused multiply-add (192 instead of 256
+  // operations per output), certified as the Gaussian passes are: against SciPy's separate operations the sum moves by
+  // at most 129 * 2^-53 * sum |products| <= 129 * 2^-53 * 27 * 65535 = 2.6e-8 (the weights are non-negative and sum to 1,
+  // a coefficient of a uint16 image is below 3^3 * 65535), so floor(t + 0.5) can differ only when t + 0.5 lies within
+  // that distance of an integer; outputs within `guard` (1e-6) of one are recomputed with the unfused sequence (the
+  // per-tap path below), as are non-finite sums.  float32 outputs keep the unfused sequence: their rounding
+  // boundaries scale with the value, the bound does not.
+  constexpr bool FUSE = sizeof(T) == 2;
   // Block order: an output row needs 4 x 4 coefficient rows, and its neighbours along z and x need mostly the same ones.
   // Blocks go to the eight XCDs in turn and every XCD has an L2 of its own, so XCD c takes the rows of slab c
   // (X / 8 consecutive rows), walks them with z fastest, then x, then the piece of the row: what the blocks in flight
@@ -775,37 +782,43 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
   const unsigned zq_u = bi % (unsigned)Z, r1 = bi / (unsigned)Z;
   const unsigned xl = r1 % (unsigned)rows_per, h = r1 / (unsigned)rows_per;
   const int x = (int)(xcd * (unsigned)rows_per + xl), zq = (int)zq_u;
-  const int y0 = (int)(h * 256u + threadIdx.x) * 4;
-  if (x >= X || y0 >= Y) return;       // Y % 4 == 0 (host)
+  static_assert(NV == 2 || NV == 4, "outputs per thread");
+  constexpr int RUN = NV + 3;   // coefficients of a row that NV consecutive outputs share
+  const int y0 = (int)(h * 256u + threadIdx.x) * NV;
+  if (x >= X || y0 >= Y) return;       // Y % NV == 0 (host)
   const int Zp = Z + 2 * NPAD, Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
   const size_t o = ((size_t)zq * X + x) * Y + y0, V = (size_t)Z * X * Y;
-  double f[3][4];
+  double f[3][NV];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) f[a][v] = 0.0;
+    for (int v = 0; v < NV; ++v) f[a][v] = 0.0;
   if (field) {
+    typedef float fvec __attribute__((ext_vector_type(NV)));
+    typedef double dvec __attribute__((ext_vector_type(2)));
     if ((fdt & 3) == 1) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float4 q = *(const float4*)((const float*)field + (size_t)a * V + o);
-        f[a][0] = (double)q.x; f[a][1] = (double)q.y; f[a][2] = (double)q.z; f[a][3] = (double)q.w;
+        const fvec q = *(const fvec*)((const float*)field + (size_t)a * V + o);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) f[a][v] = (double)q[v];
       }
     } else {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double2 q0 = *(const double2*)((const double*)field + (size_t)a * V + o);
-        const double2 q1 = *(const double2*)((const double*)field + (size_t)a * V + o + 2);
-        f[a][0] = q0.x; f[a][1] = q0.y; f[a][2] = q1.x; f[a][3] = q1.y;
-      }
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int v = 0; v < NV; v += 2) {
+          const dvec q = *(const dvec*)((const double*)field + (size_t)a * V + o + v);
+          f[a][v] = q.x; f[a][v + 1] = q.y;
+        }
     }
   }
   const int dims[3] = {Zp, Xp, Yp};
   const double dr[3] = {dz, dx, dy};
-  double w[4][3][4];     // [output][axis][tap]
-  int st[4][3];          // first tap (before clamping)
+  double w[NV][3][4];    // [output][axis][tap]
+  int st[NV][3];         // first tap (before clamping)
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < NV; ++v) {
     double cc[3] = {(double)zq, (double)x, (double)(y0 + v)};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -825,8 +838,10 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, (int)((size_t)Zp * Xp * Yp * sizeof(double)), 0x00020000);
   const unsigned rowb = (unsigned)Yp * 8u, planeb = (unsigned)Xp * rowb;
-  double t[4] = {0.0, 0.0, 0.0, 0.0};
-  const bool run_ok = st[0][2] >= 0 && st[0][2] + 6 <= Yp - 1;
+  double t[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) t[v] = 0.0;
+  const bool run_ok = st[0][2] >= 0 && st[0][2] + RUN - 1 <= Yp - 1;
   if (run_ok) {
     unsigned zo[4], xo[4];
 #pragma unroll
@@ -839,27 +854,34 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned off = zo[i] + xo[j];
-        const v4u q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-        const v4u q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
-        const v4u q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
-        const v2u q3 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 48u, 0, 0);
-        const double r[7] = {__hiloint2double((int)q0.y, (int)q0.x), __hiloint2double((int)q0.w, (int)q0.z),
-                             __hiloint2double((int)q1.y, (int)q1.x), __hiloint2double((int)q1.w, (int)q1.z),
-                             __hiloint2double((int)q2.y, (int)q2.x), __hiloint2double((int)q2.w, (int)q2.z),
-                             __hiloint2double((int)q3.y, (int)q3.x)};
+        double r[RUN + 1];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int m = 0; m + 1 < RUN; m += 2) {
+          const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 8u * m, 0, 0);
+          r[m] = __hiloint2double((int)q.y, (int)q.x); r[m + 1] = __hiloint2double((int)q.w, (int)q.z);
+        }
+        {
+          const v2u q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 8u * (RUN - 1), 0, 0);   // RUN is odd
+          r[RUN - 1] = __hiloint2double((int)q.y, (int)q.x);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             double c = r[v + k];
-            c = c * w[v][0][i]; c = c * w[v][1][j]; c = c * w[v][2][k];
-            t[v] = t[v] + c;
+            c = c * w[v][0][i]; c = c * w[v][1][j];
+            if (FUSE) t[v] = __builtin_fma(c, w[v][2][k], t[v]);
+            else { c = c * w[v][2][k]; t[v] = t[v] + c; }
           }
       }
   }
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const bool lined_up = run_ok && st[v][0] == st[0][0] && st[v][1] == st[0][1] && st[v][2] == st[0][2] + v;
+  for (int v = 0; v < NV; ++v) {
+    bool lined_up = run_ok && st[v][0] == st[0][0] && st[v][1] == st[0][1] && st[v][2] == st[0][2] + v;
+    if (FUSE) {
+      const double h = t[v] + 0.5, fr = h - floor(h);
+      lined_up = lined_up && fr >= guard && fr <= 1.0 - guard;   // false for NaN / inf as well
+    }
     if (!lined_up) {
       unsigned yoff[4];
 #pragma unroll
@@ -884,20 +906,15 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
       t[v] = tv;
     }
   }
-  if (sizeof(T) == 2) {
-    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-    us4 r;
-    r.x = (unsigned short)out_cvt<T>(t[0]); r.y = (unsigned short)out_cvt<T>(t[1]);
-    r.z = (unsigned short)out_cvt<T>(t[2]); r.w = (unsigned short)out_cvt<T>(t[3]);
-    *(us4*)(out + o) = r;
-  } else {
-    float4 r;
-    r.x = (float)out_cvt<T>(t[0]); r.y = (float)out_cvt<T>(t[1]); r.z = (float)out_cvt<T>(t[2]); r.w = (float)out_cvt<T>(t[3]);
-    *(float4*)(out + o) = r;
-  }
+  typedef T tvec __attribute__((ext_vector_type(NV)));
+  tvec res;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) res[v] = out_cvt<T>(t[v]);
+  *(tvec*)(out + o) = res;
 }
 
 int g_warp_warm = 64;   // IA3_TUNE_WARP_ONEPASS
+double g_warp_guard = 1e-6;   // IA3_TUNE_WARP_ONEPASS = -2: 2.0 (every uint16 output of the gather through the unfused sequence)
 
 // pass: 0, 1, 2 = how many passes of the prefilter the samples have been through; amax_bits: see IirInit
 IirInit make_init(int n, int pass, double src_max, const unsigned* amax_bits) {
@@ -989,13 +1006,16 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   }
   {
     ProfScope ps("warp_cubic");
-    const bool aligned = Y % 4 == 0 && ((uintptr_t)out->d & 15) == 0 && ((uintptr_t)field & 15) == 0;
+    const bool aligned = Y % 2 == 0 && ((uintptr_t)out->d & 7) == 0 && ((uintptr_t)field & 15) == 0;
     if (aligned && coef_bytes < 0xffffffffull && g_warp_warm >= 0)
     {
-      const int rows_per = (X + 7) / 8, nh = (Y / 4 + 255) / 256;
-      // (forced to 128 registers for a fourth wave per SIMD the kernel spills 25 and takes 5.7 ms instead of 4.0)
-      hipLaunchKernelGGL((warp_cubic4_k<T, 3>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
-                         (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per);
+      // two outputs per thread at five waves per SIMD (94 registers): 3.66 ms on 50 x 2048 x 2048; four per thread need 168
+      // registers (three waves): 4.0 ms — 5.7 ms when forced to 128 (spills), 5.0 ms at two waves — although they issue
+      // fewer loads: the kernel lives on waves in flight, not on its instruction count (the fused multiply-add took 10 %
+      // of the instructions off and nothing off the time)
+      const int rows_per = (X + 7) / 8, nh = (Y / 2 + 255) / 256;
+      hipLaunchKernelGGL((warp_cubic4_k<T, 2, 5>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
+                         (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per, g_warp_guard);
     }
     else
       hipLaunchKernelGGL((warp_cubic_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
@@ -1007,7 +1027,7 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
 
 }  // namespace
 
-namespace ia3k { void set_warp_onepass(int v) { g_warp_warm = v; } }
+namespace ia3k { void set_warp_onepass(int v) { if (v == -2) { g_warp_guard = 2.0; g_warp_warm = 64; } else { g_warp_guard = 1e-6; g_warp_warm = v; } } }
 
 extern "C" {
 
