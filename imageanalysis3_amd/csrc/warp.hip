@@ -762,17 +762,9 @@ __global__ __launch_bounds__(256) void warp_cubic_k(const double* __restrict__ C
 template <class T, int NV, int OCC>
 __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
                                                      double dy, const void* __restrict__ field, int fdt,
-                                                     T* __restrict__ out, int rows_per, double guard) {
+                                                     T* __restrict__ out, int rows_per) {
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  // uint16 outputs: the last multiplication of a tap and its addition as ONE fused multiply-add (192 instead of 256
-  // operations per output), certified as the Gaussian passes are: against SciPy's separate operations the sum moves by
-  // at most 129 * 2^-53 * sum |products| <= 129 * 2^-53 * 27 * 65535 = 2.6e-8 (the weights are non-negative and sum to 1,
-  // a coefficient of a uint16 image is below 3^3 * 65535), so floor(t + 0.5) can differ only when t + 0.5 lies within
-  // that distance of an integer; outputs within `guard` (1e-6) of one are recomputed with the unfused sequence (the
-  // per-tap path below), as are non-finite sums.  float32 outputs keep the unfused sequence: their rounding
-  // boundaries scale with the value, the bound does not.
-  constexpr bool FUSE = sizeof(T) == 2;
   // Block order: an output row needs 4 x 4 coefficient rows, and its neighbours along z and x need mostly the same ones.
   // Blocks go to the eight XCDs in turn and every XCD has an L2 of its own, so XCD c takes the rows of slab c
   // (X / 8 consecutive rows), walks them with z fastest, then x, then the piece of the row: what the blocks in flight
@@ -869,19 +861,14 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             double c = r[v + k];
-            c = c * w[v][0][i]; c = c * w[v][1][j];
-            if (FUSE) t[v] = __builtin_fma(c, w[v][2][k], t[v]);
-            else { c = c * w[v][2][k]; t[v] = t[v] + c; }
+            c = c * w[v][0][i]; c = c * w[v][1][j]; c = c * w[v][2][k];
+            t[v] = t[v] + c;
           }
       }
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    bool lined_up = run_ok && st[v][0] == st[0][0] && st[v][1] == st[0][1] && st[v][2] == st[0][2] + v;
-    if (FUSE) {
-      const double h = t[v] + 0.5, fr = h - floor(h);
-      lined_up = lined_up && fr >= guard && fr <= 1.0 - guard;   // false for NaN / inf as well
-    }
+    const bool lined_up = run_ok && st[v][0] == st[0][0] && st[v][1] == st[0][1] && st[v][2] == st[0][2] + v;
     if (!lined_up) {
       unsigned yoff[4];
 #pragma unroll
@@ -914,7 +901,6 @@ __global__ __launch_bounds__(256, OCC) void warp_cubic4_k(const double* __restri
 }
 
 int g_warp_warm = 64;   // IA3_TUNE_WARP_ONEPASS
-double g_warp_guard = 1e-6;   // IA3_TUNE_WARP_ONEPASS = -2: 2.0 (every uint16 output of the gather through the unfused sequence)
 
 // pass: 0, 1, 2 = how many passes of the prefilter the samples have been through; amax_bits: see IirInit
 IirInit make_init(int n, int pass, double src_max, const unsigned* amax_bits) {
@@ -1011,11 +997,12 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     {
       // two outputs per thread at five waves per SIMD (94 registers): 3.66 ms on 50 x 2048 x 2048; four per thread need 168
       // registers (three waves): 4.0 ms — 5.7 ms when forced to 128 (spills), 5.0 ms at two waves — although they issue
-      // fewer loads: the kernel lives on waves in flight, not on its instruction count (the fused multiply-add took 10 %
-      // of the instructions off and nothing off the time)
+      // fewer loads: the kernel lives on waves in flight, not on its instruction count (a certified fused multiply-add for
+      // uint16 outputs — 192 instead of 256 operations per output, outputs within 1e-6 of a rounding boundary recomputed —
+      // took 10 % of the instructions off and nothing off the time, and was taken out again)
       const int rows_per = (X + 7) / 8, nh = (Y / 2 + 255) / 256;
       hipLaunchKernelGGL((warp_cubic4_k<T, 2, 5>), dim3((unsigned)(8 * rows_per * Z * nh)), dim3(256), 0, st,
-                         (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per, g_warp_guard);
+                         (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1], drift[2], field, fdt, (T*)out->d, rows_per);
     }
     else
       hipLaunchKernelGGL((warp_cubic_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
@@ -1027,7 +1014,7 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
 
 }  // namespace
 
-namespace ia3k { void set_warp_onepass(int v) { if (v == -2) { g_warp_guard = 2.0; g_warp_warm = 64; } else { g_warp_guard = 1e-6; g_warp_warm = v; } } }
+namespace ia3k { void set_warp_onepass(int v) { g_warp_warm = v; } }
 
 extern "C" {
 

@@ -102,9 +102,8 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * once and written once: the anticausal recursion of a tile starts from a value certified by two bounding chains over
  * the samples behind it (warp.hip), with the two-sweep recursion over the rest of the line where the chains do not
  * meet; 1..63 = the same with that many warm-up samples (tests: short warm-ups fail often and drive lines through the
- * fallback); 0 = two sweeps over whole lines; -1 = two sweeps and the one-output-per-thread gather; -2 = default kernels
- * with the guard of the gather's certified fused multiply-add (uint16 outputs) wide open: every output is recomputed
- * with SciPy's unfused sequence.  Results are identical bit for bit. */
+ * fallback); 0 = two sweeps over whole lines; -1 = two sweeps and the one-output-per-thread gather.  Results are
+ * identical bit for bit. */
 #define IA3_TUNE_WARP_ONEPASS 12
 /* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
  * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */

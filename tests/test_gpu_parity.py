@@ -505,7 +505,7 @@ def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
                        ([0.2, -15.3, 0.7], field.astype(np.float64))):
         ref = O.warp_3d_image(im, drift, fld, 3, "nearest")
         try:
-            for knob in (64, 1, 3, 9, 32, 0, -1, -2):
+            for knob in (64, 1, 3, 9, 32, 0, -1):
                 L.check(L.lib().ia3_set_tuning(12, knob))      # IA3_TUNE_WARP_ONEPASS
                 w = warp_3d_image(im, drift, fld, 3, "nearest")
                 assert w.dtype == ref.dtype
