@@ -1332,10 +1332,15 @@ FitArgs make_args(const ia3_fitter* f) {
 
 extern "C" {
 
+// The staging buffer of a fitter (results on their way to the caller: 220 KB for 5 000 rows) is handed from one fitter of
+// a thread to the next: a fresh std::vector of that size is an mmap, its page faults and an munmap per FOV — ~25 us on the
+// host while the device has nothing to do.
+static thread_local std::vector<char> t_spare_stage;
 void ia3_fit_destroy(ia3_fitter* f) {
   if (!f) return;
   if (f->pool) ws_put(f->pool);   // back to the scratch cache; reuse is stream-ordered
   if (f->kd_block) ws_put(f->kd_block);
+  if (f->host_stage.capacity() > t_spare_stage.capacity() && f->host_stage.capacity() <= (64u << 20)) t_spare_stage.swap(f->host_stage);
   delete f;
 }
 
@@ -1384,6 +1389,8 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
   int nball = 0;
   rc = ball_table(p->radius_fit, &d_ball, &nball); if (rc) return rc;
   ia3_fitter* f = new ia3_fitter();   // value-initialised: pointers null, flags false
+  f->host_stage.swap(t_spare_stage);   // capacity of the thread's previous fitter (contents are overwritten before use)
+  f->host_stage.clear();
   f->im = im; f->prm = *p; f->n = n; f->nball = nball;
   f->fov_start.assign(1, 0);
   for (int k = 0; k < n_fov; ++k) { f->ims.push_back(fovs[k].im); f->fov_start.push_back(f->fov_start.back() + fovs[k].n); }

@@ -51,7 +51,8 @@ static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, 
   static const bool dbg = getenv("IA3_DEBUG_TIMES") != nullptr;
   auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   const double t0 = dbg ? now() : 0;
-  std::vector<float> ps((size_t)n * 11);
+  static thread_local std::vector<float> ps;   // kept between calls: see ia3_fit_destroy on what a fresh 220 KB vector costs
+  ps.resize((size_t)n * 11);
   rc = ia3_fit_run(f);
   const double t1 = dbg ? now() : 0;
   if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
