@@ -547,6 +547,90 @@ __global__ __launch_bounds__(576) void bg_sparse_k(const T* __restrict__ zp, int
   }
 }
 
+// The same computation for the production radius (RC = 30 at compile time) with one WAVE per plane z' and three waves per
+// candidate.  The three rows x' = x - 1, x, x + 1 of a plane take their 61 axis-1 taps from 63 consecutive rows of the
+// stack: a lane loads those 63 values once (all in flight together, row starts in scalar registers) and runs the three
+// chains on registers, instead of 3 x 61 loads in eight dependent batches.  Candidates whose 63 rows touch the border
+// of the stack (reflection, clamped x') take the row-by-row code of bg_sparse_k.  Same operations in the same order.
+template <class T, int RC>
+__global__ __launch_bounds__(192) void bg_sparse3_k(const T* __restrict__ zp, int Z, int X, int Y, TapsD taps, int mode,
+                                                    const Cand0* __restrict__ c0, const SeedCtl* __restrict__ ctl0,
+                                                    unsigned cap0, double th_low, Cand* __restrict__ out, unsigned capacity,
+                                                    SeedCtl* __restrict__ ctl) {
+  constexpr int NI = 2 * RC + 3;              // positions per row; also the rows a lane loads
+  static_assert(NI <= 64, "one lane per position");
+  __shared__ float trow[9][NI + 1];
+  __shared__ float mval[32];
+  const int dzw = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned n0 = ctl0->n_cand < cap0 ? ctl0->n_cand : cap0;
+  for (unsigned c = blockIdx.x; c < n0; c += gridDim.x) {   // block-uniform
+    const Cand0 k = c0[c];
+    const int kz = __builtin_amdgcn_readfirstlane(k.z), kx = __builtin_amdgcn_readfirstlane(k.x),
+              ky = __builtin_amdgcn_readfirstlane(k.y);
+    const int zz = min(max(kz + dzw - 1, 0), Z - 1);
+    const T* pl = zp + (size_t)zz * X * Y;
+    if (kx - 1 - RC >= 0 && kx + 1 + RC < X) {   // block-uniform
+      if (lane < NI) {
+        const unsigned yy = (unsigned)reflect_idx(ky - 1 - RC + lane, Y, mode);
+        const T* base = pl + (size_t)(kx - 1 - RC) * Y;
+        T v[NI];
+#pragma unroll
+        for (int m = 0; m < NI; ++m) v[m] = (base + (size_t)m * Y)[yy];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          double acc = (double)v[RC + dx] * taps.w[0];
+#pragma unroll
+          for (int j = RC; j >= 1; --j) acc = acc + ((double)v[RC + dx - j] + (double)v[RC + dx + j]) * taps.w[j];
+          trow[3 * dzw + dx][lane] = quant<T>(acc);
+        }
+      }
+    } else {
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = min(max(kx + dx - 1, 0), X - 1);
+        if (lane < NI) {
+          const int yy = reflect_idx(ky - 1 - RC + lane, Y, mode);
+          double acc = (double)pl[(size_t)xx * Y + yy] * taps.w[0];
+#pragma unroll 8
+          for (int j = RC; j >= 1; --j) {
+            const double a = (double)pl[(size_t)reflect_idx(xx - j, X, mode) * Y + yy];
+            const double b = (double)pl[(size_t)reflect_idx(xx + j, X, mode) * Y + yy];
+            acc = acc + (a + b) * taps.w[j];
+          }
+          trow[3 * dzw + dx][lane] = quant<T>(acc);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- axis 2 at the 27 neighbourhood positions ----
+    if (threadIdx.x < 27) {
+      const int rr = threadIdx.x / 3;
+      const int yc = min(max(ky + (int)threadIdx.x % 3 - 1, 0), Y - 1);
+      const int i0 = yc - (ky - 1 - RC);        // in [RC, RC + 2]
+      const float* t = trow[rr];
+      float ta[RC], tb[RC];
+#pragma unroll
+      for (int j = 1; j <= RC; ++j) { ta[j - 1] = t[i0 - j]; tb[j - 1] = t[i0 + j]; }
+      double acc = (double)t[i0] * taps.w[0];
+#pragma unroll
+      for (int j = RC; j >= 1; --j) acc = acc + ((double)ta[j - 1] + (double)tb[j - 1]) * taps.w[j];
+      mval[threadIdx.x] = quant<T>(acc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cmin = mval[13];
+      float vmin = cmin;
+      for (int q = 0; q < 27; ++q) vmin = mval[q] < vmin ? mval[q] : vmin;
+      const float diff = k.cmax - cmin;                       // float32(max_im) - float32(min_im), fitting.py:106
+      if (vmin != cmin && (double)diff >= th_low) {
+        const unsigned pos = atomicAdd(&ctl->n_cand, 1u);
+        if (pos < capacity) out[pos] = Cand{k.z, k.x, k.y, diff};
+        else ctl->overflow = 1;
+      }
+    }
+    __syncthreads();   // the next candidate's rows overwrite trow
+  }
+}
+
 template <class T>
 void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, int edge, double th_low,
                    Cand* out, unsigned capacity, SeedCtl* ctl, hipStream_t s, int rule = 0) {
@@ -807,6 +891,10 @@ static void launch_lazy(const void* mx, const void* zp, int Z, int X, int Y, con
     ProfScope ps("seed_sparse_bg");
     TapsD t;
     for (int j = 0; j < 64; ++j) t.w[j] = j <= R ? w[R + j] : 0.0;
+    if (R == 30)   // the production radius: 0.163 -> 0.128 ms for 5 000 candidates (grids of 1024 / 2048 / 8192 blocks: 0.158 / 0.134 / 0.129)
+      hipLaunchKernelGGL((bg_sparse3_k<T, 30>), dim3(4096), dim3(192), 0, s, (const T*)zp, Z, X, Y, t, IA3_MODE_REFLECT,
+                         (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
+    else
     hipLaunchKernelGGL((bg_sparse_k<T>), dim3(4096), dim3(576), 0, s, (const T*)zp, Z, X, Y, t, R, IA3_MODE_REFLECT,
                        (const Cand0*)c0, (const SeedCtl*)ctl0, LAZY_CAP, th_low, out, capacity, ctl);
   }
