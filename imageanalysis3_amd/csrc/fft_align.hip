@@ -493,39 +493,85 @@ __global__ __launch_bounds__(256) void half_combine_k(const cplx* __restrict__ P
   out[i] = cplx{re, im};
 }
 
-int abs_argmax(const cplx* a, size_t n, long long* idx, double* val2) {
+// Peak of a correlation + the few scalars the host needs with it, in ONE wait: the partial maxima are reduced by a
+// one-block kernel that also picks the value at the peak and the two power sums and writes everything into the thread's
+// pinned mailbox, followed by the sequence word the host polls.  (Four device-to-host copies with their synchronisations
+// stood between the coarse peak and the upsampled DFT and three more behind it: ~285 us of idle device per crop in the
+// kernel trace, a fifth of align_image.)  Same choice as the host loop of abs_argmax / real_argmax: the largest value,
+// the smallest index among equals; no finite value at all gives index 0.
+struct PeakMail { unsigned seq, pad; long long idx; double val2, re, im, sum0, sum1; };
+__global__ __launch_bounds__(256) void argmax_final_k(const double* __restrict__ pv, const long long* __restrict__ pi, int nb,
+                                                      const double* __restrict__ real_src, const cplx* __restrict__ cplx_src,
+                                                      const double* __restrict__ sums, volatile PeakMail* mail, unsigned seq) {
+  __shared__ double sv[256];
+  __shared__ long long si[256];
+  double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    const double v = pv[k]; const long long i = pi[k];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    long long idx = si[0];
+    double v2 = sv[0];
+    if (!(v2 >= 0.0)) { idx = 0; v2 = -1.0; }   // nothing compared greater than the start value (all NaN): the host loop's answer
+    mail->idx = idx; mail->val2 = v2;
+    mail->re = real_src ? real_src[idx] : (cplx_src ? cplx_src[idx].x : 0.0);
+    mail->im = cplx_src ? cplx_src[idx].y : 0.0;
+    mail->sum0 = sums ? sums[0] : 0.0; mail->sum1 = sums ? sums[1] : 0.0;
+    __threadfence_system();
+    mail->seq = seq;
+  }
+}
+// partials of a |.|^2 argmax already queued on the stream -> peak record on the host
+static int peak_to_host(const double* pv, const long long* pi, int nb, const double* real_src, const cplx* cplx_src,
+                        const double* sums, PeakMail* out) {
   hipStream_t st = stream();
-  const int nb = 512;
-  Scratch pv(nb * sizeof(double)), pi(nb * sizeof(long long));
-  if (!pv.p || !pi.p) return IA3_ENOMEM;
-  hipLaunchKernelGGL(abs_argmax_part_k, dim3(nb), dim3(256), 0, st, a, n, pv.as<double>(), pi.as<long long>());
+  void *mh = nullptr, *md = nullptr;
+  constexpr size_t OFF = 1024;   // the seed stage uses the first 64 bytes of the mailbox, the fit 2048 and up
+  if (host_mailbox(4096, &mh, &md) != IA3_OK) return IA3_ENOMEM;
+  static thread_local unsigned t_seq = 0;
+  const unsigned seq = ++t_seq ? t_seq : ++t_seq;
+  hipLaunchKernelGGL(argmax_final_k, dim3(1), dim3(256), 0, st, pv, pi, nb, real_src, cplx_src, sums,
+                     (volatile PeakMail*)((char*)md + OFF), seq);
   IA3_KCHECK();
-  std::vector<double> hv(nb); std::vector<long long> hi(nb);
-  IA3_HIP(hipMemcpyAsync(hv.data(), pv.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
-  IA3_HIP(hipMemcpyAsync(hi.data(), pi.p, nb * sizeof(long long), hipMemcpyDeviceToHost, st));
-  IA3_HIP(hipStreamSynchronize(st));
-  double bv = -1; long long bi = 0;
-  for (int k = 0; k < nb; ++k) if (hv[k] > bv || (hv[k] == bv && hi[k] < bi)) { bv = hv[k]; bi = hi[k]; }
-  *idx = bi; *val2 = bv;
+  volatile PeakMail* mb = (volatile PeakMail*)((char*)mh + OFF);
+  unsigned long long spins = 0;
+  while (mb->seq != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {   // drained (or failed) without the word
+      if (mb->seq == seq) break;
+      IA3_HIP(hipStreamSynchronize(st));
+      if (mb->seq != seq) return set_error(IA3_EHIP, "correlation peak did not reach the host mailbox");
+      break;
+    }
+  }
+  out->idx = mb->idx; out->val2 = mb->val2; out->re = mb->re; out->im = mb->im; out->sum0 = mb->sum0; out->sum1 = mb->sum1;
   return IA3_OK;
 }
-
-
-int real_argmax(const double* a, size_t n, long long* idx, double* val2) {
+int real_peak(const double* a, size_t n, const double* sums, PeakMail* out) {
   hipStream_t st = stream();
   const int nb = 512;
   Scratch pv(nb * sizeof(double)), pi(nb * sizeof(long long));
   if (!pv.p || !pi.p) return IA3_ENOMEM;
   hipLaunchKernelGGL(real_argmax_part_k, dim3(nb), dim3(256), 0, st, a, n, pv.as<double>(), pi.as<long long>());
-  IA3_KCHECK();
-  std::vector<double> hv(nb); std::vector<long long> hi(nb);
-  IA3_HIP(hipMemcpyAsync(hv.data(), pv.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
-  IA3_HIP(hipMemcpyAsync(hi.data(), pi.p, nb * sizeof(long long), hipMemcpyDeviceToHost, st));
-  IA3_HIP(hipStreamSynchronize(st));
-  double bv = -1; long long bi = 0;
-  for (int k = 0; k < nb; ++k) if (hv[k] > bv || (hv[k] == bv && hi[k] < bi)) { bv = hv[k]; bi = hi[k]; }
-  *idx = bi; *val2 = bv;
-  return IA3_OK;
+  return peak_to_host(pv.as<double>(), pi.as<long long>(), nb, a, nullptr, sums, out);
+}
+int abs_peak(const cplx* a, size_t n, const double* sums, PeakMail* out) {
+  hipStream_t st = stream();
+  const int nb = 512;
+  Scratch pv(nb * sizeof(double)), pi(nb * sizeof(long long));
+  if (!pv.p || !pi.p) return IA3_ENOMEM;
+  hipLaunchKernelGGL(abs_argmax_part_k, dim3(nb), dim3(256), 0, st, a, n, pv.as<double>(), pi.as<long long>());
+  return peak_to_host(pv.as<double>(), pi.as<long long>(), nb, nullptr, a, sums, out);
 }
 
 int g_fft_c2c = 0;   // IA3_TUNE_FFT_C2C: 1 = complex transforms of the real stacks (first version; tests compare)
@@ -639,12 +685,10 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     // rbuf := ifftn(prod), real (unnormalised by hipFFT; the transform may overwrite fa)
     IA3_FFT(hipfftExecZ2D(inv.h, fa.as<cplx>(), rbuf.as<double>()));
     IA3_KCHECK();
-    rc = real_argmax(rbuf.as<double>(), n, &idx, &v2); if (rc) return rc;
-    double cc;
-    IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipMemcpyAsync(&cc, rbuf.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipStreamSynchronize(st));
-    ccmax = cplx{cc / (double)n, 0.0};
+    PeakMail pk;
+    rc = real_peak(rbuf.as<double>(), n, sums.as<double>(), &pk); if (rc) return rc;
+    idx = pk.idx; v2 = pk.val2; hs[0] = pk.sum0; hs[1] = pk.sum1;
+    ccmax = cplx{pk.re / (double)n, 0.0};
   } else {
     if (ref->dtype == IA3_F32) {
       hipLaunchKernelGGL((to_cplx_k<float>), dim3(nb), dim3(256), 0, st, (const float*)ref->d, fa.as<cplx>(), n);
@@ -665,11 +709,10 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     // fb := ifftn(prod) (unnormalised by hipFFT: scale 1/n applied to the picked value only)
     IA3_FFT(hipfftExecZ2Z(plan.h, fa.as<cplx>(), fb.as<cplx>(), HIPFFT_BACKWARD));
     IA3_KCHECK();
-    rc = abs_argmax(fb.as<cplx>(), n, &idx, &v2); if (rc) return rc;
-    IA3_HIP(hipMemcpyAsync(hs, sums.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipMemcpyAsync(&ccmax, fb.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipStreamSynchronize(st));
-    ccmax.x /= (double)n; ccmax.y /= (double)n;
+    PeakMail pk;
+    rc = abs_peak(fb.as<cplx>(), n, sums.as<double>(), &pk); if (rc) return rc;
+    idx = pk.idx; v2 = pk.val2; hs[0] = pk.sum0; hs[1] = pk.sum1;
+    ccmax = cplx{pk.re / (double)n, pk.im / (double)n};
   }
   const int dims[3] = {Z, X, Y};
   long long rem = idx;
@@ -722,10 +765,10 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
     contract(t2.as<cplx>(), t3.as<cplx>(), R * R, Z, off[0]);   // (R_z, R_x, R_y)
     IA3_KCHECK();
     const size_t nr = (size_t)R * R * R;
-    rc = abs_argmax(t3.as<cplx>(), nr, &idx, &v2); if (rc) return rc;   // |conj(x)| = |x|
-    IA3_HIP(hipMemcpyAsync(&ccmax, t3.as<cplx>() + idx, sizeof(cplx), hipMemcpyDeviceToHost, st));
-    IA3_HIP(hipStreamSynchronize(st));
-    ccmax.y = -ccmax.y;  // .conj()
+    PeakMail fine;
+    rc = abs_peak(t3.as<cplx>(), nr, nullptr, &fine); if (rc) return rc;   // |conj(x)| = |x|
+    idx = fine.idx; v2 = fine.val2;
+    ccmax = cplx{fine.re, -fine.im};  // .conj()
     rem = idx;
     int pk[3];
     pk[2] = (int)(rem % R); rem /= R; pk[1] = (int)(rem % R); rem /= R; pk[0] = (int)rem;
