@@ -55,3 +55,42 @@ def fft3d_from2d(im1, im2, gb=5, max_disp=150):
 
 def _host(im):
     return im.download() if isinstance(im, L.DeviceStack) else im
+
+
+def translation_align_pts(cents_fix, cents_target, cutoff=2., xyz_res=1,
+                          plt_val=False, return_pts=False, verbose=False):
+    """alignment_tools.py:356-419 — translation between two point sets without any image: every pair of target
+    points votes, through the pairs of fixed points that are equally far apart (within ``cutoff``), for the
+    translations that would map the pair's ends onto the first point of such a fixed pair; the fullest cell of
+    the 3-D histogram of votes (cells of ``xyz_res``) gives a rough translation, and the median offset of the
+    points that then pair up within ``2 * xyz_res`` is returned (with the paired fixed / target points if
+    ``return_pts``).  Host NumPy/SciPy like the reference (used by ``align_beads(use_fft=False)``)."""
+    from scipy.spatial.distance import pdist, cdist
+    fix = np.array(cents_fix)
+    tar = np.array(cents_target)
+    if plt_val:
+        raise NotImplementedError("plt_val=True (matplotlib figures) is not provided")
+    i_fix, j_fix = np.triu_indices(len(fix), 1)          # pairs in the order of pdist / itertools.combinations
+    i_tar, j_tar = np.triu_indices(len(tar), 1)
+    d_fix, d_tar = pdist(fix), pdist(tar)
+    votes = []
+    for dt, a, b in zip(d_tar, i_tar, j_tar):
+        first = fix[i_fix[np.abs(d_fix - dt) < cutoff]]  # first point of every fixed pair of that length
+        votes.append(first - tar[a])
+        votes.append(first - tar[b])
+    votes = np.concatenate(votes) if votes else np.zeros((0, fix.shape[1]))
+    nbins = np.array((np.max(votes, axis=0) - np.min(votes, axis=0)) / float(xyz_res), dtype=int)
+    hist, edges = np.histogramdd(votes, bins=nbins)
+    best = np.unravel_index(np.argmax(hist), hist.shape)
+    rough = np.array([e[k] for e, k in zip(edges, best)])
+    nearest = np.argmin(cdist(fix, tar + rough), axis=1)   # for every fixed point its closest shifted target point
+    ok = np.sqrt(np.sum((tar[nearest] + rough - fix) ** 2, axis=-1)) < 2 * xyz_res
+    pair_fix, pair_tar = fix[ok], tar[nearest[ok]]
+    if len(pair_fix) == 0:
+        raise ValueError("No matched points exist in cents[inds_closestF]")
+    shift = np.median(pair_tar - pair_fix, axis=0)
+    if verbose:
+        print(f"--- {len(pair_fix)} points are aligned")
+    if return_pts:
+        return shift, pair_fix, pair_tar
+    return shift

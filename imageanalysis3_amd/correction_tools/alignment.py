@@ -78,21 +78,25 @@ def align_beads(tar_cts, ref_cts,
                 verbose=True):
     """correction_tools/alignment.py:139-216 — mean shift of uniquely paired bead centres after an FFT
     rough alignment of the two crops.  Returns (drift,) or (drift, paired target centres, paired reference centres)."""
-    from ..alignment_tools import fft3d_from2d
+    from ..alignment_tools import fft3d_from2d, translation_align_pts
     from ..spot_tools.matching import find_paired_centers, check_paired_centers
     if not use_fft:
-        raise NotImplementedError("use_fft=False (alignment_tools.translation_align_pts brute-force matching) "
-                                  "is off the production path (alignment.py:653) and not provided")
-    if tar_im is None or ref_im is None:
-        raise ValueError("both tar_im and ref_im should be given if use FFT!")
-    if np.shape(tar_im) != np.shape(ref_im):
-        raise IndexError(f"tar_im shape:{np.shape(tar_im)} should match ref_im shape:{np.shape(ref_im)}")
-    # integer shift from the projections' cross-correlation, searched over half the crop
-    coarse = fft3d_from2d(tar_im, ref_im, gb=fft_filt_size, max_disp=np.max(np.shape(tar_im)) / 2)
-    # beads that pair up uniquely within the matching distance once the coarse shift is applied
-    drift, pair_tar, pair_ref = find_paired_centers(np.array(tar_cts), np.array(ref_cts), coarse,
-                                                    cutoff=float(match_distance_th), return_paired_cts=True,
-                                                    verbose=verbose)
+        # no images: translation from the point sets alone (:177-185; the reference names the returned point sets
+        # reference first, target second)
+        drift, pair_ref, pair_tar = translation_align_pts(np.array(ref_cts), np.array(tar_cts),
+                                                          cutoff=float(match_distance_th), return_pts=True,
+                                                          verbose=verbose)
+    else:
+        if tar_im is None or ref_im is None:
+            raise ValueError("both tar_im and ref_im should be given if use FFT!")
+        if np.shape(tar_im) != np.shape(ref_im):
+            raise IndexError(f"tar_im shape:{np.shape(tar_im)} should match ref_im shape:{np.shape(ref_im)}")
+        # integer shift from the projections' cross-correlation, searched over half the crop
+        coarse = fft3d_from2d(tar_im, ref_im, gb=fft_filt_size, max_disp=np.max(np.shape(tar_im)) / 2)
+        # beads that pair up uniquely within the matching distance once the coarse shift is applied
+        drift, pair_tar, pair_ref = find_paired_centers(np.array(tar_cts), np.array(ref_cts), coarse,
+                                                        cutoff=float(match_distance_th), return_paired_cts=True,
+                                                        verbose=verbose)
     if verbose:
         print(f"-- {len(pair_ref)} bead pairs, drift before the outlier test: {drift}")
     if check_paired_cts and len(pair_ref) > 3:   # neighbour-consistency test needs a triangulation: at least 4 pairs
