@@ -544,10 +544,10 @@ static int peak_to_host(const double* pv, const long long* pi, int nb, const dou
                      (volatile PeakMail*)((char*)md + OFF), seq);
   IA3_KCHECK();
   volatile PeakMail* mb = (volatile PeakMail*)((char*)mh + OFF);
-  unsigned long long spins = 0;
+  SpinWait sw;
   while (mb->seq != seq) {
-    __builtin_ia32_pause();
-    if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {   // drained (or failed) without the word
+    sw.relax();
+    if (((sw.n & 0xfffff) == 0 || (sw.n > 40400 && (sw.n & 0x3ff) == 0)) && hipStreamQuery(st) != hipErrorNotReady) {   // drained (or failed) without the word
       if (mb->seq == seq) break;
       IA3_HIP(hipStreamSynchronize(st));
       if (mb->seq != seq) return set_error(IA3_EHIP, "correlation peak did not reach the host mailbox");

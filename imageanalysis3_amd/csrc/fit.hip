@@ -1621,10 +1621,10 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
     // behind the copy the host is about to wait for, not in front of it
     ws_put_deferred_now();
     volatile unsigned* mb = (volatile unsigned*)((char*)mh + SEQ_OFF);
-    unsigned long long spins = 0;
+    SpinWait sw;
     while (*mb != seq) {
-      __builtin_ia32_pause();
-      if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {   // the stream drained (or failed) without the word
+      sw.relax();
+      if (((sw.n & 0xfffff) == 0 || (sw.n > 40400 && (sw.n & 0x3ff) == 0)) && hipStreamQuery(st) != hipErrorNotReady) {   // the stream drained (or failed) without the word
         if (*mb == seq) break;
         IA3_HIP(hipStreamSynchronize(st));
         if (*mb != seq) return set_error(IA3_EHIP, "fit results did not reach the host mailbox");

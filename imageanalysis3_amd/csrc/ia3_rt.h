@@ -26,6 +26,13 @@ int num_cus();  // compute units of the selected device
 // that spins on an event: small results reach the host without a copy into pageable memory and a sleeping synchronise
 int host_mailbox(size_t bytes, void** host, void** dev);
 int stream_wait_spin(hipStream_t st);
+// One step of a host-side polling loop: a CPU relax hint for the first ~100-200 us (what the per-FOV path waits for is
+// microseconds away), afterwards the core is given up between looks (a group fit runs for tens of milliseconds and up to
+// 17 library threads may be waiting at once: they must not take the cores of the callers and of the upload copies).
+struct SpinWait {
+  unsigned long long n = 0;
+  void relax();
+};
 int set_upload_threads(int n);   // IA3_TUNE_UPLOAD_THREADS
 inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 

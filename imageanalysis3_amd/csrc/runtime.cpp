@@ -115,7 +115,7 @@ int host_mailbox(size_t bytes, void** host, void** dev) {
     if (c.mail_host) (void)hipHostFree(c.mail_host);
     c.mail_host = c.mail_dev = nullptr; c.mail_bytes = 0;
     const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-    if (hipHostMalloc(&c.mail_host, want, hipHostMallocMapped) != hipSuccess) return set_error(IA3_ENOMEM, "pinned mailbox");
+    if (hipHostMalloc(&c.mail_host, want, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return set_error(IA3_ENOMEM, "pinned mailbox");
     if (hipHostGetDevicePointer(&c.mail_dev, c.mail_host, 0) != hipSuccess) { (void)hipHostFree(c.mail_host); c.mail_host = nullptr; return set_error(IA3_EHIP, "pinned mailbox mapping"); }
     memset(c.mail_host, 0, want);
     c.mail_bytes = want;
@@ -123,15 +123,31 @@ int host_mailbox(size_t bytes, void** host, void** dev) {
   *host = c.mail_host; *dev = c.mail_dev;
   return IA3_OK;
 }
+void SpinWait::relax() {
+  if (++n < 40000) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+    return;
+  }
+  if (n < 40400) { sched_yield(); return; }
+  timespec ts = {0, 20000};   // 20 us
+  nanosleep(&ts, nullptr);
+}
+
 // hipStreamSynchronize that spins on an event instead of sleeping (the results it waits for are microseconds away)
 int stream_wait_spin(hipStream_t st) {
   ThreadCtx& c = t_ctx;
   if (!c.mail_ev && hipEventCreateWithFlags(&c.mail_ev, hipEventDisableTiming) != hipSuccess) { c.mail_ev = nullptr; IA3_HIP(hipStreamSynchronize(st)); return IA3_OK; }
   IA3_HIP(hipEventRecord(c.mail_ev, st));
+  unsigned long long looks = 0;
   for (;;) {
     const hipError_t e = hipEventQuery(c.mail_ev);
     if (e == hipSuccess) return IA3_OK;
     if (e != hipErrorNotReady) return set_error(IA3_EHIP, "stream wait failed: %s", hipGetErrorString(e));
+    if (++looks > 2000) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }   // a long wait: give the core up between looks
   }
 }
 

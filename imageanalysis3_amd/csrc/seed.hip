@@ -17,7 +17,6 @@
 // (8 B/voxel for f32) by an LDS-tiled kernel with a rolling three-plane register pipeline along z.
 #include "ia3_rt.h"
 #include <memory>
-#include <immintrin.h>
 #include <algorithm>
 #include <math.h>
 #include <string.h>
@@ -666,7 +665,7 @@ namespace {
 // and the seed list never leaves HBM between the detector and the fitter.
 constexpr unsigned FIN_CAP = 8192;
 constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
-struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; };   // the last two mirror SeedCtl: one read-back
+struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; unsigned done, pad[3]; };   // n_cand / overflow mirror SeedCtl: one read-back; done: blocks of fin_scatter_k that have stored their seeds
 
 __device__ __forceinline__ unsigned fin_n(const SeedCtl* sctl) { return sctl->n_cand < FIN_CAP ? sctl->n_cand : FIN_CAP; }
 __device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h desc, then z, x, y desc (finish_seeds)
@@ -752,25 +751,33 @@ __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__
                                                      volatile unsigned* __restrict__ mail, unsigned seq) {
   const unsigned n = fin_n(sctl);
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) {   // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
-    const unsigned nc = sctl->n_cand;
-    const unsigned ov = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
-    fcw->n_cand = nc;
-    fcw->overflow = ov;
-    if (mail) {   // the four control words straight into the host's pinned mailbox, then the sequence number it polls
-      mail[1] = fcw->n_alive; mail[2] = (unsigned)fcw->chosen; mail[3] = nc; mail[4] = ov;
-      __threadfence_system();
-      mail[0] = seq;
+  if (i < n) {
+    const double th = lev.th[fc->chosen];
+    const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
+    const unsigned r = alive ? rank[i] : 0u;
+    if (alive && !(max_num > 0 && r >= (unsigned)max_num)) {
+      zxy[3 * r] = c[i].z; zxy[3 * r + 1] = c[i].x; zxy[3 * r + 2] = c[i].y;
+      hh[r] = (double)c[i].h;
     }
   }
-  if (i >= n) return;
-  const double th = lev.th[fc->chosen];
-  const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
-  if (!alive) return;
-  const unsigned r = rank[i];
-  if (max_num > 0 && r >= (unsigned)max_num) return;
-  zxy[3 * r] = c[i].z; zxy[3 * r + 1] = c[i].x; zxy[3 * r + 2] = c[i].y;
-  hh[r] = (double)c[i].h;
+  // The host polls the mailbox and may hand the seed list to ANOTHER stream (the group fitter of ia3_fit_fovs) as soon as
+  // it sees the sequence number, before this kernel has ended: the word is therefore published by the block that
+  // finishes LAST, after every block's seeds have been released to device scope.
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(&fcw->done, 1u) != gridDim.x - 1) return;
+  __threadfence();
+  // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
+  const unsigned nc = sctl->n_cand;
+  const unsigned ov = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
+  fcw->n_cand = nc;
+  fcw->overflow = ov;
+  if (mail) {   // the four control words straight into the host's pinned mailbox, then the sequence number it polls
+    mail[1] = fcw->n_alive; mail[2] = (unsigned)fcw->chosen; mail[3] = nc; mail[4] = ov;
+    __threadfence_system();
+    mail[0] = seq;
+  }
 }
 
 }  // namespace
@@ -1085,10 +1092,10 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
         // the count arrives in the pinned mailbox microseconds after the kernel's store: poll it (a copy into pageable
         // memory + a sleeping synchronise cost 30-50 us of idle device between the detector and the fit)
         volatile unsigned* mb = (volatile unsigned*)mail_host;
-        unsigned long long spins = 0;
+        SpinWait sw;
         while (mb[0] != seq) {
-          __builtin_ia32_pause();
-          if ((++spins & 0xfffff) == 0 && hipStreamQuery(s) != hipErrorNotReady) {   // the stream drained (or failed) without the word
+          sw.relax();
+          if (((sw.n & 0xfffff) == 0 || (sw.n > 40400 && (sw.n & 0x3ff) == 0)) && hipStreamQuery(s) != hipErrorNotReady) {   // the stream drained (or failed) without the word
             if (mb[0] == seq) break;
             fe = hipStreamSynchronize(s);
             if (fe == hipSuccess && mb[0] != seq) fe = hipErrorUnknown;

@@ -42,7 +42,7 @@ def get_seeds(im, max_num_seeds=None, th_seed=150,
         _local_edges = np.zeros(len(np.shape(im)))
         _im = im
     if use_percentile:                                                       # :75-76 (whole image)
-        _th_seed = np.percentile(im, th_seed_per) - np.percentile(im, (100 - th_seed_per) / 2)
+        _th_seed = _score_at_percentile(im, th_seed_per) - _score_at_percentile(im, (100 - th_seed_per) / 2)
     else:
         _th_seed = th_seed
     if verbose:
@@ -72,6 +72,24 @@ def get_seeds(im, max_num_seeds=None, th_seed=150,
     if verbose:
         print(f"->{_th_used.value:.2f}, found {len(_final)} seeds in {time.time()-_start_time:.2f}s")
     return _final
+
+
+def _score_at_percentile(a, per):
+    """``scipy.stats.scoreatpercentile(a, per)`` (what spot_tools/fitting.py:76 calls) with its arithmetic — the two
+    order statistics around index ``per/100 * (n-1)`` weighted in float64, ``sum(v * w) / sum(w)`` — but from a
+    partition instead of a full sort.  ``np.percentile`` interpolates as ``a + (b - a) * t`` (in float32 for a float32
+    image) and differs from it in the last bits, which moves threshold compares."""
+    flat = np.asarray(a).ravel()
+    if flat.size == 0:
+        return np.nan
+    if not (0 <= per <= 100):
+        raise ValueError("percentile must be in the range [0, 100]")
+    idx = per / 100. * (flat.size - 1)
+    i = int(idx)
+    if i == idx:
+        return np.add.reduce(np.partition(flat, i)[i:i + 1] * np.array(1), axis=0) / 1.0
+    w = np.array([(i + 1 - idx), (idx - i)], float)
+    return np.add.reduce(np.partition(flat, [i, i + 1])[i:i + 2] * w, axis=0) / w.sum()
 
 
 def remove_edge_points(im, T_seeds, distance=2):

@@ -361,6 +361,41 @@ def fit_case_golden(R, name, spec):
     print(name, "seeds", len(d["seeds_h"]), "table", d["table"].shape, "n_iter", fitter.n_iter)
 
 
+SEEDOPT_CASES = ["c1_f32", "c1_u16", "clu_f32"]
+
+
+def seed_mask_for(shape):
+    """The mask of the seed_mask fixtures (mirrored by tests): a slanted half-space plus a box, as float32 0/1."""
+    z, x, y = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    m = ((x + 2 * y) % 97 < 60) | ((z > shape[0] // 2) & (x < shape[1] // 3))
+    return m.astype(np.float32)
+
+
+def seedopts_golden(meta):
+    """Options of get_seeds / fit_fov_image that the other fixtures leave at their defaults: the percentile threshold
+    (spot_tools/fitting.py:75-76, scipy.stats.scoreatpercentile on the uncropped image) and seed_mask (:210-218)."""
+    R = ref_loader.load_reference()
+    fit = R.fitting
+    d = {}
+    for name in SEEDOPT_CASES:
+        im = case_image(CASES[name])
+        for per in (95, 99.5, 98):
+            tag = "%s_per%s" % (name, str(per).replace(".", "p"))
+            d[tag] = fit.get_seeds(im, use_percentile=True, th_seed_per=per, return_h=True)
+            d[tag + "_nodyn"] = fit.get_seeds(im, use_percentile=True, th_seed_per=per, use_dynamic_th=False, return_h=True)
+        d[name + "_per_sel"] = fit.get_seeds(im, use_percentile=True, th_seed_per=99.5, return_h=True,
+                                             sel_center=[s // 2 for s in im.shape], seed_radius=25)
+        d[name + "_per_table"] = quiet(fit.fit_fov_image, im, "647", use_percentile=True, th_seed_per=99.5,
+                                       max_num_seeds=None, verbose=False)
+        mask = seed_mask_for(im.shape)
+        d[name + "_mask_table"] = quiet(fit.fit_fov_image, im, "647", th_seed=600, max_num_seeds=None, seed_mask=mask,
+                                        verbose=False)
+        d[name + "_mask_given"] = quiet(fit.fit_fov_image, im, "647", seeds=fit.get_seeds(im, th_seed=600, return_h=True),
+                                        seed_mask=mask > 0, verbose=False)
+    np.savez_compressed(os.path.join(OUT, "seedopts.npz"), **d)
+    print("seedopts:", {k: v.shape for k, v in d.items() if k.endswith("table")})
+
+
 def one_case(name):
     """python oracle/make_golden.py case:<name> — one fitting case, meta.json updated in place."""
     R = ref_loader.load_reference()
@@ -477,6 +512,7 @@ def main():
     daxp_golden(meta)
     seg_golden(meta)
     profiles_golden(meta)
+    seedopts_golden(meta)
 
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -33,6 +33,13 @@ def build_case(name):
     return im
 
 
+def seed_mask_for(shape):
+    """The mask of the seed_mask fixtures (mirror of oracle/make_golden.py::seed_mask_for)."""
+    z, x, y = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    m = ((x + 2 * y) % 97 < 60) | ((z > shape[0] // 2) & (x < shape[1] // 3))
+    return m.astype(np.float32)
+
+
 def load_golden(fname):
     return dict(np.load(os.path.join(GOLDEN, fname), allow_pickle=False))
 

@@ -84,7 +84,10 @@ def test_bench_fov_window_vs_oracle(dtype):
         np.savez(os.path.join(ROOT, "gpurun_out", "window_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw,
                  nfev_peak=fo.nfev_peak, nfev_last=fo.nfev_last, stuck=stuck)
     assert rel.max() <= 1e-4, (rel.max(), cover)
-    assert stuck.sum() <= (0 if dtype == np.float32 else 60), cover
+    # the carve-outs are pinned to what they were seen to cover (uint16 window 2 slow rows, 0 stuck;
+    # float32 none of either), with a margin of two rows, so a change that pushes more fits into them fails here
+    assert slow.sum() <= (0 if dtype == np.float32 else 4), cover
+    assert stuck.sum() <= (0 if dtype == np.float32 else 2), cover
     # ---- device on the whole FOV: production-size launches ----------------------------------------------------------
     sf = get_seeds(im, th_seed=600.0, return_h=True)
     in_f = (sf[:, 1] < INNER) & (sf[:, 2] < INNER)
@@ -110,7 +113,7 @@ def test_bench_fov_window_vs_oracle(dtype):
         tied[i_] = any(k_ != i_ and so[k_, 3] == so[i_, 3] for k_ in nb)
     cover_t = "equal-height overlapping pairs left out: %d of %d rows" % (tied.sum(), len(so))
     print(cover_t)
-    assert tied.sum() <= (0 if dtype == np.float32 else 0.03 * len(so)), cover_t
+    assert tied.sum() <= (0 if dtype == np.float32 else 8), cover_t   # seen: 6 rows (three pairs)
     sel = np.where(ok & ~tied & in_o & (so[:, 1] < INNER - 16) & (so[:, 2] < INNER - 16))[0]
     d, j = cKDTree(t[:, 1:4]).query(po[sel, 1:4])
     if d.max() >= 1e-3:
@@ -120,6 +123,80 @@ def test_bench_fov_window_vs_oracle(dtype):
     assert len(sel) > 1000 and d.max() < 1e-3, (d.max(), len(sel), cover_t)
     rel = _rel(t[j], po[sel])
     assert rel.max() <= 1e-4, (rel.max(), "compared rows %d" % len(sel), cover, cover_t)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16])
+def test_bench_clustered_window_vs_oracle(dtype):
+    """The crowded field the bench measures (layout B: 5 000 spots in 200 territories, seed 50 — bench.py's own generator
+    call) at production size: seed sets bit-exact on a window and on the whole FOV, and on the window — where the oracle
+    finishes in test time — the ordered refit (External/Fitting_v4.py:590-683) sweep for sweep: same number of sweeps,
+    first-fit voxel counts exact (Voronoi ties by the cKDTree rule), rows <= 1e-4."""
+    import np_oracle as O
+    from imageanalysis3_amd import synth
+    from imageanalysis3_amd.spot_tools.fitting import get_seeds
+    from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
+    from scipy.spatial import cKDTree
+    im = synth.make_fov(SHAPE, 5000, 50, layout="clustered", dtype=dtype)[0]
+    CW = 768
+    x0, y0 = 640, 512     # a window off the FOV's corner: tiles, XCD slabs and territories cut at all four sides
+    win = np.ascontiguousarray(im[:, x0:x0 + CW, y0:y0 + CW])
+    so = O.get_seeds(win, th_seed=600.0, return_h=True)
+    sw = get_seeds(win, th_seed=600.0, return_h=True)
+    assert np.array_equal(seed_set(sw), seed_set(so))
+    assert len(so) > 400, len(so)
+    # whole-FOV seeds inside the window's interior (filter halo 30 + 3) are the window's seeds
+    sf = get_seeds(im, th_seed=600.0, return_h=True)
+    H = 34
+    in_f = (sf[:, 1] >= x0 + H) & (sf[:, 1] < x0 + CW - H) & (sf[:, 2] >= y0 + H) & (sf[:, 2] < y0 + CW - H)
+    in_o = (so[:, 1] >= H) & (so[:, 1] < CW - H) & (so[:, 2] >= H) & (so[:, 2] < CW - H)
+    sfw = sf[in_f].copy()
+    sfw[:, 1] -= x0
+    sfw[:, 2] -= y0
+    assert np.array_equal(seed_set(sfw), seed_set(so[in_o]))
+    # ---- the fits, in the oracle's seed order ------------------------------------------------------------------------
+    fo = O.iter_fit_seed_points(win, so[:, :3].T)
+    fo.firstfit()
+    first_o = np.array(fo.ps, dtype=np.float64)
+    nvox_o = np.array([len(g_[0]) for g_ in fo.gparms])
+    fo.repeatfit()
+    po = np.array(fo.ps, dtype=np.float64)
+    f = iter_fit_seed_points(win, so[:, :3].T)
+    f.firstfit()
+    first_w = np.array(f.ps, dtype=np.float64)
+    assert np.array_equal(np.asarray(f.nvox), nvox_o)          # Voronoi cells incl. exact ties
+    f.repeatfit()
+    pw = np.array(f.ps, dtype=np.float64)
+    pairs = cKDTree(so[:, :3]).query_pairs(10.0 + 1e-9)
+    # fits that stop at maxfev in the oracle end wherever their last step landed; every seed that overlaps one (within
+    # 2 r), and what overlaps those, sees a different residual: left out, counted
+    stuck = fo.nfev_peak >= 1000
+    tree = cKDTree(so[:, :3])
+    for _ in range(3):
+        near = tree.query_ball_point(so[stuck, :3], 10.0 + 1e-9)
+        if len(near):
+            stuck[np.unique(np.concatenate([np.asarray(q, dtype=int) for q in near]))] = True
+    finite = ~np.isnan(po).any(1)
+    slow = ~stuck & finite & (fo.nfev_peak >= 100)
+    ok = ~stuck & finite & ~slow
+    cover = "seeds %d, overlapping pairs %d, sweeps %d: 1e-4 bar %d, slow (nfev >= 100, 2e-2 bar) %d, stuck %d, NaN %d" % (
+        len(so), len(pairs), fo.n_iter, ok.sum(), slow.sum(), stuck.sum(), (~finite).sum())
+    print(cover)
+    assert len(pairs) > 300 and fo.n_iter >= 3, cover          # it IS a crowded field
+    assert f.n_iter == fo.n_iter, (f.n_iter, cover)
+    assert np.array_equal(np.isnan(pw).any(1), np.isnan(po).any(1)), cover
+    fin1 = ~np.isnan(first_o).any(1)
+    assert _rel(first_w[fin1], first_o[fin1]).max() <= 1e-4, cover
+    rel = _rel(pw[ok], po[ok])
+    if rel.max() > 1e-4:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "clustered_window_%s.npz" % np.dtype(dtype).name), so=so, po=po, pw=pw,
+                 nfev_peak=fo.nfev_peak, stuck=stuck)
+    assert rel.max() <= 1e-4, (rel.max(), cover)
+    if slow.any():
+        assert _rel(pw[slow], po[slow]).max() <= 2e-2, cover
+    # pinned to what the oracle was seen to do on this window (both dtypes: no fit at maxfev, one fit with >= 100
+    # evaluations), margin two rows
+    assert stuck.sum() <= (0 if dtype == np.float32 else 2) and slow.sum() <= 3, cover
 
 
 def test_drift_crops_full_size_vs_oracle():

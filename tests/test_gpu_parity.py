@@ -216,6 +216,47 @@ def test_fit_fov_image_golden(name):
     assert np.array_equal(im, keep)
     t20 = fit_fov_image(im, "647", th_seed=600, max_num_seeds=20, verbose=False)
     assert t20.shape == g["table_max20"].shape
+    if im.dtype == np.float32:   # no equal DoG heights in the float32 cases: the 20 brightest seeds are the same 20
+        assert_rows_close(t20, g["table_max20"])
+    else:                        # uint16 heights tie (NumPy's introsort order among equals is implementation-defined):
+        #                          every row must still be one of the full table's spots
+        from scipy.spatial import cKDTree
+        d, j = cKDTree(g["table"][:, 1:4]).query(t20[:, 1:4])
+        assert d.max() < 0.05, d.max()
+
+
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "clu_f32"])
+def test_percentile_threshold_and_seed_mask_golden(name):
+    """Options that run host-side in the shim — the percentile threshold of get_seeds (spot_tools/fitting.py:75-76) and
+    fit_fov_image's seed_mask (:210-218) — against the reference's own outputs (tests/golden/seedopts.npz)."""
+    from conftest import seed_mask_for
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image, get_seeds
+    from imageanalysis3_amd import _lib as L
+    g = load_golden("seedopts.npz")
+    im = build_case(name)
+    for per in (95, 99.5, 98):
+        tag = "%s_per%s" % (name, str(per).replace(".", "p"))
+        got = get_seeds(im, use_percentile=True, th_seed_per=per, return_h=True)
+        assert np.array_equal(seed_set(got), seed_set(g[tag])), tag
+        got = get_seeds(im, use_percentile=True, th_seed_per=per, use_dynamic_th=False, return_h=True)
+        assert np.array_equal(seed_set(got), seed_set(g[tag + "_nodyn"])), tag
+    got = get_seeds(im, use_percentile=True, th_seed_per=99.5, return_h=True, sel_center=[s // 2 for s in im.shape],
+                    seed_radius=25)
+    assert np.array_equal(seed_set(got), seed_set(g[name + "_per_sel"]))
+    t = fit_fov_image(im, "647", use_percentile=True, th_seed_per=99.5, max_num_seeds=None, verbose=False)
+    assert t.shape == g[name + "_per_table"].shape
+    assert_rows_close(t, g[name + "_per_table"])
+    with L.DeviceStack.upload(im) as st:   # the same through a resident stack (the percentile needs the host copy)
+        t = fit_fov_image(st, "647", use_percentile=True, th_seed_per=99.5, max_num_seeds=None, verbose=False)
+    assert_rows_close(t, g[name + "_per_table"])
+    mask = seed_mask_for(im.shape)
+    t = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, seed_mask=mask, verbose=False)
+    assert t.shape == g[name + "_mask_table"].shape
+    assert_rows_close(t, g[name + "_mask_table"])
+    seeds = load_golden("fit_%s.npz" % name)["seeds_h"]
+    t = fit_fov_image(im, "647", seeds=seeds, seed_mask=mask > 0, verbose=False)
+    assert t.shape == g[name + "_mask_given"].shape
+    assert_rows_close(t, g[name + "_mask_given"])
 
 
 def test_single_spot_known_answer():

@@ -49,6 +49,29 @@ def test_fit_tables_bit_exact(name):
     assert np.array_equal(O.fit_fov_image(im, "647", th_seed=600, max_num_seeds=20), g["table_max20"])
 
 
+@pytest.mark.parametrize("name", ["c1_f32", "c1_u16", "clu_f32"])
+def test_percentile_threshold_and_seed_mask_oracle_vs_reference_golden(name):
+    """get_seeds(use_percentile=True) (spot_tools/fitting.py:75-76: scipy's scoreatpercentile on the uncropped image) and
+    fit_fov_image(seed_mask=...) (:210-218) against the reference's own outputs."""
+    from conftest import seed_mask_for
+    g = load_golden("seedopts.npz")
+    im = build_case(name)
+    for per in (95, 99.5, 98):
+        tag = "%s_per%s" % (name, str(per).replace(".", "p"))
+        assert np.array_equal(O.get_seeds(im, use_percentile=True, th_seed_per=per, return_h=True), g[tag])
+        assert np.array_equal(O.get_seeds(im, use_percentile=True, th_seed_per=per, use_dynamic_th=False, return_h=True),
+                              g[tag + "_nodyn"])
+    assert np.array_equal(O.get_seeds(im, use_percentile=True, th_seed_per=99.5, return_h=True,
+                                      sel_center=[s // 2 for s in im.shape], seed_radius=25), g[name + "_per_sel"])
+    assert np.array_equal(O.fit_fov_image(im, "647", use_percentile=True, th_seed_per=99.5, max_num_seeds=None),
+                          g[name + "_per_table"])
+    mask = seed_mask_for(im.shape)
+    assert np.array_equal(O.fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, seed_mask=mask), g[name + "_mask_table"])
+    assert np.array_equal(O.fit_fov_image(im, "647", seeds=O.get_seeds(im, th_seed=600, return_h=True), seed_mask=mask > 0),
+                          g[name + "_mask_given"])
+    assert 0 < len(g[name + "_mask_table"]) < len(load_golden("fit_%s.npz" % name)["table"])   # the mask removes some
+
+
 def test_centers_and_sparse():
     g = load_golden("fit_c1_f32.npz")
     im = build_case("c1_f32")

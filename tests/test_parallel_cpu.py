@@ -73,3 +73,58 @@ def test_gather_spot_tables_gloo_world2(mode):
     expect = np.concatenate([t for _, _, tabs in res for t in tabs] + [np.zeros((0, 11), np.float32)], axis=0)
     for _, out, _ in res:
         assert out.shape == expect.shape and np.array_equal(out, expect)
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """`bench.py --gpus N` either starts N ranks itself or runs under a launcher that did: a WORLD_SIZE that disagrees
+    with --gpus, or --gpus 0, ends the run before any work is done (non-zero exit, message on stderr)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr, r.stderr[-400:]
+    env.pop("WORLD_SIZE")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus" in r.stderr
+
+
+def test_bench_launches_its_own_ranks(tmp_path, monkeypatch):
+    """Without a launcher `--gpus 2` goes through launch_ranks: child ranks are started with torch.distributed.run on
+    127.0.0.1 before the parent touches a GPU, rank 0's line is relayed, and a line that does not report 2 ranks is an
+    error.  (The children need GPUs; here the launcher command is replaced by a stub that plays rank 0.)"""
+    import subprocess
+    import sys
+    import json
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeProc(object):
+        def __init__(self, line):
+            self.stdout = iter(["rank chatter\n", line + "\n"])
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, stdout=None, env=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return FakeProc(seen["line"])
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    a = bench.parse()
+    seen["line"] = json.dumps({"metric": "m", "n_gpus": 2, "ms_per_step_by_rank": [1.0, 1.1]})
+    bench.launch_ranks(a)
+    cmd = seen["cmd"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen["line"] = json.dumps({"metric": "m", "n_gpus": 1, "ms_per_step_by_rank": [1.0]})
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(a)
