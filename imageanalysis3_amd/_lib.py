@@ -31,6 +31,7 @@ EXPORTS = [
     "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
     "ia3_stack_crop", "ia3_warp3d", "ia3_warp3d_dev",
+    "ia3_align_image_dev", "ia3_process_movies",
 ]
 
 
@@ -61,6 +62,44 @@ class FovJob(C.Structure):
     _fields_ = [("host", C.c_void_p), ("dev", C.c_void_p), ("rows", C.c_void_p), ("capacity", C.c_int),
                 ("n_rows", C.c_int), ("n_seeds", C.c_int), ("n_iter", C.c_int), ("rc", C.c_int),
                 ("fits", C.c_longlong), ("nfev", C.c_longlong), ("voxel_evals", C.c_longlong)]
+
+
+MOVIE_MAXCH = 8
+
+
+class MovieParams(C.Structure):
+    """ia3_movie_params (include/ia3.h)."""
+    _fields_ = [("frames", C.c_int), ("X", C.c_int), ("Y", C.c_int), ("Z", C.c_int),
+                ("n_load", C.c_int), ("load_start", C.c_int * MOVIE_MAXCH), ("load_step", C.c_int),
+                ("n_sel", C.c_int), ("sel", C.c_int * MOVIE_MAXCH),
+                ("hot_pixel_corr", C.c_int), ("hot_pixel_th", C.c_double), ("z_shift_corr", C.c_int),
+                ("n_bleed", C.c_int), ("bleed_idx", C.c_int * MOVIE_MAXCH),
+                ("bleed_profile", C.c_void_p), ("bleed_dtype", C.c_int),
+                ("illum_profile", C.c_void_p * MOVIE_MAXCH), ("illum_dtype", C.c_int * MOVIE_MAXCH),
+                ("drift_idx", C.c_int), ("ref_bead", C.c_void_p),
+                ("n_crops", C.c_int), ("crops", C.c_int * 48),
+                ("precision_fold", C.c_int), ("normalization", C.c_int), ("min_good_drifts", C.c_int),
+                ("drift_diff_th", C.c_double),
+                ("warp", C.c_int), ("warp_always", C.c_int * MOVIE_MAXCH),
+                ("chrom_field", C.c_void_p * MOVIE_MAXCH), ("chrom_dtype", C.c_int * MOVIE_MAXCH),
+                ("highpass_sigma", C.c_double), ("highpass_truncate", C.c_double),
+                ("fit_spots", C.c_int),
+                ("seed", SeedParams * MOVIE_MAXCH), ("fit", FitParams),
+                ("normalize", C.c_int), ("bg_crop_size", C.c_int), ("bg_edges", C.POINTER(C.c_double)),
+                ("bg_n_edges", C.c_int), ("bg_max_iter", C.c_int),
+                ("correct_threads", C.c_int), ("fit_group_images", C.c_int), ("upload_ahead", C.c_int)]
+
+
+class MovieJob(C.Structure):
+    """ia3_movie_job (include/ia3.h)."""
+    _fields_ = [("host_raw", C.c_void_p), ("path", C.c_char_p), ("offset_bytes", C.c_longlong), ("big_endian", C.c_int),
+                ("drift_in", C.c_double * 3), ("measure_drift", C.c_int),
+                ("images_out", C.c_void_p * MOVIE_MAXCH),
+                ("rows", C.c_void_p * MOVIE_MAXCH), ("capacity", C.c_int * MOVIE_MAXCH),
+                ("drift", C.c_double * 3), ("drift_flag", C.c_int),
+                ("n_rows", C.c_int * MOVIE_MAXCH), ("n_seeds", C.c_int * MOVIE_MAXCH), ("n_iter", C.c_int * MOVIE_MAXCH),
+                ("rc", C.c_int),
+                ("t_upload_ms", C.c_double), ("t_correct_ms", C.c_double), ("t_fit_ms", C.c_double)]
 
 
 _lib = None
@@ -322,3 +361,56 @@ def fit_fovs(ims, seed_params, fit_params, in_flight=4, capacity=16384):
     tables = [r[:j.n_rows].copy() for j, r in zip(jobs, rows)]
     info = [dict(n_seeds=j.n_seeds, n_iter=j.n_iter, fits=j.fits, nfev=j.nfev, voxel_evals=j.voxel_evals) for j in jobs]
     return tables, info
+
+
+def process_movies(params, movies, drifts_in=None, measure_drift=True, want_images=False, capacity=16384):
+    """``ia3_process_movies``: ``movies`` = raw (frames, X, Y) uint16 arrays and/or .dax paths (``(path, offset_bytes,
+    big_endian)`` tuples or plain strings), all of the layout ``params`` (a filled ``MovieParams``) describes.  Returns
+    one dict per movie: ``tables`` (list of (M,11) float32 per selected channel), ``drift``, ``drift_flag``, ``images``
+    (list of (Z,X,Y) uint16 or None), ``n_seeds``, ``n_iter``, ``ms`` (host wall time per stage).  ``drifts_in``: per movie
+    a drift to use (or start from); ``measure_drift``: bool or per-movie list."""
+    n = len(movies)
+    if n == 0:
+        return []
+    n_sel = int(params.n_sel)
+    Z, X, Y = int(params.Z), int(params.X), int(params.Y)
+    keep = []
+    while True:
+        jobs = (MovieJob * n)()
+        rows = [[np.empty((capacity, 11), dtype=np.float32) for _ in range(n_sel)] for _ in range(n)]
+        images = [[np.empty((Z, X, Y), dtype=np.uint16) if want_images else None for _ in range(n_sel)] for _ in range(n)]
+        for k, (j, m) in enumerate(zip(jobs, movies)):
+            if isinstance(m, np.ndarray):
+                if m.dtype != np.uint16 or m.ndim != 3 or tuple(m.shape) != (int(params.frames), X, Y):
+                    raise TypeError("the raw movie should be a (%d, %d, %d) uint16 array" % (int(params.frames), X, Y))
+                a = np.ascontiguousarray(m)
+                keep.append(a)
+                j.host_raw = a.ctypes.data
+            else:
+                path, off, big = (m, 0, False) if isinstance(m, (str, bytes)) else m
+                j.path = os.fsencode(path)
+                j.offset_bytes, j.big_endian = int(off), 1 if big else 0
+            md = measure_drift[k] if isinstance(measure_drift, (list, tuple)) else measure_drift
+            j.measure_drift = 1 if md else 0
+            if drifts_in is not None and drifts_in[k] is not None:
+                for a_ in range(3):
+                    j.drift_in[a_] = float(drifts_in[k][a_])
+            for s_ in range(n_sel):
+                j.rows[s_], j.capacity[s_] = rows[k][s_].ctypes.data, capacity
+                if want_images:
+                    j.images_out[s_] = images[k][s_].ctypes.data
+        rc = lib().ia3_process_movies(jobs, n, C.byref(params))
+        need = max(max(j.n_rows[s_] for s_ in range(n_sel)) for j in jobs)
+        if rc == IA3_ECAPACITY and need > capacity:
+            capacity = need
+            continue
+        check(rc)
+        break
+    out = []
+    for k, j in enumerate(jobs):
+        out.append(dict(tables=[rows[k][s_][:j.n_rows[s_]].copy() for s_ in range(n_sel)],
+                        drift=np.array([j.drift[0], j.drift[1], j.drift[2]]), drift_flag=int(j.drift_flag),
+                        images=images[k] if want_images else None,
+                        n_seeds=[int(j.n_seeds[s_]) for s_ in range(n_sel)], n_iter=[int(j.n_iter[s_]) for s_ in range(n_sel)],
+                        ms=dict(upload=j.t_upload_ms, correct=j.t_correct_ms, fit=j.t_fit_ms)))
+    return out

@@ -115,33 +115,77 @@ __global__ void hot_fix_u16f_k(uint16_t* __restrict__ im, int Z, int X, int Y, c
   }
 }
 
+// Columns with more than `th` votes, compacted on the device: the host used to download the whole vote plane (16.8 MB
+// for a 2048 x 2048 image) and scan it — 3-5 ms of host time per channel, four channels per movie.  ctl[0] = all hot
+// columns (border ones included: n_hot), ctl[1] = entries written to `list` (interior ones, flat index x * Y + y, in
+// no particular order; the host sorts them into np.where order).
+constexpr int HOT_CAP = 16384;
+__global__ __launch_bounds__(256) void hot_compact_k(const int* __restrict__ votes, int X, int Y, double th,
+                                                     int* __restrict__ ctl, int* __restrict__ list) {
+  const size_t n = (size_t)X * Y;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (!((double)votes[i] > th)) continue;
+    atomicAdd(&ctl[0], 1);
+    const int x = (int)(i / (size_t)Y), y = (int)(i % (size_t)Y);
+    if (x > 0 && y > 0 && x < X - 1 && y < Y - 1) {
+      const int k = atomicAdd(&ctl[1], 1);
+      if (k < HOT_CAP) list[k] = (int)i;
+    }
+  }
+}
+
 int hot_pixels_inplace(ia3_stack* s, double hot_pix_th, double hot_th, int float_arith, int* n_hot) {
   hipStream_t st = stream();
   const int dtype = s->dtype, Z = s->Z, X = s->X, Y = s->Y;
   const size_t plane = (size_t)X * Y;
+  if (plane > 0x7fffffffull) return set_error(IA3_EUNSUPPORTED, "hot pixels: plane of %d x %d exceeds 2^31 pixels", X, Y);
   if (float_arith && dtype != IA3_U16) float_arith = 0;   // a float32 stack already computes in float32
-  std::vector<int> votes(plane);
-  Scratch dv(plane * sizeof(int));
-  if (!dv.p) return IA3_ENOMEM;
+  Scratch dv(plane * sizeof(int)), dl((size_t)(2 + HOT_CAP) * sizeof(int));
+  if (!dv.p || !dl.p) return IA3_ENOMEM;
+  hipError_t e = hipMemsetAsync(dl.p, 0, 2 * sizeof(int), st);
+  if (e != hipSuccess) return set_error(IA3_EHIP, "memset failed: %s", hipGetErrorString(e));
   {
     ProfScope ps("hot_vote");
     dim3 g((unsigned)((Y + 63) / 64), (unsigned)((X + 3) / 4));
     if (dtype == IA3_F32) hipLaunchKernelGGL((hot_vote_k<float>), g, dim3(256), 0, st, (const float*)s->d, Z, X, Y, hot_th, dv.as<int>());
     else if (float_arith) hipLaunchKernelGGL(hot_vote_u16f_k, g, dim3(256), 0, st, (const uint16_t*)s->d, Z, X, Y, hot_th, dv.as<int>());
     else hipLaunchKernelGGL((hot_vote_k<uint16_t>), g, dim3(256), 0, st, (const uint16_t*)s->d, Z, X, Y, hot_th, dv.as<int>());
+    const double th = hot_pix_th * (double)Z;
+    hipLaunchKernelGGL(hot_compact_k, dim3(1024), dim3(256), 0, st, (const int*)dv.as<int>(), X, Y, th, dl.as<int>(), dl.as<int>() + 2);
   }
-  hipError_t e = hipMemcpyAsync(votes.data(), dv.p, plane * sizeof(int), hipMemcpyDeviceToHost, st);
+  IA3_KCHECK();
+  // the two counts, then the (few) entries: pinned mailbox words would save ~20 us more; this runs once per channel
+  int ctl[2] = {0, 0};
+  e = hipMemcpyAsync(ctl, dl.p, sizeof(ctl), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel vote failed: %s", hipGetErrorString(e));
-  std::vector<int> cand;  // np.where order: x ascending, then y
-  int total = 0;
-  const double th = hot_pix_th * (double)Z;
-  for (int x = 0; x < X; ++x)
-    for (int y = 0; y < Y; ++y)
-      if ((double)votes[(size_t)x * Y + y] > th) {
-        ++total;
-        if (x > 0 && y > 0 && x < X - 1 && y < Y - 1) { cand.push_back(x); cand.push_back(y); }
-      }
+  // np.where order: x ascending, then y.  (thread-local: the upload below reads it after this function has returned;
+  // the next call on this thread synchronises the stream before it touches the vector again)
+  static thread_local std::vector<int> cand;
+  cand.clear();
+  int total = ctl[0];
+  if (ctl[1] > HOT_CAP) {   // more interior hot columns than the device list holds: the whole vote plane, scanned here
+    std::vector<int> votes(plane);
+    e = hipMemcpyAsync(votes.data(), dv.p, plane * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel vote download failed: %s", hipGetErrorString(e));
+    const double th = hot_pix_th * (double)Z;
+    total = 0;
+    for (int x = 0; x < X; ++x)
+      for (int y = 0; y < Y; ++y)
+        if ((double)votes[(size_t)x * Y + y] > th) {
+          ++total;
+          if (x > 0 && y > 0 && x < X - 1 && y < Y - 1) { cand.push_back(x); cand.push_back(y); }
+        }
+  } else if (ctl[1] > 0) {
+    std::vector<int> flat((size_t)ctl[1]);
+    e = hipMemcpyAsync(flat.data(), dl.as<int>() + 2, flat.size() * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel list download failed: %s", hipGetErrorString(e));
+    std::sort(flat.begin(), flat.end());
+    cand.reserve(flat.size() * 2);
+    for (int i : flat) { cand.push_back(i / Y); cand.push_back(i % Y); }
+  }
   if (n_hot) *n_hot = total;
   if (cand.empty()) return IA3_OK;
   const int n = (int)(cand.size() / 2);
@@ -162,8 +206,7 @@ int hot_pixels_inplace(ia3_stack* s, double hot_pix_th, double hot_th, int float
     hipLaunchKernelGGL(hot_mark_k, dim3((n + 255) / 256), dim3(256), 0, st, dv.as<int>(), dc.as<int>(), n, Y);
     hipLaunchKernelGGL(hot_fix_u16f_k, dim3((Z + 63) / 64), dim3(64), 0, st, (uint16_t*)s->d, Z, X, Y, dc.as<int>(), n,
                        (const int*)dv.p, dr.as<float>());
-    e = hipStreamSynchronize(st);   // dr/dv go back to the pool after this scope
-    if (e != hipSuccess) return set_error(IA3_EHIP, "hot pixel fix failed: %s", hipGetErrorString(e));
+    // (dr / dv go back to the scratch cache when this scope ends; the cache orders their reuse behind this stream)
   }
   IA3_KCHECK();
   return IA3_OK;

@@ -1,6 +1,7 @@
 // Chained per-FOV spot calling on a resident stack: get_seeds -> firstfit -> repeatfit -> row filters
 // (spot_tools/fitting.py:169-237 fit_fov_image without the optional intensity normalisation).
 #include "ia3_rt.h"
+#include "ia3_pipe.h"
 #include <math.h>
 #include <time.h>
 #include <stdio.h>
@@ -20,7 +21,8 @@ using namespace ia3rt;
 // counters of the calling thread's last ia3_fit_fov_dev: fits run, model evaluations, voxel evaluations
 static thread_local long long t_last_stats[5] = {0, 0, 0, 0, 0};
 
-static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
+namespace ia3pipe {
+int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, int capacity, int* n_rows) {
   int m = 0;
   for (int i = 0; i < n; ++i) {
     const float* r = ps + (size_t)i * 11;
@@ -37,8 +39,8 @@ static int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_r
 }
 
 // seeds known on the host (count n; centres on the device or on the host)
-static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, const ia3_fit_params* fp, float* out_rows,
-                           int capacity, int* n_rows, int* n_iter) {
+int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, const ia3_fit_params* fp, float* out_rows,
+                    int capacity, int* n_rows, int* n_iter, long long* stats5) {
   ia3_fitter* f = nullptr;
   int rc;
   if (sd.on_device) {
@@ -56,7 +58,7 @@ static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, 
   rc = ia3_fit_run(f);
   const double t1 = dbg ? now() : 0;
   if (!rc) rc = ia3_fit_results_ex(f, ps.data(), nullptr, nullptr, n_iter);
-  if (!rc) ia3k::fit_host_counters(f, t_last_stats);
+  if (!rc) { ia3k::fit_host_counters(f, t_last_stats); if (stats5) memcpy(stats5, t_last_stats, sizeof(t_last_stats)); }
   const double t2 = dbg ? now() : 0;
   ia3_fit_destroy(f);
   if (rc) return rc;
@@ -64,6 +66,8 @@ static int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, 
   if (dbg) fprintf(stderr, "fit_known_seeds: create->run done %.1f us, results %.1f us, destroy+filter %.1f us\n", t1 - t0, t2 - t1, now() - t2);
   return rc;
 }
+}  // namespace ia3pipe
+using ia3pipe::filter_rows;
 
 extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, const ia3_fit_params* fp,
                                float* out_rows, int capacity, int* n_rows, int* n_seeds, int* n_iter) {
@@ -84,7 +88,7 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
   if (n_seeds) *n_seeds = n;
   if (n == 0) return IA3_OK;  // fitting.py:206-207
-  return fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter);
+  return ia3pipe::fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter, nullptr);
 }
 
 extern "C" int ia3_fit_fov_wait_share(int64_t* wait_cycles, int64_t* wave_cycles) {
@@ -114,8 +118,9 @@ struct Pool {
 };
 Pool* g_pool = nullptr;        // leaked on purpose: workers may outlive static destruction
 std::mutex g_pool_mu;
+}  // namespace
 
-void pool_run(int workers, const std::function<void()>& fn) {
+void ia3pipe::pool_run(int workers, const std::function<void()>& fn) {
   Pool* p;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -152,7 +157,7 @@ void pool_run(int workers, const std::function<void()>& fn) {
   std::unique_lock<std::mutex> lk(sync->mu);
   sync->cv.wait(lk, [&] { return sync->left == 0; });
 }
-}  // namespace
+using ia3pipe::pool_run;
 
 // A batch of independent FOVs from ONE caller thread.  The reference spreads its per-image tasks over an mp.Pool
 // (classes/field_of_view.py:1129-1142).  Here the batch runs as a two-stage pipeline over groups of `in_flight` images:
@@ -173,16 +178,17 @@ struct Slot {
   bool seeded = false, fitted = false;
 };
 
-int fit_group(ia3_fov_job* jobs, std::vector<std::unique_ptr<Slot>>& slots, int lo, int hi, const ia3_fit_params* fp,
-              std::vector<std::string>& errs) {
+}  // namespace
+
+void ia3pipe::fit_group_items(FitItem* items, int n_items, const ia3_fit_params* fp) {
   std::vector<int> members;
-  for (int k = lo; k < hi; ++k)
-    if (!jobs[k].rc && !slots[(size_t)k]->fitted && slots[(size_t)k]->n > 0) members.push_back(k);
-  if (members.empty()) return IA3_OK;
+  for (int k = 0; k < n_items; ++k)
+    if (!items[k].rc && items[k].n > 0) members.push_back(k);
+  if (members.empty()) return;
   std::vector<const ia3_stack*> ims;
   std::vector<const double*> seeds;
   std::vector<int> ns;
-  for (int k : members) { ims.push_back(slots[(size_t)k]->im); seeds.push_back(slots[(size_t)k]->sd.d_zxy); ns.push_back(slots[(size_t)k]->n); }
+  for (int k : members) { ims.push_back(items[k].im); seeds.push_back(items[k].d_zxy); ns.push_back(items[k].n); }
   ia3_fitter* f = nullptr;
   int rc = ia3k::fit_create_multi(ims.data(), seeds.data(), ns.data(), (int)members.size(), fp, &f);
   std::vector<float> ps;
@@ -199,17 +205,41 @@ int fit_group(ia3_fov_job* jobs, std::vector<std::unique_ptr<Slot>>& slots, int 
   if (!rc) {
     const int* st = ia3k::fit_fov_starts(f);
     for (size_t m = 0; m < members.size(); ++m) {
-      ia3_fov_job& j = jobs[members[m]];
+      FitItem& j = items[members[m]];
       j.n_iter = iters[m];
       j.fits = cnt[3 * m]; j.nfev = cnt[3 * m + 1]; j.voxel_evals = cnt[3 * m + 2];
       const int r = filter_rows(ims[m], ps.data() + (size_t)st[m] * 11, ns[m], j.rows, j.capacity, &j.n_rows);
-      if (r) { j.rc = r; errs[(size_t)members[m]] = ia3_last_error(); }
+      if (r) { j.rc = r; j.err = ia3_last_error(); }
     }
   } else {
     const std::string msg = ia3_last_error();
-    for (int k : members) { jobs[k].rc = rc; errs[(size_t)k] = msg; }
+    for (int k : members) { items[k].rc = rc; items[k].err = msg; }
   }
   ia3_fit_destroy(f);
+}
+
+namespace {
+int fit_group(ia3_fov_job* jobs, std::vector<std::unique_ptr<Slot>>& slots, int lo, int hi, const ia3_fit_params* fp,
+              std::vector<std::string>& errs) {
+  std::vector<ia3pipe::FitItem> items;
+  std::vector<int> who;
+  for (int k = lo; k < hi; ++k)
+    if (!jobs[k].rc && !slots[(size_t)k]->fitted && slots[(size_t)k]->n > 0) {
+      ia3pipe::FitItem it;
+      it.im = slots[(size_t)k]->im; it.d_zxy = slots[(size_t)k]->sd.d_zxy; it.n = slots[(size_t)k]->n;
+      it.rows = jobs[k].rows; it.capacity = jobs[k].capacity;
+      items.push_back(it);
+      who.push_back(k);
+    }
+  if (items.empty()) return IA3_OK;
+  ia3pipe::fit_group_items(items.data(), (int)items.size(), fp);
+  for (size_t m = 0; m < items.size(); ++m) {
+    ia3_fov_job& j = jobs[who[m]];
+    const ia3pipe::FitItem& it = items[m];
+    j.n_rows = it.n_rows; j.n_iter = it.n_iter;
+    j.fits = it.fits; j.nfev = it.nfev; j.voxel_evals = it.voxel_evals;
+    if (it.rc) { j.rc = it.rc; errs[(size_t)who[m]] = it.err; }
+  }
   return IA3_OK;
 }
 }  // namespace
@@ -289,7 +319,7 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
           s.n = s.sd.on_device ? s.sd.n : (int)(s.sd.host.zxyh.size() / 4);
           j.n_seeds = s.n;
           if (s.n > 0 && !s.sd.on_device) {   // the rare host-side seed finish (> 8192 candidates): fitted here, on its own
-            r = fit_known_seeds(s.im, s.sd, s.n, fp, j.rows, j.capacity, &j.n_rows, &j.n_iter);
+            r = ia3pipe::fit_known_seeds(s.im, s.sd, s.n, fp, j.rows, j.capacity, &j.n_rows, &j.n_iter, nullptr);
             if (!r) { j.fits = t_last_stats[0]; j.nfev = t_last_stats[1]; j.voxel_evals = t_last_stats[2]; }
             s.fitted = true;
           }

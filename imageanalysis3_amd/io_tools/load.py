@@ -527,3 +527,263 @@ def correct_fov_image(dax_filename, sel_channels,
     if return_drift:
         _return_args.extend([_drift, _drift_flag])
     return tuple(_return_args)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# many movies through one pipelined call (ia3_process_movies): correct_fov_image + fit_fov_image per selected channel
+# ---------------------------------------------------------------------------------------------------------------
+
+class MoviePlan(object):
+    """Everything that is the same for every movie of a run — channel layout, correction profiles and the reference bead
+    image resident in HBM, seeding / fitting parameters — as the ``ia3_movie_params`` that ``ia3_process_movies`` takes.
+
+    Arguments are those of ``correct_fov_image`` (io_tools/load.py:166-522) plus, as in
+    ``classes/batch_functions.py:60-302``: ``ref_image`` (the corrected reference bead image: ndarray, resident
+    ``DeviceStack`` or a .dax path that ``align_image`` would load), ``seed_th`` (threshold per selected channel),
+    ``fitting_args`` (the keyword arguments the caller would hand to ``fit_fov_image``) and ``fit_spots``.
+    ``run(movies, ...)`` then processes raw movies (ndarrays or .dax paths): uploads, corrections / drift / warps and group
+    fits of different movies overlap on library threads.  Results are those of the per-movie calls.
+
+    Raises ``NotImplementedError`` for options the pipelined entry does not cover (the caller then goes movie by movie):
+    bead-fitting drift (``use_autocorr=False``), ``warp_image=False``, ``normalization``, a non-uint16 output type, seeds /
+    seed masks / percentile thresholds in ``fitting_args``."""
+
+    def __init__(self, sel_channels, ref_image=None, single_im_size=None, all_channels=None,
+                 num_buffer_frames=10, num_empty_frames=0, calculate_drift=True, drift_channel='488',
+                 use_autocorr=True, drift_args={}, corr_channels=None, correction_folder=None, warp_image=True,
+                 hot_pixel_corr=True, hot_pixel_th=4, z_shift_corr=False,
+                 illumination_corr=True, illumination_profile=None, bleed_corr=True, bleed_profile=None,
+                 chromatic_ref_channel='647', chromatic_corr=True, chromatic_profile=None,
+                 gaussian_highpass=False, gauss_sigma=3, gauss_truncate=2, normalization=False, output_dtype=np.uint16,
+                 verbose=True, seed_th=None, fitting_args={}, fit_spots=True, frames=None,
+                 correct_threads=2, fit_group_images=12, upload_ahead=2):
+        from .. import _image_size, _allowed_colors, _corr_channels
+        from ..correction_tools.alignment import generate_drift_crops, DEFAULT_NORMALIZATION
+        single_im_size = _image_size if single_im_size is None else single_im_size
+        all_channels = _allowed_colors if all_channels is None else all_channels
+        corr_channels = _corr_channels if corr_channels is None else corr_channels
+        if isinstance(sel_channels, (str, int)):
+            sel_channels = [str(sel_channels)]
+        sel_channels = [str(ch) for ch in sel_channels]
+        single_im_size = np.array(single_im_size, dtype=int)
+        all_channels = [str(ch) for ch in all_channels]
+        num_buffer_frames, num_empty_frames = int(num_buffer_frames), int(num_empty_frames)
+        if normalization:
+            raise NotImplementedError("normalization=True is outside the accelerated path")
+        if np.dtype(output_dtype) != np.uint16:
+            raise NotImplementedError("output_dtype other than uint16 is outside the accelerated path")
+        if not warp_image:
+            raise NotImplementedError("warp_image=False (spot translation functions) goes movie by movie")
+        if calculate_drift and not use_autocorr:
+            raise NotImplementedError("bead-fitting drift (use_autocorr=False) goes movie by movie")
+        # channel bookkeeping exactly as correct_fov_image (:196-236)
+        corr_channels = [str(ch) for ch in sorted(corr_channels, key=lambda v: -int(v)) if str(ch) in all_channels]
+        _overlap_channels = [_ch for _ch in corr_channels if _ch in sel_channels]
+        _load_channels = [_ch for _ch in corr_channels] if (len(_overlap_channels) > 0 and bleed_corr) else []
+        for _ch in sel_channels:
+            if _ch not in _load_channels:
+                _load_channels.append(_ch)
+        _drift_channel = str(drift_channel)
+        if _drift_channel not in all_channels:
+            raise ValueError(f"Wrong input of drift_channel:{_drift_channel}, should be among {all_channels}")
+        if calculate_drift and _drift_channel not in _load_channels:
+            _load_channels.append(_drift_channel)
+        if len(_load_channels) > L.MOVIE_MAXCH:
+            raise NotImplementedError("more than %d channels per movie" % L.MOVIE_MAXCH)
+        Z, X, Y = (int(v) for v in single_im_size)
+        self.sel_channels, self.load_channels, self.shape = sel_channels, _load_channels, (Z, X, Y)
+        self._keep = []
+        p = L.MovieParams()
+        if frames is None:
+            frames = Z * len(all_channels) + 2 * num_buffer_frames + num_empty_frames
+        _num_color = (int(frames) - 2 * num_buffer_frames - num_empty_frames) / Z
+        if _num_color != int(_num_color):
+            raise ValueError("Wrong num_color, should be integer!")
+        _num_color = int(_num_color)
+        p.frames, p.X, p.Y, p.Z = int(frames), X, Y, Z
+        starts = _channel_starts(_load_channels, all_channels[:_num_color], num_buffer_frames, num_empty_frames)
+        p.n_load, p.load_step = len(_load_channels), _num_color
+        for _i, _s in enumerate(starts):
+            p.load_start[_i] = int(_s)
+        p.n_sel = len(sel_channels)
+        for _i, _ch in enumerate(sel_channels):
+            p.sel[_i] = _load_channels.index(_ch)
+        p.hot_pixel_corr, p.hot_pixel_th = (1 if hot_pixel_corr else 0), float(hot_pixel_th)
+        p.z_shift_corr = 1 if z_shift_corr else 0
+        # profiles (uploaded once, or handed over as DeviceBuffers)
+        if illumination_corr:
+            if illumination_profile is None:
+                illumination_profile = load_correction_profile('illumination', corr_channels=_load_channels,
+                                                               correction_folder=correction_folder, all_channels=all_channels,
+                                                               ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                               verbose=False)
+            if not isinstance(illumination_profile, dict):
+                raise TypeError("Wrong input type of illumination_profile, should be dict!")
+            for _i, _ch in enumerate(_load_channels):
+                if _ch not in illumination_profile:
+                    raise KeyError(f"channel:{_ch} not given in illumination_profile")
+                _ip = _as_buffer(illumination_profile[_ch])
+                if tuple(_ip.arr.shape) != (X, Y):
+                    raise IndexError(f"illumination profile shape {_ip.arr.shape} should be {(X, Y)}")
+                self._keep.append(_ip)
+                p.illum_profile[_i], p.illum_dtype[_i] = _ip.ptr.value, _ip.dtype_code
+        if bleed_corr and len(_overlap_channels) > 0:
+            if bleed_profile is None:
+                bleed_profile = load_correction_profile('bleedthrough', corr_channels=corr_channels,
+                                                        correction_folder=correction_folder, all_channels=all_channels,
+                                                        ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                        verbose=False)
+            if not isinstance(bleed_profile, DeviceBuffer):
+                bleed_profile = np.array(bleed_profile, dtype=np.float32)
+            _bp = _as_buffer(bleed_profile)
+            _nc = len(corr_channels)
+            if tuple(_bp.arr.shape) != (_nc, _nc, X, Y):
+                raise IndexError(f"Wrong input shape for bleed_profile: {_bp.arr.shape}, should be {(_nc, _nc, X, Y)}")
+            self._keep.append(_bp)
+            p.n_bleed = _nc
+            for _i, _ch in enumerate(corr_channels):
+                p.bleed_idx[_i] = _load_channels.index(_ch)
+            p.bleed_profile, p.bleed_dtype = _bp.ptr.value, _bp.dtype_code
+        _chromatic_channels = [_ch for _ch in corr_channels if _ch in sel_channels and _ch != chromatic_ref_channel]
+        if chromatic_corr and len(_overlap_channels) > 0:
+            if chromatic_profile is None:
+                chromatic_profile = load_correction_profile('chromatic', corr_channels=corr_channels,
+                                                            correction_folder=correction_folder, all_channels=all_channels,
+                                                            ref_channel=chromatic_ref_channel, im_size=single_im_size,
+                                                            verbose=False)
+            if not isinstance(chromatic_profile, dict):
+                raise TypeError("Wrong input type of chromatic_profile, should be dict!")
+            for _ch in _load_channels:
+                if _ch in corr_channels and _ch not in chromatic_profile:
+                    raise KeyError(f"channel:{_ch} not given in chromatic_profile")
+        # the reference resamples inside `if verbose:` (:434-453): a silent call returns unwarped images
+        p.warp = 1 if verbose else 0
+        for _i, _ch in enumerate(sel_channels):
+            _chrom = bool(chromatic_corr and _ch in _chromatic_channels)
+            p.warp_always[_i] = 1 if _chrom else 0
+            if _chrom and chromatic_profile[_ch] is not None:
+                _fb = _as_buffer(chromatic_profile[_ch])
+                if tuple(_fb.arr.shape) != (3, Z, X, Y):
+                    raise IndexError(f"chromatic_profile[{_ch}] shape {_fb.arr.shape} should be {(3, Z, X, Y)}")
+                self._keep.append(_fb)
+                p.chrom_field[_i], p.chrom_dtype[_i] = _fb.ptr.value, _fb.dtype_code
+        if gaussian_highpass:
+            p.highpass_sigma, p.highpass_truncate = float(gauss_sigma), float(gauss_truncate)
+        # drift
+        p.drift_idx = -1
+        self.measure_drift = bool(calculate_drift)
+        if calculate_drift:
+            p.drift_idx = _load_channels.index(_drift_channel)
+            _da = dict(drift_args)
+            for _k in ('all_channels', 'ref_all_channels', 'drift_channel', 'verbose', 'detailed_verbose', 'use_autocorr',
+                       'correction_args', 'match_distance_th', 'fitting_args'):
+                _da.pop(_k, None)
+            crop_list = _da.pop('crop_list', None)
+            if crop_list is None:
+                crop_list = generate_drift_crops(single_im_size)
+            crop_list = np.array(crop_list, dtype=int)
+            if crop_list.ndim != 3 or crop_list.shape[1:] != (3, 2) or len(crop_list) > 8:
+                raise IndexError("crop should be 3x2 np.ndarray.")
+            crop_list[:, :, 0] = np.maximum(crop_list[:, :, 0], 0)
+            crop_list[:, :, 1] = np.minimum(crop_list[:, :, 1], np.array([Z, X, Y])[None, :])
+            p.n_crops = len(crop_list)
+            for _i, _v in enumerate(crop_list.reshape(-1)):
+                p.crops[_i] = int(_v)
+            p.precision_fold = int(_da.pop('precision_fold', 100))
+            p.min_good_drifts = int(_da.pop('min_good_drifts', 3))
+            p.drift_diff_th = float(_da.pop('drift_diff_th', 1.))
+            p.normalization = 1 if DEFAULT_NORMALIZATION == "phase" else 0
+            if _da:
+                raise NotImplementedError("drift_args %s go movie by movie" % sorted(_da))
+            if isinstance(ref_image, str):
+                from ..correction_tools.alignment import align_image   # noqa: F401  (the loader it uses)
+                _corr = {'single_im_size': single_im_size, 'num_buffer_frames': num_buffer_frames,
+                         'num_empty_frames': num_empty_frames, 'hot_pixel_corr': True, 'z_shift_corr': False,
+                         'bleed_corr': False, 'chromatic_corr': False, 'normalization': False,
+                         'illumination_corr': bool(illumination_corr)}
+                if illumination_corr:
+                    _corr['illumination_profile'] = illumination_profile
+                ref_image = correct_fov_image(ref_image, [_drift_channel], all_channels=all_channels, calculate_drift=False,
+                                              return_drift=False, verbose=False, return_device=True, **_corr)[0][0]
+                self._keep.append(ref_image)
+            if isinstance(ref_image, np.ndarray):
+                if tuple(ref_image.shape) != (Z, X, Y):
+                    raise IndexError(f"shape of reference image:{ref_image.shape} should be {(Z, X, Y)}")
+                ref_image = L.DeviceStack.upload(ref_image if ref_image.dtype == np.uint16 else ref_image.astype(np.uint16))
+                self._keep.append(ref_image)
+            if not isinstance(ref_image, L.DeviceStack):
+                raise TypeError(f"ref_filename should be np.ndarray or string of path, but {type(ref_image)} is given")
+            if ref_image.dtype != np.uint16 or tuple(ref_image.shape) != (Z, X, Y):
+                raise TypeError("the resident reference bead stack must be uint16 of the image size")
+            self._keep.append(ref_image)
+            p.ref_bead = ref_image._h
+        # seeding + fitting (spot_tools/fitting.py:169-262 through classes/batch_functions.py:248-300)
+        p.fit_spots = 1 if fit_spots else 0
+        fa = dict(fitting_args)
+        for _k in ('seeds', 'seed_mask'):
+            if fa.get(_k, None) is not None:
+                raise NotImplementedError("fitting_args['%s'] goes movie by movie" % _k)
+            fa.pop(_k, None)
+        if fa.pop('use_percentile', False):
+            raise NotImplementedError("percentile thresholds go movie by movie")
+        fa.pop('th_seed_per', None)
+        fa.pop('th_seed', None)      # set per channel below, as the reference's loop does
+        fa.pop('verbose', None)
+        if not fa.pop('remove_boundary_points', True):
+            raise NotImplementedError("remove_boundary_points=False goes movie by movie")
+        seeding_kwargs = dict(fa.pop('seeding_kwargs', {}))
+        for _k in ('sel_center', 'use_percentile'):
+            if seeding_kwargs.pop(_k, None):
+                raise NotImplementedError("seeding_kwargs['%s'] goes movie by movie" % _k)
+        for _k in ('seed_radius', 'th_seed_per', 'return_h', 'verbose'):
+            seeding_kwargs.pop(_k, None)
+        seed_kw = dict(max_num_seeds=fa.pop('max_num_seeds', 500), use_dynamic_th=fa.pop('use_dynamic_th', True),
+                       dynamic_niters=fa.pop('dynamic_niters', 10), min_dynamic_seeds=fa.pop('min_dynamic_seeds', 1),
+                       remove_hot_pixel=fa.pop('remove_hot_pixel', True), **seeding_kwargs)
+        if seed_th is None:
+            seed_th = {}
+        for _i, _ch in enumerate(sel_channels):
+            _th = float(seed_th[_ch] if isinstance(seed_th, dict) else seed_th[_i]) if fit_spots else 300.
+            _sp, _k = L.make_seed_params(_th, **seed_kw)
+            self._keep.append(_k)
+            p.seed[_i] = _sp
+        fit_radius = int(fa.pop('fit_radius', 5))
+        p.fit = L.make_fit_params(radius_fit=fit_radius, **dict(fa.pop('fitting_args', {})))
+        normalize_background, normalize_local = fa.pop('normalize_background', False), fa.pop('normalize_local', False)
+        background_args = dict(fa.pop('background_args', {}))
+        if normalize_local or normalize_background:
+            background_args.pop('make_plot', None)
+            _dt = background_args.pop('dtype', _image_dtype)
+            edges = _background_edges(_dt if _dt is not None else np.uint16, background_args.pop('bin_size', 10))
+            self._keep.append(edges)
+            p.normalize = 2 if normalize_local else 1
+            p.bg_crop_size = fit_radius * 2
+            p.bg_edges, p.bg_n_edges = L.dptr(edges), len(edges)
+            p.bg_max_iter = int(background_args.pop('max_iter', 10))
+            if background_args:
+                raise NotImplementedError("background_args %s go movie by movie" % sorted(background_args))
+        if fa:
+            raise NotImplementedError("fitting_args %s go movie by movie" % sorted(fa))
+        p.correct_threads, p.fit_group_images, p.upload_ahead = int(correct_threads), int(fit_group_images), int(upload_ahead)
+        self.params = p
+
+    def run(self, movies, drifts_in=None, measure_drift=None, want_images=False, capacity=16384):
+        """``movies``: raw (frames, X, Y) uint16 arrays or .dax paths.  Per movie a dict: ``tables`` (one (M,11) float32
+        table per selected channel), ``drift``, ``drift_flag``, ``images`` (with ``want_images``), ``n_seeds``, ``n_iter``,
+        ``ms``.  ``drifts_in`` / ``measure_drift`` (bool or list): a known drift per movie instead of measuring it."""
+        items = []
+        for m in movies:
+            if isinstance(m, str):
+                n, w, h, big = _dax_info(m)
+                if (n, w, h) != (int(self.params.frames), self.shape[1], self.shape[2]):
+                    raise ValueError(f"{m}: movie of {(n, w, h)} does not have the planned layout "
+                                     f"{(int(self.params.frames), self.shape[1], self.shape[2])}")
+                items.append((m, 0, big))
+            else:
+                items.append(m)
+        if measure_drift is None:
+            measure_drift = self.measure_drift
+        if drifts_in is not None:   # the chain carries a given drift as float32 (io_tools/load.py:202-206)
+            drifts_in = [None if d is None else np.array(d, dtype=np.float32).astype(np.float64) for d in drifts_in]
+        return L.process_movies(self.params, items, drifts_in=drifts_in, measure_drift=measure_drift,
+                                want_images=want_images, capacity=capacity)

@@ -347,6 +347,16 @@ int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X,
                       int normalization, double* shift, double* err, double* phasediff);
 int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsample, int normalization,
                           double* shift, double* err, double* phasediff);
+/* correction_tools/alignment.py:527-695 align_image, phase-correlation path (use_autocorr=True), on resident stacks: crop
+ * after crop (crops: n_crops x 3 x 2 ints, [start, stop) per axis) skimage's phase_cross_correlation(ref crop, src crop,
+ * upsample); as soon as >= min_good_drifts crops are in and >= min_good_drifts of them lie within drift_diff_th of their
+ * mean, the mean of those is the drift (:664-674, flag 0); with no such agreement after the last crop, the mean of the
+ * two closest drifts and the one nearest to both (:676-693, flag 1).  drifts_out (n_crops x 3, may be NULL) / n_used: the
+ * per-crop drifts that were measured. */
+int ia3_align_image_dev(const ia3_stack* src, const ia3_stack* ref, const int* crops, int n_crops, int upsample,
+                        int normalization, int min_good_drifts, double drift_diff_th, double* drift, int* flag,
+                        double* drifts_out, int* n_used);
+
 /* ---- warp -------------------------------------------------------------------------------------
  * correction_tools/translate.py:5-31 warp_3d_image and its inlined twins (io_tools/load.py:438-453,
  * classes/preprocess.py:918-946): out = map_coordinates(im, grid (+ field) - drift, order, mode, cval).
@@ -361,6 +371,65 @@ int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_d
 
 /* new resident stack = s[z0:z1, x0:x1, y0:y1] (drift crops, correction_tools/alignment.py:617-622) */
 int ia3_stack_crop(const ia3_stack* s, int z0, int z1, int x0, int x1, int y0, int y1, ia3_stack** out);
+
+/* ---- whole round-folder movies: the per-image task of classes/batch_functions.py:60-302 batch_process_image_to_spots
+ * (fanned out over an mp.Pool by classes/field_of_view.py:1027-1142), as ONE pipelined call over many movies -------------
+ * Per movie: raw (frames, X, Y) uint16 movie from host memory or a .dax file -> split_im_by_channels
+ * (io_tools/load.py:524-550) -> hot pixels, z shift, bleedthrough, illumination (:323-384) -> bead drift against the
+ * resident reference bead stack (align_image, phase correlation) -> cubic warp with drift + dense chromatic field
+ * (:424-453) -> (Gaussian high-pass :489-498) -> get_seeds + firstfit + repeatfit + row filters of every selected channel
+ * (spot_tools/fitting.py:169-237) with that channel's seeding threshold.  Results are those of correct_fov_image followed
+ * by fit_fov_image movie by movie; what changes is the schedule: one library thread uploads movie k+1 while
+ * `correct_threads` others run the corrections, drift and warps of the movies before it on streams of their own and one
+ * more fits the channels of SEVERAL movies with one group fitter (fit_group_images images per group, see ia3_fit_fovs). */
+#define IA3_MOVIE_MAXCH 8
+typedef struct ia3_movie_params {
+  int frames, X, Y;                    /* raw movie */
+  int Z;                               /* planes per channel */
+  int n_load;                          /* channels taken out of the movie (<= IA3_MOVIE_MAXCH) */
+  int load_start[IA3_MOVIE_MAXCH];     /* first frame of each; frames start, start + load_step, ... */
+  int load_step;                       /* number of colours in the movie */
+  int n_sel;                           /* selected channels: corrected images / spot tables come back for these */
+  int sel[IA3_MOVIE_MAXCH];            /* index into the loaded channels */
+  int hot_pixel_corr; double hot_pixel_th;   /* io_tools/load.py:323-334 (hot_pix_th 0.5, float32 arithmetic) */
+  int z_shift_corr;                    /* :337-345 */
+  int n_bleed;                         /* :348-370: loaded channels mixed by the bleedthrough profile (0 = off) */
+  int bleed_idx[IA3_MOVIE_MAXCH];      /* ... in the profile's channel order */
+  const void* bleed_profile; int bleed_dtype;            /* device buffer (C,C,X,Y); 1 float32, 2 float64 */
+  const void* illum_profile[IA3_MOVIE_MAXCH]; int illum_dtype[IA3_MOVIE_MAXCH];   /* per loaded channel, NULL = none (:373-384) */
+  int drift_idx;                       /* loaded channel holding the beads; < 0: no drift measurement */
+  const ia3_stack* ref_bead;           /* corrected reference bead stack, resident */
+  int n_crops; int crops[8][3][2];     /* generate_drift_crops */
+  int precision_fold, normalization, min_good_drifts; double drift_diff_th;
+  int warp;                            /* 0: images are never resampled (warp_image=False, or a silent call: :434-436) */
+  int warp_always[IA3_MOVIE_MAXCH];    /* per SELECTED channel: 1 = a chromatic channel, resampled whatever the drift;
+                                          0 = resampled only when the drift is non-zero (:427) */
+  const void* chrom_field[IA3_MOVIE_MAXCH]; int chrom_dtype[IA3_MOVIE_MAXCH];     /* per SELECTED channel: (3,Z,X,Y) device buffer or NULL */
+  double highpass_sigma, highpass_truncate;   /* sigma <= 0: no high-pass */
+  int fit_spots;
+  ia3_seed_params seed[IA3_MOVIE_MAXCH];      /* per SELECTED channel (th_seed differs by channel, batch_functions.py:10-17) */
+  ia3_fit_params fit;
+  /* spot_tools/fitting.py:240-258: heights divided by the image's background level (1, normalize_background) or by the
+   * level of each spot's neighbourhood of +-crop_size (2, normalize_local); bg_edges / bg_max_iter as in
+   * ia3_find_background.  0 = heights as fitted. */
+  int normalize; int bg_crop_size; const double* bg_edges; int bg_n_edges; int bg_max_iter;
+  int correct_threads;                 /* <= 0: 2 */
+  int fit_group_images;                /* <= 0: 12 */
+  int upload_ahead;                    /* raw movies resident ahead of the corrections; <= 0: 2 */
+} ia3_movie_params;
+typedef struct ia3_movie_job {
+  const void* host_raw;                /* (frames, X, Y) uint16 in host memory, or NULL to read `path` */
+  const char* path; long long offset_bytes; int big_endian;
+  double drift_in[3]; int measure_drift;      /* measure_drift 0: drift_in is used as it is (flag 0) */
+  void* images_out[IA3_MOVIE_MAXCH];   /* per selected channel: host buffer for the corrected (Z,X,Y) uint16 image, or NULL */
+  float* rows[IA3_MOVIE_MAXCH]; int capacity[IA3_MOVIE_MAXCH];      /* per selected channel: capacity x 11 float32 */
+  /* out */
+  double drift[3]; int drift_flag;
+  int n_rows[IA3_MOVIE_MAXCH], n_seeds[IA3_MOVIE_MAXCH], n_iter[IA3_MOVIE_MAXCH];
+  int rc;
+  double t_upload_ms, t_correct_ms, t_fit_ms;   /* host wall time this movie spent in each stage */
+} ia3_movie_job;
+int ia3_process_movies(ia3_movie_job* jobs, int n_jobs, const ia3_movie_params* p);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,8 @@ def test_struct_layout_matches_header(tmp_path):
     import subprocess
     from imageanalysis3_amd import _lib
     pairs = [("ia3_seed_params", _lib.SeedParams), ("ia3_fit_params", _lib.FitParams),
-             ("ia3_legacy_seed_params", _lib.LegacySeedParams), ("ia3_fov_job", _lib.FovJob)]
+             ("ia3_legacy_seed_params", _lib.LegacySeedParams), ("ia3_fov_job", _lib.FovJob),
+             ("ia3_movie_params", _lib.MovieParams), ("ia3_movie_job", _lib.MovieJob)]
     lines = []
     for cname, ct in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
