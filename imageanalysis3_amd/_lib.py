@@ -99,7 +99,8 @@ class MovieJob(C.Structure):
                 ("drift", C.c_double * 3), ("drift_flag", C.c_int),
                 ("n_rows", C.c_int * MOVIE_MAXCH), ("n_seeds", C.c_int * MOVIE_MAXCH), ("n_iter", C.c_int * MOVIE_MAXCH),
                 ("rc", C.c_int),
-                ("t_upload_ms", C.c_double), ("t_correct_ms", C.c_double), ("t_fit_ms", C.c_double)]
+                ("t_upload_ms", C.c_double), ("t_correct_ms", C.c_double), ("t_fit_ms", C.c_double),
+                ("stamps", C.c_double * 6)]
 
 
 _lib = None
@@ -412,5 +413,6 @@ def process_movies(params, movies, drifts_in=None, measure_drift=True, want_imag
                         drift=np.array([j.drift[0], j.drift[1], j.drift[2]]), drift_flag=int(j.drift_flag),
                         images=images[k] if want_images else None,
                         n_seeds=[int(j.n_seeds[s_]) for s_ in range(n_sel)], n_iter=[int(j.n_iter[s_]) for s_ in range(n_sel)],
-                        ms=dict(upload=j.t_upload_ms, correct=j.t_correct_ms, fit=j.t_fit_ms)))
+                        ms=dict(upload=j.t_upload_ms, correct=j.t_correct_ms, fit=j.t_fit_ms),
+                        stamps=[float(v) for v in j.stamps]))
     return out

@@ -23,7 +23,7 @@ from . import _allowed_kwds, _max_num_seeds
 from .. import _image_dtype
 from .. import _lib as L
 from ..io_tools import h5lite
-from ..io_tools.load import correct_fov_image
+from ..io_tools.load import correct_fov_image, _dax_info
 from ..spot_tools.fitting import fit_fov_image, get_centers  # noqa: F401  (importable from here, as in the reference)
 
 # seeding threshold per channel (reference :10-17)
@@ -469,17 +469,124 @@ def batch_process_image_to_spots(dax_filename,
     return
 
 
-def batch_process_images_to_spots(args_list, num_threads=4, shared_kwargs=None):
+# the keyword arguments of batch_process_image_to_spots and their defaults, in positional order (reference :60-87)
+_BATCH_ARGS = ('dax_filename', 'sel_channels', 'save_filename', 'data_type', 'region_ids', 'ref_filename', 'load_file_lock',
+               'warp_image', 'correction_args', 'save_image', 'empty_value', 'fov_savefile_lock', 'overwrite_image',
+               'drift_args', 'save_drift', 'drift_filename', 'drift_file_lock', 'overwrite_drift', 'fit_spots', 'fit_in_mask',
+               'fitting_args', 'save_spots', 'spot_file_lock', 'overwrite_spot', 'verbose', 'return_spots', 'fit_workers')
+_BATCH_DEFAULTS = dict(load_file_lock=None, warp_image=True, correction_args={}, save_image=True, empty_value=0,
+                       fov_savefile_lock=None, overwrite_image=False, drift_args={}, save_drift=True, drift_filename=None,
+                       drift_file_lock=None, overwrite_drift=False, fit_spots=True, fit_in_mask=False, fitting_args={},
+                       save_spots=True, spot_file_lock=None, overwrite_spot=False, verbose=False, return_spots=False,
+                       fit_workers=None)
+
+
+def _plan_key(kw):
+    """Movies that can share one MoviePlan: same channels, same reference image and profile objects, same options."""
+    def ident(v):
+        if isinstance(v, dict):
+            return tuple(sorted((str(k), ident(x)) for k, x in v.items()))
+        if isinstance(v, (list, tuple)):
+            return tuple(ident(x) for x in v)
+        if isinstance(v, (str, int, float, bool, type(None))):
+            return v
+        if isinstance(v, np.ndarray) and v.size <= 64:
+            return (v.shape, v.dtype.str, v.tobytes())
+        return ('obj', id(v))   # profiles, reference image: shared by reference
+    return (tuple(str(c) for c in kw['sel_channels']), ident(kw['ref_filename']), bool(kw['warp_image']),
+            ident(kw['correction_args']), ident(kw['drift_args']), ident(kw['fitting_args']), bool(kw['verbose']),
+            bool(kw['save_image']), bool(kw['fit_spots']), kw['data_type'])
+
+
+def _pipelined_movies(tasks, chunk=8):
+    """``batch_process_image_to_spots`` for many movies through ``ia3_process_movies`` (io_tools.load.MoviePlan): movie k+1
+    is uploaded while the corrections, drift and warps of the movies before it run, and the channels of several movies
+    are fitted by one group fitter.  ``tasks``: full keyword dicts.  Returns {task index: return value} for the movies it
+    took; the rest — anything the pipelined entry does not cover, movies whose save file already holds some of their
+    images — is left to the per-movie path.  File contents are those of the per-movie path."""
+    from ..io_tools.load import MoviePlan
+    done = {}
+    groups = {}
+    for i, kw in enumerate(tasks):
+        try:
+            if kw['fit_in_mask'] or kw['fit_workers'] not in (None, 1) or not kw['warp_image']:
+                continue
+            _check_batch_arguments(kw['dax_filename'], kw['save_filename'], kw['ref_filename'], kw['sel_channels'], kw['region_ids'])
+            _require_type(kw['data_type'])
+        except Exception:
+            continue   # the per-movie call raises it in its own words
+        groups.setdefault((_plan_key(kw), _dax_info(kw['dax_filename'])[:3]), []).append(i)
+    for key, members in groups.items():
+        kw0 = tasks[members[0]]
+        channels = [str(c) for c in kw0['sel_channels']]
+        # ---- what the save file holds (reference :121-166): only movies none of whose images can be reused -----------
+        fresh, start, measure = [], {}, {}
+        for i in members:
+            kw = tasks[i]
+            rids = [int(r) for r in kw['region_ids']]
+            redo = kw['overwrite_image'] or kw['overwrite_drift']
+            usable, drifts = False, []
+            with _held(kw['fov_savefile_lock']), SaveFile(kw['save_filename'], kw['data_type']) as sf:
+                for rid in rids:
+                    slot = sf.row(rid)
+                    drifts.append(sf['drifts'][slot, :])
+                    if not redo and int(sf['flags'][slot]) - 1 == int(kw['warp_image']):
+                        im = sf['ims'][slot]
+                        usable = usable or bool(im.any() if kw['empty_value'] == 0 else (im != kw['empty_value']).any())
+            if usable:
+                continue
+            fresh.append(i)
+            start[i], measure[i] = _stored_drift(drifts, kw['overwrite_drift'])
+        if not fresh:
+            continue
+        try:
+            seed_th = {c: Channel_2_SeedTh[c] for c in channels} if kw0['fit_spots'] else None
+            # correct_fov_image(..., **correction_args, **drift_args) in the per-movie call (reference :178-186)
+            plan = MoviePlan(channels, ref_image=kw0['ref_filename'], calculate_drift=any(measure.values()),
+                             warp_image=True, verbose=kw0['verbose'], seed_th=seed_th, fitting_args=kw0['fitting_args'],
+                             fit_spots=kw0['fit_spots'], frames=_dax_info(kw0['dax_filename'])[0],
+                             **kw0['correction_args'], **kw0['drift_args'])
+        except (NotImplementedError, KeyError, TypeError):
+            continue
+        for c0 in range(0, len(fresh), chunk):
+            part = fresh[c0:c0 + chunk]
+            res = plan.run([tasks[i]['dax_filename'] for i in part], drifts_in=[start[i] for i in part],
+                           measure_drift=[measure[i] for i in part], want_images=kw0['save_image'])
+            for i, r in zip(part, res):
+                kw = tasks[i]
+                rids = [int(x) for x in kw['region_ids']]
+                drift = r['drift'] if measure[i] else np.array(start[i], dtype=np.float32)
+                if kw['save_image']:
+                    with _held(kw['fov_savefile_lock']):
+                        save_image_to_fov_file(kw['save_filename'], r['images'], kw['data_type'], rids, True, drift,
+                                               r['drift_flag'], kw['overwrite_image'], kw['verbose'])
+                spot_list, raw_spot_list = np.array([]), []
+                if kw['fit_spots']:
+                    # fit_fov_image returns np.array([]) for an image without seeds (spot_tools/fitting.py:206-207)
+                    raw_spot_list = [t if ns > 0 else np.array([]) for t, ns in zip(r['tables'], r['n_seeds'])]
+                    spot_list = [raw.copy() for raw in raw_spot_list]
+                    if kw['save_spots']:
+                        with _held(kw['spot_file_lock']):
+                            save_spots_to_fov_file(kw['save_filename'], spot_list, kw['data_type'], rids,
+                                                   raw_spot_list=raw_spot_list, overwrite=kw['overwrite_spot'],
+                                                   verbose=kw['verbose'])
+                done[i] = (spot_list, raw_spot_list) if kw['return_spots'] else None
+    return done
+
+
+def batch_process_images_to_spots(args_list, num_threads=4, shared_kwargs=None, pipeline=None):
     """The fan-out of ``Field_of_View._process_image_to_spots`` (classes/field_of_view.py:1015-1142) for one GPU.
 
     The reference starts ``mp.Pool(num_threads).starmap(batch_process_image_to_spots, args)`` with manager locks for
-    the save file; every task pickles its arguments (reference image and profiles included).  Here the tasks are
-    threads of the one process that owns the GPU: libia3 gives each thread its own HIP streams, so the corrections,
-    warps and fits of different movies overlap on the device, profiles / the reference bead image are shared by
-    reference (hand them over as ``DeviceBuffer`` / ndarray once), and a plain ``threading.RLock`` serialises the
-    save file.  ``args_list``: one dict of ``batch_process_image_to_spots`` keyword arguments per movie (or a tuple of
-    its positional arguments); ``shared_kwargs`` are added to each.  Returns the per-movie return values, in order.
-    Across GPUs: one such process per device over ``parallel.shard_fovs``."""
+    the save file; every task pickles its arguments (reference image and profiles included).  Here the movies go through
+    ONE pipelined library call (``ia3_process_movies``, see ``_pipelined_movies``): upload of the next movie, corrections /
+    drift / warps of the current ones and cross-movie group fits overlap on library threads, profiles and the reference
+    bead image are uploaded once.  Movies that entry does not cover (options outside it, save files that already hold
+    some of their images) — or all of them with ``pipeline=False`` — run as threads of this process, each with its own HIP
+    streams, a plain ``threading.RLock`` serialising the save file.  ``args_list``: one dict of
+    ``batch_process_image_to_spots`` keyword arguments per movie (or a tuple of its positional arguments);
+    ``shared_kwargs`` are added to each.  ``pipeline``: None = use it when there is more than one movie.  Returns the
+    per-movie return values, in order.  Across GPUs: one such process per device over ``parallel.shard_fovs``."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
     shared_kwargs = dict(shared_kwargs or {})
@@ -500,7 +607,32 @@ def batch_process_images_to_spots(args_list, num_threads=4, shared_kwargs=None):
                 kw[name] = dict(kw[name])
         return batch_process_image_to_spots(*pos, **kw)
 
-    if num_threads <= 1 or len(args_list) <= 1:
-        return [run(t) for t in args_list]
-    with ThreadPoolExecutor(max_workers=int(num_threads)) as pool:
-        return list(pool.map(run, args_list))
+    results = {}
+    use_pipeline = (len(args_list) > 1 and num_threads > 1) if pipeline is None else bool(pipeline)
+    if use_pipeline:
+        full = []
+        for task in args_list:
+            kw = dict(_BATCH_DEFAULTS)
+            kw.update(shared_kwargs)
+            if isinstance(task, dict):
+                kw.update(task)
+            else:
+                kw.update(dict(zip(_BATCH_ARGS, task)))
+            if kw.get('fov_savefile_lock') is None:
+                kw['fov_savefile_lock'] = file_lock
+            if kw.get('spot_file_lock') is None:
+                kw['spot_file_lock'] = file_lock
+            for name in ('fitting_args', 'correction_args', 'drift_args'):
+                kw[name] = dict(kw[name])
+            full.append(kw if all(k in kw for k in _BATCH_ARGS[:6]) else None)
+        if all(kw is not None for kw in full):
+            results = _pipelined_movies(full)
+    rest = [i for i in range(len(args_list)) if i not in results]
+    if num_threads <= 1 or len(rest) <= 1:
+        for i in rest:
+            results[i] = run(args_list[i])
+    else:
+        with ThreadPoolExecutor(max_workers=int(num_threads)) as pool:
+            for i, r in zip(rest, pool.map(run, [args_list[i] for i in rest])):
+                results[i] = r
+    return [results[i] for i in range(len(args_list))]

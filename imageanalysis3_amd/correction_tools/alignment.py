@@ -210,22 +210,42 @@ def align_image(
     _drifts = []
     _updated_mean_dft = None
     try:
-        for _i, _crop in enumerate(crop_list):
+        if use_autocorr:
+            # the crop loop, the phase correlations and the consensus rule in one library call (csrc/movie.cpp,
+            # ia3_align_image_dev: the same entry the movie pipeline uses); drifts of the crops it needed come back
+            _start_time = time.time()
+            _lims = np.array(crop_list, dtype=int).reshape(-1, 3, 2).copy()
+            _lims[:, :, 0] = np.maximum(_lims[:, :, 0], 0)
+            _lims[:, :, 1] = np.minimum(_lims[:, :, 1], np.array(_src.shape)[None, :])
+            _cl = np.ascontiguousarray(_lims, dtype=np.int32)
+            _out, _flag, _nused = (C.c_double * 3)(), C.c_int(0), C.c_int(0)
+            _each = np.zeros((len(_cl), 3), dtype=np.float64)
+            L.check(L.lib().ia3_align_image_dev(_src._h, _ref._h, _cl.ctypes.data_as(C.POINTER(C.c_int)), len(_cl),
+                                                int(precision_fold), 1 if DEFAULT_NORMALIZATION == "phase" else 0,
+                                                int(min_good_drifts), C.c_double(float(drift_diff_th)), _out,
+                                                C.byref(_flag), L.dptr(_each), C.byref(_nused)))
+            _drifts = [_each[_i].copy() for _i in range(_nused.value)]
+            if verbose:
+                for _i, _dft in enumerate(_drifts):
+                    print(f"-- drift {_i}: {np.around(_dft, 2)}")
+                print(f"-- {len(_drifts)} crops in {time.time()-_start_time:.3f}s.")
+            if _flag.value == 0:
+                _updated_mean_dft = np.array([_out[0], _out[1], _out[2]])
+                if verbose:
+                    print(f"--- crops agree within {drift_diff_th} px: done.")
+        for _i, _crop in enumerate(crop_list if not use_autocorr else []):
             _start_time = time.time()
             _lims = np.array(_crop, dtype=int)
             _sim, _rim = _src.crop(_lims), _ref.crop(_lims)
             try:
-                if use_autocorr:
-                    _dft, _error, _phasediff = phase_cross_correlation(_rim, _sim, upsample_factor=precision_fold)
-                else:
-                    _src_spots = fit_fov_image(_sim, drift_channel, verbose=detailed_verbose, **_fitting_args)
-                    _sp_src_cts = select_sparse_centers(_src_spots[:, 1:4], match_distance_th)
-                    _ref_spots = fit_fov_image(_rim, drift_channel, verbose=detailed_verbose, **_fitting_args)
-                    _sp_ref_cts = select_sparse_centers(_ref_spots[:, 1:4], match_distance_th, verbose=detailed_verbose)
-                    _dft, _paired_src_cts, _paired_ref_cts = align_beads(
-                        _sp_src_cts, _sp_ref_cts, _sim, _rim, use_fft=True, match_distance_th=match_distance_th,
-                        return_paired_cts=True, verbose=detailed_verbose)
-                    _dft = _dft * -1  # beads center is the opposite as cross correlation (:658)
+                _src_spots = fit_fov_image(_sim, drift_channel, verbose=detailed_verbose, **_fitting_args)
+                _sp_src_cts = select_sparse_centers(_src_spots[:, 1:4], match_distance_th)
+                _ref_spots = fit_fov_image(_rim, drift_channel, verbose=detailed_verbose, **_fitting_args)
+                _sp_ref_cts = select_sparse_centers(_ref_spots[:, 1:4], match_distance_th, verbose=detailed_verbose)
+                _dft, _paired_src_cts, _paired_ref_cts = align_beads(
+                    _sp_src_cts, _sp_ref_cts, _sim, _rim, use_fft=True, match_distance_th=match_distance_th,
+                    return_paired_cts=True, verbose=detailed_verbose)
+                _dft = _dft * -1  # beads center is the opposite as cross correlation (:658)
             finally:
                 _sim.free()
                 _rim.free()

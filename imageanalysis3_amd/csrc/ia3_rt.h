@@ -131,7 +131,7 @@ struct SeedOut {
   double th_used;
 };
 int dog_seed(const ia3_stack* im, const ia3_seed_params& p, SeedOut& out);
-// same, with the seed list left on the device when the device-side finish applies (<= 8192 candidates, stack no
+// same, with the seed list left on the device when the device-side finish applies (<= 32768 candidates, stack no
 // larger than 256 x 4096 x 4096): d_zxy = n x 3 float64 centres, d_h = n float64 heights inside `hold`; otherwise
 // on_device == false and `host` carries the list.
 struct SeedDev {

@@ -131,7 +131,7 @@ struct Image {                       // one selected channel of one movie, from 
   ia3_stack* st = nullptr;
   ia3k::SeedDev sd;
   int n = 0;
-  bool host_fitted = false;          // seeds came back on the host (> 8192 candidates): fitted by the corrector itself
+  bool host_fitted = false;          // seeds came back on the host (> 32768 candidates): fitted by the corrector itself
   std::atomic<int> users{0};         // the fit and the optional download; the last one frees the stack
 };
 
@@ -186,6 +186,7 @@ void uploader(Pipe& P) {
       else rc = set_error(IA3_EINVAL, "movie %d has neither a host array nor a file", k);
     }
     j.t_upload_ms = now_ms() - ta;
+    j.stamps[0] = ta - P.t0; j.stamps[1] = now_ms() - P.t0;
     if (rc) fail(P, k, rc);
     {
       std::lock_guard<std::mutex> lk(P.mu);
@@ -340,6 +341,7 @@ void corrector(Pipe& P) {
       // this thread's stream has produced the stacks and the seed lists; the fitter runs on another stream
       if (want_fit) { int r = stream_wait_spin(stream()); if (r) fail(P, k, r); }
       j.t_correct_ms = now_ms() - ta;
+      j.stamps[2] = ta - P.t0; j.stamps[3] = now_ms() - P.t0;
       if (want_fit) {
         std::lock_guard<std::mutex> lk(P.mu);
         for (Image* im : ims) P.fitq.push_back(im);
@@ -405,7 +407,9 @@ void fitter(Pipe& P) {
       }
     }
     for (Image* im : grp) {
-      P.jobs[im->movie].t_fit_ms += dt / (double)grp.size();
+      ia3_movie_job& j = P.jobs[im->movie];
+      j.t_fit_ms += dt / (double)grp.size();
+      j.stamps[4] = ta - P.t0; j.stamps[5] = ta + dt - P.t0;
       release(im);
     }
   }
@@ -450,6 +454,7 @@ extern "C" int ia3_process_movies(ia3_movie_job* jobs, int n_jobs, const ia3_mov
     j.rc = 0; j.drift_flag = 0;
     j.drift[0] = j.drift[1] = j.drift[2] = 0;
     j.t_upload_ms = j.t_correct_ms = j.t_fit_ms = 0;
+    for (int q = 0; q < 6; ++q) j.stamps[q] = 0;
     for (int s = 0; s < IA3_MOVIE_MAXCH; ++s) j.n_rows[s] = j.n_seeds[s] = j.n_iter[s] = 0;
     if (p->fit_spots)
       for (int s = 0; s < p->n_sel; ++s)

@@ -318,7 +318,7 @@ extern "C" int ia3_fit_fovs(ia3_fov_job* jobs, int n_jobs, int dtype, int Z, int
         if (!r) {
           s.n = s.sd.on_device ? s.sd.n : (int)(s.sd.host.zxyh.size() / 4);
           j.n_seeds = s.n;
-          if (s.n > 0 && !s.sd.on_device) {   // the rare host-side seed finish (> 8192 candidates): fitted here, on its own
+          if (s.n > 0 && !s.sd.on_device) {   // the rare host-side seed finish (> 32768 candidates): fitted here, on its own
             r = ia3pipe::fit_known_seeds(s.im, s.sd, s.n, fp, j.rows, j.capacity, &j.n_rows, &j.n_iter, nullptr);
             if (!r) { j.fits = t_last_stats[0]; j.nfev = t_last_stats[1]; j.voxel_evals = t_last_stats[2]; }
             s.fitted = true;

@@ -8,7 +8,7 @@
 // with enough seeds) needs no second sweep.  Candidates are sparse (~1e-5 of the voxels): a wave ballots its hits, one lane
 // reserves space with a single atomic and the hits are written by prefix rank (wavefront ballot + prefix-sum
 // compaction).  The rest (np.where order, hot-column vote, sort by height, truncation: fitting.py:131-150) runs on the
-// device too (fin_*_k) for up to 8192 candidates, on the host beyond.
+// device too (fin_*_k) for up to 32768 candidates, on the host beyond.
 //
 // Two forms of the detector.  Default (3x3x3 footprint, background radius 4..63): the background filter is evaluated
 // LAZILY — only its axis-0 pass on the whole stack, a block-minimum bound of min_im, candidates = local maxima of max_im
@@ -661,9 +661,10 @@ namespace {
 
 // ---- tail of get_seeds on the device (fitting.py:113-150) ---------------------------------------------------------
 // level pick, hot-column vote, sort by height and truncation for up to FIN_CAP candidates, as four small kernels
-// of all-pairs work (n <= 8192: at most 67 M comparisons spread over 256 blocks): no sort network, no hash table,
+// of all-pairs work (n = 5 000 ... 13 000 in production: 25 ... 170 M comparisons spread over 160 ... 400 blocks; blocks past
+// the last candidate leave at once): no sort network, no hash table,
 // and the seed list never leaves HBM between the detector and the fitter.
-constexpr unsigned FIN_CAP = 8192;
+constexpr unsigned FIN_CAP = 32768;   // (8192 until round 4: illumination-corrected production images leave ~13 k candidates at the lowest dynamic level)
 constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
 struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; unsigned done, pad[3]; };   // n_cand / overflow mirror SeedCtl: one read-back; done: blocks of fin_scatter_k that have stored their seeds
 
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(256) void fin_hot_k(const SeedCtl* __restrict__ sct
                                                  const FinCtl* __restrict__ fc, unsigned* __restrict__ hotcnt) {
   __shared__ int tx[256], ty[256];
   const unsigned n = fin_n(sctl);
+  if (blockIdx.x * 256 >= n) return;   // whole block
   const double th = lev.th[fc->chosen];
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   const bool mine = i < n && (double)c[i].h >= th;
@@ -722,6 +724,7 @@ __global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sc
                                                   unsigned* __restrict__ rank) {
   __shared__ unsigned long long tk[256];
   const unsigned n = fin_n(sctl);
+  if (blockIdx.x * 256 >= n) return;   // whole block
   const double th = lev.th[fc->chosen];
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   const bool alive = i < n && (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);

@@ -428,6 +428,7 @@ typedef struct ia3_movie_job {
   int n_rows[IA3_MOVIE_MAXCH], n_seeds[IA3_MOVIE_MAXCH], n_iter[IA3_MOVIE_MAXCH];
   int rc;
   double t_upload_ms, t_correct_ms, t_fit_ms;   /* host wall time this movie spent in each stage */
+  double stamps[6];   /* ms since the call began: upload begin / end, corrections begin / seeded, (last) group fit begin / end */
 } ia3_movie_job;
 int ia3_process_movies(ia3_movie_job* jobs, int n_jobs, const ia3_movie_params* p);
 

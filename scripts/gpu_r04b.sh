@@ -1,0 +1,7 @@
+#!/bin/bash
+set -e -o pipefail
+OUT=gpurun_out/r04b
+mkdir -p $OUT
+python -m pytest tests -m gpu -x -q -k "batch or chain or align or drift or hot or dax or movie or fork or correct_fov" > $OUT/pytest.log 2>&1 || { tail -60 $OUT/pytest.log; exit 1; }
+tail -3 $OUT/pytest.log
+timeout -k 10 600 python scripts/time_movies.py 12 $OUT/time_movies.json 2>&1 | tee $OUT/time_movies.log

@@ -1296,9 +1296,11 @@ def test_profiles_read_from_correction_folder(tmp_path):
     assert np.array_equal(ims[0], q.im_750) and np.array_equal(ims[1], q.im_561) and not np.array_equal(ims[0], ims2[0])
 
 
-def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path):
-    """Several movies of one FOV processed by a thread pool into one save file: same file content as one after the
-    other (and as the reference's single-movie fixture for the ids they share)."""
+def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path, monkeypatch):
+    """Several movies of one FOV into one save file, three ways: one after the other (the per-movie entry), through the
+    pipelined library call (ia3_process_movies: upload | corrections + drift + warps | cross-movie group fits) and as a
+    pool of host threads — same file content every time (and the reference's single-movie fixture for the ids they
+    share)."""
     import contextlib, io
     from conftest import batch_inputs, write_dax
     from imageanalysis3_amd.classes import batch_functions as B
@@ -1316,7 +1318,12 @@ def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path):
         ids.append([10 + 2 * r, 11 + 2 * r])
     all_ids = [i for pair in ids for i in pair]
 
-    def run(path, threads, stored_drift=True, ref=ref_im):
+    from imageanalysis3_amd import _lib as L
+    calls = []
+    real = L.process_movies
+    monkeypatch.setattr(L, "process_movies", lambda *a, **k: (calls.append(len(a[1])), real(*a, **k))[1])
+
+    def run(path, threads, stored_drift=True, ref=ref_im, pipeline=None):
         B.create_fov_save_file(path, 'unique', all_ids, ['750', '647'] * 4, size, max_num_seeds=4)
         if stored_drift:
             with H.File(path, "a", libver="latest") as f:
@@ -1325,15 +1332,20 @@ def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path):
         shared = dict(save_filename=path, data_type='unique', ref_filename=ref, warp_image=True,
                       correction_args=dict(corr), fitting_args=dict(fit), verbose=True)
         with contextlib.redirect_stdout(io.StringIO()):
-            out = B.batch_process_images_to_spots(args, num_threads=threads, shared_kwargs=shared)
+            out = B.batch_process_images_to_spots(args, num_threads=threads, shared_kwargs=shared, pipeline=pipeline)
         assert out == [None] * 4
         with H.File(path, "r") as f:
             return {k: f['unique'][k][...] for k in ('ims', 'spots', 'raw_spots', 'flags', 'drifts')}
 
     seq = run(str(tmp_path / "seq.hdf5"), 1)
+    assert calls == []
     par = run(str(tmp_path / "par.hdf5"), 4)
+    assert calls == [4]                                   # all four movies went through ONE pipelined call
+    thr = run(str(tmp_path / "thr.hdf5"), 4, pipeline=False)
+    assert calls == [4]
     for k in seq:
         assert np.array_equal(seq[k], par[k]), k
+        assert np.array_equal(seq[k], thr[k]), k
     assert (seq['flags'] == 2).all() and seq['spots'].any(axis=(1, 2)).all()
     # drift measured per movie (phase correlation of the bead channel against a reference bead image): every thread
     # runs its own FFT plans, results do not depend on the number of threads
@@ -1342,8 +1354,16 @@ def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path):
     bead_ref = np.roll(bead, (1, -2), axis=(1, 2))
     seq_d = run(str(tmp_path / "seq_d.hdf5"), 1, stored_drift=False, ref=bead_ref)
     par_d = run(str(tmp_path / "par_d.hdf5"), 4, stored_drift=False, ref=bead_ref)
+    thr_d = run(str(tmp_path / "thr_d.hdf5"), 4, stored_drift=False, ref=bead_ref, pipeline=False)
+    assert calls == [4, 4]
     for k in seq_d:
         assert np.array_equal(seq_d[k], par_d[k]), k
+        assert np.array_equal(seq_d[k], thr_d[k]), k
+    # a save file that already holds these movies' images: nothing for the pipelined entry to do, the per-movie rules apply
+    again = run(str(tmp_path / "par_d.hdf5"), 4, stored_drift=False, ref=bead_ref)
+    assert calls == [4, 4]
+    for k in seq_d:
+        assert np.array_equal(seq_d[k], again[k]), k
     assert np.abs(seq_d['drifts']).max() > 0.5 and (seq_d['drifts'] == seq_d['drifts'][0]).all()
     gold = load_golden("h5batch.npz")
     for r in range(4):   # every round holds the frames of the single-movie fixture
