@@ -751,7 +751,8 @@ __device__ __forceinline__ int gather_first(const FitArgs& fa, int i, IA3_LDS Ba
 constexpr int KDQ_CAP = 24;   // queue entries per lane (realistic fields need <= 5, a 4 600-seed blob of 6 px sigma 16)
 // Launched per field of view: `tree` is built from that field's seeds (its point indices are local: seed - seed0).
 __global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, int seed0, const int* __restrict__ tie_flag,
-                                                     unsigned long long* __restrict__ tie_lost, int* __restrict__ ctl_abort) {
+                                                     unsigned long long* __restrict__ tie_lost, int* __restrict__ ctl_abort,
+                                                     int qcap) {
   __shared__ KdQEntry heap[KDQ_CAP][64];
   const int i = seed0 + (int)blockIdx.x;
   if (i >= seed0 + tree.n || !tie_flag[i]) return;
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, in
       const int z = iz + o.dz, x = ix + o.dx, y = iy + o.dy;
       if (z >= 0 && z < fa.Z && x >= 0 && x < fa.X && y >= 0 && y < fa.Y) {
         const double q[3] = {(double)z, (double)x, (double)y};
-        KdQueue<IA3_LDS KdQEntry*> queue((IA3_LDS KdQEntry*)&heap[0][lane], 64, KDQ_CAP);
+        KdQueue<IA3_LDS KdQEntry*> queue((IA3_LDS KdQEntry*)&heap[0][lane], 64, qcap);
         const int w = kd_nearest(tree, q, 2.0 * fa.radius, queue);
         overflow |= queue.overflow;
         lose = w != i - seed0;
@@ -795,6 +796,8 @@ __global__ __launch_bounds__(64) void voronoi_ties_k(FitArgs fa, KdTree tree, in
     const unsigned long long m = __ballot(lose);
     if (lane == 0) tie_lost[(size_t)i * SLOTS + s] = m;
   }
+  // a query that ran out of queue entries: the host repeats the tie queries with the same tree and an unbounded queue
+  // (resolve_ties_host) before the fit is launched again
   if (__ballot(overflow) && lane == 0) atomicMax(ctl_abort, 3);
 }
 
@@ -944,6 +947,8 @@ struct StageCtl {
 };
 static_assert(sizeof(StageCtl) == 128 * (NCLAIM + 2), "one 128-byte line per counter");
 
+__device__ long long d_wait_bound = 1LL << 22;   // polls before a dependency wait gives up (IA3_DEBUG_FIT_WAITBOUND)
+
 // wave-uniform poll: every lane issues the (same-address) load, lane 0's value decides for the whole wave
 __device__ __forceinline__ bool wait_done(const int* done, int j, int need, StageCtl* ctl) {
   // An ordinary refit is over in tens of microseconds and its successor should notice at once; a wave that holds a later
@@ -961,7 +966,7 @@ __device__ __forceinline__ bool wait_done(const int* done, int j, int need, Stag
     ++spins;
     if ((spins & 15) == 0) {
       const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (spins > (1LL << 22) || ab) {   // 28 s of waiting: never expected
+      if (spins > d_wait_bound || ab) {   // 2^22 polls = 28 s of waiting: never expected
         __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -1274,6 +1279,7 @@ struct ia3_fitter {
   void *d_tie_flag, *d_tie_lost;   // per seed: has exact Voronoi ties (nbr_build_k) / lane masks of the tie voxels it loses
   void* kd_block;      // device copy of the seed trees (nodes | permutation per field), made only when ties exist
   bool ties_resolved;  // d_tie_lost is valid
+  bool ties_host = false;   // ... and was made on the host (a device query overflowed its queue)
   std::vector<double> host_seeds;   // n x 3 when the seeds came from (or were fetched to) the host
   std::vector<char> kd_stage;       // source of the asynchronous tree upload
   bool cached;         // host_stage holds [counters | n_iter | ctl | overflow | rows] of the finished fit (run_sweeps)
@@ -1296,6 +1302,7 @@ int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets
 int g_fit_maxfev = 0;   // IA3_DEBUG_FIT_MAXFEV: profiling only (splits the kernel time into a fixed and a per-evaluation part)
 int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the kernel's 256 registers allow two)
 int g_fit_merge = 1;    // IA3_TUNE_FIT_MERGE: sweeps after the first pair in one launch when few seeds are left (run_sweeps)
+int g_fit_kdq = KDQ_CAP;   // IA3_TUNE_FIT_KDQ: queue entries per voxel of the device tie queries
 
 FitArgs make_args(const ia3_fitter* f) {
   FitArgs a;
@@ -1521,6 +1528,13 @@ void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
 void set_fit_maxfev(int n) { g_fit_maxfev = n; }
 void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
 void set_fit_merge(int on) { g_fit_merge = on != 0; }
+int set_fit_waitbound(int polls) {
+  int rc = ia3rt::ensure_init(); if (rc) return rc;
+  const long long v = polls > 0 ? (long long)polls : (1LL << 22);
+  IA3_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_wait_bound), &v, sizeof(v)));
+  return IA3_OK;
+}
+void set_fit_kdq(int cap) { g_fit_kdq = cap < 1 ? 1 : (cap > KDQ_CAP ? KDQ_CAP : cap); }
 void fit_host_counters(const ia3_fitter* f, long long out[5]) {
   for (int k = 0; k < 5; ++k) out[k] = (long long)f->host_counters[k];
 }
@@ -1688,11 +1702,67 @@ static int resolve_ties(ia3_fitter* f) {
       b.t.data = (const double*)f->d_seeds + 3 * (size_t)s0;
       b.t.n = nk;
       hipLaunchKernelGGL(voronoi_ties_k, dim3((unsigned)nk), dim3(64), 0, st, a, b.t, s0, (const int*)f->d_tie_flag,
-                         (unsigned long long*)f->d_tie_lost, &((StageCtl*)f->d_ctl)->abort);
+                         (unsigned long long*)f->d_tie_lost, &((StageCtl*)f->d_ctl)->abort, g_fit_kdq);
     }
   }
   IA3_KCHECK();
   f->ties_resolved = true;
+  return IA3_OK;
+}
+
+// The same decisions on the host, for the case that a device query overflowed its queue (KDQ_CAP entries per voxel; never
+// seen on real fields): per field with ties the tree is still in f->kd_stage, every voxel of a flagged seed's ball asks
+// it through a queue as large as the tree, and a voxel is lost in a tie iff the tree answers with another seed that is
+// exactly as far away (voronoi_ties_k's rule: a strictly nearer seed is not a tie and is handled by the gather itself).
+static int resolve_ties_host(ia3_fitter* f) {
+  hipStream_t st = stream();
+  const int n = f->n, nf = (int)f->ims.size();
+  std::vector<int> flag((size_t)n), fov_ties((size_t)nf);
+  std::vector<int> ball((size_t)f->nball);
+  IA3_HIP(hipMemcpyAsync(flag.data(), f->d_tie_flag, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipMemcpyAsync(fov_ties.data(), f->d_fov_ties, sizeof(int) * (size_t)nf, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipMemcpyAsync(ball.data(), f->d_ball, sizeof(int) * (size_t)f->nball, hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
+  std::vector<unsigned long long> lost((size_t)n * SLOTS, 0ull);
+  auto d2 = [](const double* a, double z, double x, double y) {   // dist2_seq: separate multiplies and adds, in this order
+    const double d0 = a[0] - z, d1 = a[1] - x, d2_ = a[2] - y;
+    volatile double m0 = d0 * d0, m1 = d1 * d1, m2 = d2_ * d2_;
+    volatile double s01 = m0 + m1;
+    return (double)(s01 + m2);
+  };
+  const double r2x = 2.0 * (double)f->prm.radius_fit;
+  for (int k = 0; k < nf; ++k) {
+    const int s0 = f->fov_start[(size_t)k], nk = f->fov_start[(size_t)k + 1] - s0;
+    if (!fov_ties[(size_t)k] || nk == 0) continue;
+    std::vector<ia3::KdNode> nodes;
+    std::vector<int> perm;
+    KdTree t;
+    ia3k::kd_build(f->host_seeds.data() + 3 * (size_t)s0, nk, nodes, perm, t.mins, t.maxes);
+    t.nodes = nodes.data(); t.indices = perm.data(); t.data = f->host_seeds.data() + 3 * (size_t)s0; t.n = nk;
+    std::vector<KdQEntry> heap(nodes.size() + 2);
+    const ia3_stack* im = f->ims[(size_t)k];
+    for (int i = s0; i < s0 + nk; ++i) {
+      if (!flag[(size_t)i]) continue;
+      const double* c0 = f->host_seeds.data() + 3 * (size_t)i;
+      const int iz = (int)c0[0], ix = (int)c0[1], iy = (int)c0[2];
+      for (int vi = 0; vi < f->nball; ++vi) {
+        const int w_ = ball[(size_t)vi];
+        const int z = iz + (int)(signed char)(w_ & 0xff), x = ix + (int)(signed char)((w_ >> 8) & 0xff), y = iy + (int)(signed char)((w_ >> 16) & 0xff);
+        if (z < 0 || z >= im->Z || x < 0 || x >= im->X || y < 0 || y >= im->Y) continue;
+        const double q[3] = {(double)z, (double)x, (double)y};
+        KdQueue<KdQEntry*> queue(heap.data(), 1, (int)heap.size());
+        const int w = kd_nearest(t, q, r2x, queue);
+        if (queue.overflow) return set_error(IA3_EUNSUPPORTED, "Voronoi tie query exceeded the host queue");
+        if (w < 0 || w == i - s0) continue;
+        const double* cw = f->host_seeds.data() + 3 * (size_t)(s0 + w);
+        if (d2(cw, q[0], q[1], q[2]) == d2(c0, q[0], q[1], q[2])) lost[(size_t)i * SLOTS + (size_t)(vi / 64)] |= 1ull << (vi % 64);
+      }
+    }
+  }
+  f->kd_stage.assign((const char*)lost.data(), (const char*)lost.data() + lost.size() * sizeof(unsigned long long));
+  IA3_HIP(hipMemcpyAsync(f->d_tie_lost, f->kd_stage.data(), f->kd_stage.size(), hipMemcpyHostToDevice, st));
+  IA3_HIP(hipStreamSynchronize(st));   // kd_stage is reused; the upload is small
+  f->ties_host = true;
   return IA3_OK;
 }
 
@@ -1729,6 +1799,11 @@ static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
       rc = resolve_ties(f); if (rc) return rc;
       fresh = true;
       continue;   // the same stages again, now with the tie masks
+    }
+    if (hc.abort == 3 && f->ties_resolved && !f->ties_host) {
+      rc = resolve_ties_host(f); if (rc) return rc;
+      fresh = true;
+      continue;   // the same stages again, with the host's tie masks
     }
     rc = check_ctl(hc); if (rc) return rc;
     fresh = false;

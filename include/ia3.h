@@ -105,9 +105,18 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * fallback); 0 = two sweeps over whole lines; -1 = two sweeps and the one-output-per-thread gather.  Results are
  * identical bit for bit. */
 #define IA3_TUNE_WARP_ONEPASS 12
+/* IA3_TUNE_FIT_KDQ: entries of the per-voxel queue of the Voronoi tie queries on the device (1..24, default 24); a query
+ * that needs more is finished on the host with the same tree (tests lower it to drive fields through that path).  Tables
+ * are identical bit for bit. */
+#define IA3_TUNE_FIT_KDQ 13
 /* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
  * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */
 #define IA3_DEBUG_FIT_MAXFEV 100
+/* IA3_DEBUG_FIT_WAITBOUND: TESTS ONLY: polls after which a refit that waits for the fits it depends on gives up and the
+ * launch aborts with IA3_EHIP ("a dependency wait exceeded its bound"); <= 0 (default) = 2^22 polls (~28 s, never reached
+ * by a live kernel).  A small value makes ordinary waits of a crowded field trip it, which is how the abort path is
+ * exercised; the call fails, nothing else changes. */
+#define IA3_DEBUG_FIT_WAITBOUND 101
 int ia3_set_tuning(int key, int value);
 
 /* ---- device-resident stacks ----------------------------------------------------------------- */

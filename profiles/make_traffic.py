@@ -11,7 +11,7 @@ def short(name):
 SCOPE = {"gauss_axis0_folded<float, 50, 30, 3>": "gauss_axis0_pair", "gauss_xy_short<float, 3>": "gauss_xy_R3",
          "blockmin_k<float, 32, 4>": "seed_blockmin", "stripbound_k": "seed_blockmin", "seed_cand3_tiled<float, 64, 32>": "seed_detect",
          "seed_cand3_tiled<float, 32, 32>": "seed_detect",
-         "bg_sparse_k<float>": "seed_sparse_bg", "fit_stages_k": "fit_first"}
+         "bg_sparse_k<float>": "seed_sparse_bg", "bg_sparse3_k<float, 30>": "seed_sparse_bg", "fit_stages_k": "fit_first"}
 
 
 def main(folder):

@@ -293,6 +293,51 @@ def test_clustered_field_vs_oracle_and_reference():
         assert relg.max() <= 1e-4, (name, relg.max())
 
 
+def test_voronoi_tie_query_overflow_is_finished_on_the_host():
+    """A device tie query that runs out of queue entries (24 per voxel; never seen on real fields) no longer fails the
+    call: the host repeats the tie queries with the same tree and an unbounded queue.  IA3_TUNE_FIT_KDQ = 1 makes
+    nearly every query of the crowded goldens overflow: tables identical to the default run, bit for bit."""
+    import ctypes as C
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    from imageanalysis3_amd.External.Fitting_v4 import iter_fit_seed_points
+    for name in ("clu_f32", "club_f32"):
+        g = load_golden("fit_%s.npz" % name)
+        im = build_case(name)
+        ref = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+        try:
+            L.check(L.lib().ia3_set_tuning(C.c_int(13), C.c_int(1)))
+            got = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+            f = iter_fit_seed_points(im, g["seeds_h"][:, :3].T, radius_fit=5)
+            f.firstfit()
+            assert np.array_equal(f.nvox, g["first_nvox"]), name       # the Voronoi cells are the reference's
+        finally:
+            L.check(L.lib().ia3_set_tuning(C.c_int(13), C.c_int(24)))
+        assert np.array_equal(got, ref), name
+        assert got.shape == g["table"].shape
+
+
+def test_dependency_wait_abort_is_reported_and_the_library_recovers():
+    """The refit sweeps wait for the fits they depend on with a bound (2^22 polls, ~28 s) behind which the launch gives up
+    instead of hanging the device.  IA3_DEBUG_FIT_WAITBOUND lowers it to a few polls, so that an ordinary wait in a
+    crowded field trips it: the call fails with the library's error (no table), and the next call — bound restored —
+    returns the golden table."""
+    import ctypes as C
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    g = load_golden("fit_club_f32.npz")
+    im = build_case("club_f32")
+    try:
+        L.check(L.lib().ia3_set_tuning(C.c_int(101), C.c_int(16)))
+        with pytest.raises(L.IA3Error, match="dependency wait exceeded its bound"):
+            fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    finally:
+        L.check(L.lib().ia3_set_tuning(C.c_int(101), C.c_int(0)))
+    t = fit_fov_image(im, "647", th_seed=600, max_num_seeds=None, verbose=False)
+    assert t.shape == g["table"].shape
+    assert_rows_close(t, g["table"])
+
+
 def test_gauss_seidel_order_mid_size_exact():
     """333 seeds in 16 territories (218 overlapping pairs, 6 sweeps): the dependency-ordered kernel must reproduce
     the sequential reference order exactly — same n_iter, float32-identical rows — and do so on every run."""
@@ -850,71 +895,66 @@ def test_correct_fov_image_translation_functions():
     assert np.array_equal(funcs[1](spots), gf["drift_only"])          # 647 (reference channel): drift only
 
 
-# ---- DaxProcesser step API (classes/preprocess.py:337-1260) -----------------------------------------------------
+# ---- the step driver's operator sequence (classes/preprocess.py:337-1260), replayed flat ---------------------------
 @pytest.mark.parametrize("tag,rescale,illum64", [("a", True, False), ("b", False, True)])
 def test_daxprocesser_steps_golden_bit_exact(tag, rescale, illum64, tmp_path):
+    """The fixtures are the reference's step driver run on a synthetic movie; what they pin is the operator sequence with
+    that driver's arithmetic (tests/harness/replay.py): every step bit-exact (CRC + sampled voxels)."""
     from conftest import build_chain_case, write_dax
-    from harness.dax_processer import DaxProcesser
+    from harness import replay as R
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    from imageanalysis3_amd.correction_tools.alignment import align_image
     case = build_chain_case()
     g = load_golden("daxp.npz")
     chs = case["chs"]
     path = str(tmp_path / "movie.dax")
     write_dax(path, case["raw"])
+    st = R.load_channels(path, chs, chs, [case["Z"], case["X"], case["Y"]], n_buffer=case["nb"])
 
     def check(step, channels):
         for c in channels:
-            im = getattr(p, "im_" + c)
+            im = st[c].download()
             key = "%s_%s_%s" % (tag, step, c)
             idx, vals = g[key + "_smp"]
             assert im.dtype == np.uint16
             assert np.array_equal(im.reshape(-1)[idx], vals.astype(np.uint16)), (key, "sampled voxels differ")
             assert crc(im) == g[key + "_crc"], key
 
-    p = DaxProcesser(path, Channels=chs, DriftChannel='488', verbose=False)
-    assert p.drift_channel == '488' and not hasattr(p, "im_750")
-    p._load_image(ImSize=[case["Z"], case["X"], case["Y"]], NbufferFrame=case["nb"])
-    assert p.loaded_channels == chs and tuple(p.image_size) == (case["Z"], case["X"], case["Y"])
-    p._corr_hot_pixels_3D()
-    check("hot", chs)
-    p._corr_bleedthrough(correction_pf=case["bleed"], rescale=rescale)
-    check("bleed", chs[:3])
-    illum = {k: (a.astype(np.float64) if illum64 else a) for k, a in case["illum"].items()}
-    p._corr_illumination(correction_pf=illum, rescale=rescale)
-    check("illum", chs)
-    p._warp_image(drift=np.array(case["drift"]), chromatic_pf=case["chrom"])
-    check("warp", chs)
-    assert all(p.correction_log[c].get('corr_drift') for c in chs) and p.correction_log['750'].get('corr_chromatic')
-    p._corr_illumination(correction_pf=illum)       # logged as done: a second call is a no-op
-    check("warp", chs)
-    if tag == "a":
-        p._gaussian_highpass(correction_channels=['750'])
-        check("highpass", ['750'])
-        p._fit_spots(fit_channels=['647', '561'], th_seed=300)
-        for c in ('647', '561'):
-            ref = g["a_spots_%s" % c]
-            got = getattr(p, "spots_" + c)
-            # seeds sit 3-4 voxels apart here: exact Voronoi ties exist; the library resolves them by cKDTree's layout
-            # as the reference does.
-            import np_oracle as O
-            orc = O.fit_fov_image(getattr(p, "im_" + c), c, th_seed=300, max_num_seeds=None)
-            ia, ib = match_rows(got, orc)
-            rel = np.abs(got[ia][:, :8] - orc[ib][:, :8]) / np.maximum(np.abs(orc[ib][:, :8]), 1e-3)
-            # one fit of this noisy rescaled field runs into maxfev = 1000 without converging (MINPACK warns about it in the
-            # oracle too); where such a fit stops depends on the last bits of every step, and the seeds coupled to it through
-            # the refit sweeps inherit the difference: that group is held to 3e-2 (the non-converged row itself moves by
-            # ~1 % between MINPACK's QR and the kernel's Cholesky with Newton-refined pivots), everything else to 1e-5
-            assert (rel.max(1) > 1e-5).sum() <= 3 and rel.max() < 3e-2, rel.max(1)
-            ia, ib = match_rows(got, ref)
-            np.testing.assert_allclose(got[ia][:, :8], ref[ib][:, :8], rtol=1e-2, atol=1e-3)
-            assert np.array_equal(getattr(p, "spots_cell_ids_" + c), np.zeros(len(ref), np.int32))
-        # drift against itself: flag 0, zeros; against a shifted copy of the bead channel through align_image
-        assert p._calculate_drift(path, DriftChannel='488', save_attr=False) == (pytest.approx(np.zeros(3)), 0)
-        assert p._save_to_hdf5() is None and p._load_from_hdf5() is None   # empty in the reference too (:1155-1164)
-    # assigning an image uploads it; deleting frees it
-    p.im_561 = np.zeros((case["Z"], case["X"], case["Y"]), np.uint16)
-    assert p.im_561.sum() == 0
-    del p.im_561
-    assert not hasattr(p, "im_561")
+    try:
+        R.hot_pixels_in_image_dtype(st, chs)
+        check("hot", chs)
+        R.bleedthrough_rescaled(st, chs[:3], case["bleed"], rescale)     # the bead channel is not part of the mix
+        check("bleed", chs[:3])
+        illum = {k: (a.astype(np.float64) if illum64 else a) for k, a in case["illum"].items()}
+        R.illumination_rescaled(st, chs, illum, rescale)
+        check("illum", chs)
+        # the signal channels get drift + chromatic field (none for the reference channel), the bead channel the drift only
+        R.warp_drift_then_field(st, chs, np.array(case["drift"]), {c: case["chrom"].get(c) for c in chs[:3]})
+        check("warp", chs)
+        if tag == "a":
+            R.highpass(st, ['750'])
+            check("highpass", ['750'])
+            for c in ('647', '561'):
+                ref = g["a_spots_%s" % c]
+                got = fit_fov_image(st[c], c, th_seed=300, max_num_seeds=None, verbose=False)
+                # seeds sit 3-4 voxels apart here: exact Voronoi ties exist; the library resolves them by cKDTree's layout
+                # as the reference does.
+                import np_oracle as O
+                orc = O.fit_fov_image(st[c].download(), c, th_seed=300, max_num_seeds=None)
+                ia, ib = match_rows(got, orc)
+                rel = np.abs(got[ia][:, :8] - orc[ib][:, :8]) / np.maximum(np.abs(orc[ib][:, :8]), 1e-3)
+                # one fit of this noisy rescaled field runs into maxfev = 1000 without converging (MINPACK warns about it in
+                # the oracle too); where such a fit stops depends on the last bits of every step, and the seeds coupled to it
+                # through the refit sweeps inherit the difference: that group is held to 3e-2 (the non-converged row itself
+                # moves by ~1 % between MINPACK's QR and the kernel's Cholesky with Newton-refined pivots), the rest to 1e-5
+                assert (rel.max(1) > 1e-5).sum() <= 3 and rel.max() < 3e-2, rel.max(1)
+                ia, ib = match_rows(got, ref)
+                np.testing.assert_allclose(got[ia][:, :8], ref[ib][:, :8], rtol=1e-2, atol=1e-3)
+            # drift of the bead channel against itself through align_image: zeros, flag 0
+            d, f = align_image(st['488'], st['488'], drift_channel='488', all_channels=chs, verbose=False)
+            assert f == 0 and np.abs(d).max() == 0
+    finally:
+        R.free_all(st)
 
 
 def test_fit_fov_images_concurrent_equals_sequential():
@@ -1197,33 +1237,32 @@ def test_batch_process_image_to_spots_golden(tag, warp, tmp_path):
 
 
 def test_daxprocesser_fit_spots_by_segmentation_golden(tmp_path):
-    """classes/preprocess.py:1093-1153 against the reference's own run: per-label crops (with and without a drift),
-    kept spots and their labels; a label whose box holds no seed contributes nothing."""
-    import contextlib, io
+    """classes/preprocess.py:1093-1153 against the reference's own run, as a flat replay: per-label crops (with and
+    without a drift) cut on the device, fit_fov_image on each, kept spots and their labels; a label whose box holds no
+    seed contributes nothing."""
     from conftest import seg_labels, build_chain_case, write_dax
-    from harness.dax_processer import DaxProcesser
-    from harness.cell import segmentation_mask_2_bounding_box
+    from harness import replay as R
     g = load_golden("seg.npz")
     case = build_chain_case()
     size = [case["Z"], case["X"], case["Y"]]
     lab = seg_labels(size)
     assert (zlib.crc32(np.ascontiguousarray(lab).tobytes()) & 0xFFFFFFFF) == int(g["lab_crc"])
-    box = segmentation_mask_2_bounding_box(lab == 2, 3)        # 3 is taken as cell_id (absent): margin stays 1
     zz, xx, yy = np.where(lab == 2)
-    assert box.array.tolist() == [[max(zz.min() - 1, 0), min(zz.max() + 2, size[0])], [xx.min() - 1, xx.max() + 2],
-                                  [yy.min() - 1, yy.max() + 2]]
+    assert R.label_box(lab == 2).tolist() == [[max(zz.min() - 1, 0), min(zz.max() + 2, size[0])], [xx.min() - 1, xx.max() + 2],
+                                              [yy.min() - 1, yy.max() + 2]]
     path = str(tmp_path / "movie.dax")
     write_dax(path, case["raw"])
-    p = DaxProcesser(path, Channels=case["chs"], DriftChannel='488', verbose=False)
-    with contextlib.redirect_stdout(io.StringIO()):
-        p._load_image(ImSize=size, NbufferFrame=case["nb"])
-        p._corr_hot_pixels_3D()
-        assert p._fit_spots_by_segmentation('647', lab, th_seed=300, segment_search_radius=3) is None
-        p.drift = np.array(case["drift"])
-        s750, i750 = p._fit_spots_by_segmentation('750', lab, th_seed=300, num_spots=2, save_attrs=False)
-        s561, i561 = p._fit_spots_by_segmentation('561', (lab == 4) * 4, th_seed=300, save_attrs=False)
-    assert np.array_equal(p.spots_cell_ids_647, g["ids_647"]) and p.spots_cell_ids_647.dtype == np.int32
-    assert_rows_close(np.asarray(p.spots_647), g["spots_647"])
+    st = R.load_channels(path, case["chs"], case["chs"], size, n_buffer=case["nb"])
+    try:
+        R.hot_pixels_in_image_dtype(st, case["chs"])
+        s647, i647 = R.fit_in_labels(st['647'], '647', lab, np.zeros(3), th_seed=300, search_radius=3)
+        drift = np.array(case["drift"])
+        s750, i750 = R.fit_in_labels(st['750'], '750', lab, drift, th_seed=300, num_spots=2)
+        s561, i561 = R.fit_in_labels(st['561'], '561', (lab == 4) * 4, drift, th_seed=300)
+    finally:
+        R.free_all(st)
+    assert np.array_equal(i647, g["ids_647"]) and i647.dtype == np.int32
+    assert_rows_close(np.asarray(s647), g["spots_647"])
     assert np.array_equal(i750, g["ids_750"])
     assert_rows_close(np.asarray(s750), g["spots_750"])
     assert len(s561) == 0 and len(i561) == 0 and g["spots_561"].shape == (0,)
@@ -1231,18 +1270,19 @@ def test_daxprocesser_fit_spots_by_segmentation_golden(tmp_path):
 
 def test_profiles_read_from_correction_folder(tmp_path):
     """Profiles left as None are read from the correction folder under the reference's file names
-    (io_tools/load.py:239-281, :553-640): same images as with the profiles handed over; DaxProcesser steps and
-    batch_process_image_quick (classes/preprocess.py:1257-1278) take the same route."""
-    import contextlib, io, pickle
+    (io_tools/load.py:239-281, :553-640): same images as with the profiles handed over; the step driver's operator
+    sequence with profiles read the same way reproduces its fixture."""
+    import contextlib, io
     from conftest import build_chain_case, chain_kwargs, write_dax
-    from imageanalysis3_amd.io_tools.load import correct_fov_image
-    from harness.dax_processer import DaxProcesser, batch_process_image_quick
+    from imageanalysis3_amd.io_tools.load import correct_fov_image, load_correction_profile
+    from harness import replay as R
     case = build_chain_case()
     g = load_golden("chain.npz")
     Z, X, Y = case["Z"], case["X"], case["Y"]
+    chs = case["chs"]
     folder = str(tmp_path / "corr")
     os.makedirs(folder)
-    for c in case["chs"]:
+    for c in chs:
         np.save(os.path.join(folder, "illumination_correction_%s_%dx%d.npy" % (c, X, Y)), case["illum"][c])
     np.save(os.path.join(folder, "bleedthrough_correction_750_647_561_%d_%d.npy" % (X, Y)), case["bleed"].reshape(-1))
     for c in ('750', '561'):
@@ -1258,42 +1298,22 @@ def test_profiles_read_from_correction_folder(tmp_path):
         assert np.array_equal(im, g["full_%s" % ch]), ch
     with pytest.raises(FileNotFoundError):
         correct_fov_image(path, sel, correction_folder=str(tmp_path), **kw)
-    # DaxProcesser: profiles from its CorrectionFolder
+    # the step driver's sequence with every profile read from the folder
     d = load_golden("daxp.npz")
-    p = DaxProcesser(path, CorrectionFolder=folder, Channels=case["chs"], DriftChannel='488', verbose=False)
-    p._load_image(ImSize=[Z, X, Y], NbufferFrame=case["nb"])
-    p._corr_hot_pixels_3D()
-    p._corr_bleedthrough(rescale=True)
-    p._corr_illumination(rescale=True)
-    p._warp_image(drift=np.array(case["drift"]))
-    for c in case["chs"]:
-        assert (zlib.crc32(np.ascontiguousarray(getattr(p, "im_" + c)).tobytes()) & 0xFFFFFFFF) == int(d["a_warp_%s_crc" % c]), c
-    # the quick wrapper: load + hot pixels + illumination on a movie whose .xml / .inf describe it (no buffer frames)
-    from imageanalysis3_amd import synth
-    z2, x2 = 6, 32
-    ims2 = [synth.make_fov((z2, x2, x2), 3, 70 + i, dtype=np.uint16, margin=(1, 5, 5))[0] for i in range(4)]
-    raw2 = np.zeros((4 * z2, x2, x2), np.uint16)
-    for i in range(4):
-        raw2[i::4] = ims2[i]
-    path2 = str(tmp_path / "quick.dax")
-    write_dax(path2, raw2)
-    with open(path2[:-4] + ".inf", "w") as f:   # `key = value` lines only: _LoadInfFile (:1197-1205) splits every line
-        f.write("frame dimensions = %d x %d\nnumber of frames = %d\nframe size = %d\n" % (x2, x2, 4 * z2, x2 * x2))
-    with open(path2[:-4] + ".xml", "w") as f:
-        f.write("<settings><illumination><shutters>shutters/shutter_750_647_561_488_s%d.xml</shutters></illumination></settings>" % z2)
-    rng = np.random.RandomState(3)
-    for c in case["chs"]:
-        np.save(os.path.join(folder, "illumination_correction_%s_%dx%d.npy" % (c, x2, x2)), (0.5 + 0.5 * rng.rand(x2, x2)).astype(np.float32))
-    with contextlib.redirect_stdout(io.StringIO()):
-        ims = batch_process_image_quick(path2, folder, ['750', '561'], verbose=False)
-        q = DaxProcesser(path2, folder, Channels=None, DriftChannel='488', DapiChannel='405', verbose=False)
-        assert list(q.channels) == case["chs"]
-        q._load_image(sel_channels=['750', '561'])
-        assert np.array_equal(q.im_750, ims2[0]) and np.array_equal(q.im_561, ims2[2])
-        q._corr_hot_pixels_3D(correction_channels=['750', '561'])
-        q._corr_illumination(correction_channels=['750', '561'])
-    assert len(ims) == 2 and ims[0].dtype == np.uint16
-    assert np.array_equal(ims[0], q.im_750) and np.array_equal(ims[1], q.im_561) and not np.array_equal(ims[0], ims2[0])
+    common = dict(correction_folder=folder, all_channels=chs, im_size=[Z, X, Y])
+    bleed = load_correction_profile('bleedthrough', chs[:3], ref_channel=chs[0], **common)
+    illum = load_correction_profile('illumination', chs, ref_channel=chs[0], **common)
+    chrom = load_correction_profile('chromatic', chs[:3], ref_channel='647', **common)
+    st = R.load_channels(path, chs, chs, [Z, X, Y], n_buffer=case["nb"])
+    try:
+        R.hot_pixels_in_image_dtype(st, chs)
+        R.bleedthrough_rescaled(st, chs[:3], bleed, True)
+        R.illumination_rescaled(st, chs, illum, True)
+        R.warp_drift_then_field(st, chs, np.array(case["drift"]), chrom)
+        for c in chs:
+            assert (zlib.crc32(np.ascontiguousarray(st[c].download()).tobytes()) & 0xFFFFFFFF) == int(d["a_warp_%s_crc" % c]), c
+    finally:
+        R.free_all(st)
 
 
 def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path, monkeypatch):

@@ -215,39 +215,14 @@ with h5py.File(sys.argv[1], "a", libver="latest") as f:
     assert list(g0['flags']) == [2, 1, 2] and np.array_equal(g0['extra'], np.arange(5))
 
 
-def test_segmentation_helpers_host_side(tmp_path):
-    """Label lookup around spots (classes/partition_spots.py:113-140, :212-236), the mask bounding box
-    (segmentation_tools/cell.py:598-611) and DaxProcesser's label / stage-position readers (:1184-1255)."""
-    import pickle as pk
-    from harness.partition_spots import Spots_Partition, find_coordinate_intensities
-    from harness.dax_processer import DaxProcesser
-    from imageanalysis3_amd.classes.preprocess import Spots3D
-    from harness.cell import segmentation_mask_2_bounding_box
+def test_segmentation_replay_helpers_host_side():
+    """Host-side pieces of the segmentation-driven fit replay (tests/harness/replay.py): the label vote around a spot
+    (classes/partition_spots.py:113-140 semantics) and the label's bounding box (segmentation_tools/cell.py:598-611)."""
+    from harness import replay as R
     lab = np.zeros((6, 20, 20), np.int32)
     lab[:, 2:8, 2:8] = 1
     lab[:, 10:18, 9:16] = 7
-    rows = np.zeros((4, 11), np.float32)
-    rows[:, 1:4] = [[3, 4.4, 5.6], [2, 13, 12], [0, 19, 0], [5, 8.6, 8.4]]
-    sp = Spots3D(rows)
-    sig = find_coordinate_intensities(lab, sp, search_radius=1)
-    assert sig.shape == (4, 27) and (sig[0] == 1).all() and (sig[1] == 7).all() and (sig[2] == 0).all()
-    assert list(Spots_Partition.spots_to_labels(lab, sp, search_radius=1, verbose=False)) == [1, 7, -1, 7]
-    assert list(Spots_Partition.spots_to_DAPI(lab, sp, search_radius=1, verbose=False)) == [1, 7, 0, 7]
-    assert segmentation_mask_2_bounding_box(lab, 7, 2).array.tolist() == [[0, 6], [8, 20], [7, 18]]
-    assert segmentation_mask_2_bounding_box(lab > 0).array.tolist() == [[0, 6], [1, 19], [1, 17]]
-    # readers
-    np.save(str(tmp_path / "seg.npy"), lab)
-    pk.dump(lab, open(str(tmp_path / "seg.pkl"), "wb"))
-    with H.File(str(tmp_path / "seg.hdf5"), "w") as f:
-        f.create_group("12").create_dataset("dna_mask", data=lab)
-        f.create_group("13").create_dataset("dna_mask", data=lab * 2)
-    for name in ("seg.npy", "seg.pkl", "seg.hdf5"):
-        assert np.array_equal(DaxProcesser._LoadSegmentation(str(tmp_path / name), verbose=False), lab)
-    assert np.array_equal(DaxProcesser._LoadSegmentation(str(tmp_path / "seg.hdf5"), fov_id=13, verbose=False), lab * 2)
-    with pytest.raises(ValueError):
-        DaxProcesser._LoadSegmentation(str(tmp_path / "none.npy"))
-    with open(str(tmp_path / "m.xml"), "w") as f:
-        f.write("<settings><acquisition><stage_position>-1203.5,88.25</stage_position></acquisition></settings>")
-    assert list(DaxProcesser._FindGlobalPosition(str(tmp_path / "m.dax"))) == [-1203.5, 88.25]
-    with pytest.raises(ValueError):
-        DaxProcesser._FindGlobalPosition(str(tmp_path / "other.dax"))
+    centres = np.array([[3, 4.4, 5.6], [2, 13, 12], [0, 19, 0], [5, 8.6, 8.4]])
+    assert list(R.labels_around(lab, centres, 1)) == [1, 7, -1, 7]
+    assert R.label_box(lab == 7, 2).tolist() == [[0, 6], [8, 20], [7, 18]]
+    assert R.label_box(lab > 0).tolist() == [[0, 6], [1, 19], [1, 17]]
