@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libia3.so")
+LIB_PATH = os.environ.get("IA3_LIB_PATH") or os.path.join(_HERE, "libia3.so")   # IA3_LIB_PATH: developer builds (scripts/ab_*)
 
 IA3_U16, IA3_F32 = 0, 1
 IA3_OK, IA3_EINVAL, IA3_EHIP, IA3_ENOMEM, IA3_ECAPACITY, IA3_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -31,7 +31,7 @@ EXPORTS = [
     "ia3_gaussfit_voxels",
     "ia3_fftalign_2d", "ia3_fft3d_from2d", "ia3_fft3d_from2d_dev", "ia3_phase_xcorr3d", "ia3_phase_xcorr3d_dev",
     "ia3_stack_crop", "ia3_warp3d", "ia3_warp3d_dev",
-    "ia3_align_image_dev", "ia3_process_movies",
+    "ia3_align_image_dev", "ia3_process_movies", "ia3_drift_ref_create", "ia3_drift_ref_free", "ia3_align_image_ref",
 ]
 
 
@@ -76,7 +76,7 @@ class MovieParams(C.Structure):
                 ("n_bleed", C.c_int), ("bleed_idx", C.c_int * MOVIE_MAXCH),
                 ("bleed_profile", C.c_void_p), ("bleed_dtype", C.c_int),
                 ("illum_profile", C.c_void_p * MOVIE_MAXCH), ("illum_dtype", C.c_int * MOVIE_MAXCH),
-                ("drift_idx", C.c_int), ("ref_bead", C.c_void_p),
+                ("drift_idx", C.c_int), ("ref_bead", C.c_void_p), ("drift_ref", C.c_void_p),
                 ("n_crops", C.c_int), ("crops", C.c_int * 48),
                 ("precision_fold", C.c_int), ("normalization", C.c_int), ("min_good_drifts", C.c_int),
                 ("drift_diff_th", C.c_double),
@@ -123,6 +123,7 @@ def lib():
         L.ia3_stream.restype = C.c_void_p
         L.ia3_stack_free.restype = None
         L.ia3_fit_destroy.restype = None
+        L.ia3_drift_ref_free.restype = None
         _lib = L
     return _lib
 

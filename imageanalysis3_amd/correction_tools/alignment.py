@@ -68,6 +68,44 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, no
     return np.array([shift[0], shift[1], shift[2]]), float(err.value), float(ph.value)
 
 
+class DriftReference(object):
+    """The reference bead image of a run with the half spectra of its drift crops kept on the device
+    (``ia3_drift_ref``): every image of a run is aligned to the same reference (classes/batch_functions.py:169-206), so
+    its transforms are made once.  Hand it to ``align_image`` as ``ref_im``; drifts are those of the plain image.
+    ``ref_im``: (Z,X,Y) ndarray or resident ``DeviceStack``; ``crop_list``: as for ``align_image`` (default:
+    ``generate_drift_crops`` of the image size)."""
+
+    def __init__(self, ref_im, crop_list=None, dtype=np.uint16):
+        self._own = not isinstance(ref_im, L.DeviceStack)
+        if self._own and not isinstance(ref_im, np.ndarray):
+            raise IOError(f"Wrong input file type, {type(ref_im)} should be np.ndarray or a resident stack")
+        self.stack = L.DeviceStack.upload(ref_im if ref_im.dtype == np.dtype(dtype) else ref_im.astype(dtype)) if self._own else ref_im
+        self.shape, self.dtype = tuple(self.stack.shape), self.stack.dtype
+        if crop_list is None:
+            crop_list = generate_drift_crops(self.shape)
+        lims = np.array(crop_list, dtype=int).reshape(-1, 3, 2).copy()
+        lims[:, :, 0] = np.maximum(lims[:, :, 0], 0)
+        lims[:, :, 1] = np.minimum(lims[:, :, 1], np.array(self.shape)[None, :])
+        self.crops = np.ascontiguousarray(lims, dtype=np.int32)
+        h = C.c_void_p()
+        L.check(L.lib().ia3_drift_ref_create(self.stack._h, self.crops.ctypes.data_as(C.POINTER(C.c_int)), len(self.crops),
+                                             C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None) is not None:
+            L.lib().ia3_drift_ref_free(self._h)
+            self._h = None
+            if self._own:
+                self.stack.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def align_beads(tar_cts, ref_cts,
                 tar_im=None, ref_im=None,
                 use_fft=True, fft_filt_size=0,
@@ -182,6 +220,14 @@ def align_image(
         src_im = _load(src_im, _all_channels0)
     if isinstance(ref_im, str):
         ref_im = _load(ref_im, _ref_all_channels0)
+    _dref = ref_im if isinstance(ref_im, DriftReference) else None   # reference crop spectra kept on the device
+    if _dref is not None:
+        if not use_autocorr:
+            raise ValueError("a DriftReference holds phase-correlation spectra: use_autocorr=True")
+        if crop_list is not None and not np.array_equal(np.array(crop_list, dtype=int).reshape(-1, 3, 2), _dref.crops):
+            raise ValueError("crop_list differs from the crops the DriftReference was made for")
+        crop_list = _dref.crops
+        ref_im = _dref.stack
     _ok = (np.ndarray, L.DeviceStack)   # a DeviceStack (e.g. from correct_fov_image(return_device=True)) skips the upload
     if not isinstance(src_im, _ok) or not isinstance(ref_im, _ok):
         raise IOError(f"Wrong input file type, {type(src_im)} / {type(ref_im)} should be .dax file or np.ndarray")
@@ -220,10 +266,16 @@ def align_image(
             _cl = np.ascontiguousarray(_lims, dtype=np.int32)
             _out, _flag, _nused = (C.c_double * 3)(), C.c_int(0), C.c_int(0)
             _each = np.zeros((len(_cl), 3), dtype=np.float64)
-            L.check(L.lib().ia3_align_image_dev(_src._h, _ref._h, _cl.ctypes.data_as(C.POINTER(C.c_int)), len(_cl),
-                                                int(precision_fold), 1 if DEFAULT_NORMALIZATION == "phase" else 0,
-                                                int(min_good_drifts), C.c_double(float(drift_diff_th)), _out,
-                                                C.byref(_flag), L.dptr(_each), C.byref(_nused)))
+            if _dref is not None:
+                L.check(L.lib().ia3_align_image_ref(_src._h, _dref._h, int(precision_fold),
+                                                    1 if DEFAULT_NORMALIZATION == "phase" else 0, int(min_good_drifts),
+                                                    C.c_double(float(drift_diff_th)), _out, C.byref(_flag), L.dptr(_each),
+                                                    C.byref(_nused)))
+            else:
+                L.check(L.lib().ia3_align_image_dev(_src._h, _ref._h, _cl.ctypes.data_as(C.POINTER(C.c_int)), len(_cl),
+                                                    int(precision_fold), 1 if DEFAULT_NORMALIZATION == "phase" else 0,
+                                                    int(min_good_drifts), C.c_double(float(drift_diff_th)), _out,
+                                                    C.byref(_flag), L.dptr(_each), C.byref(_nused)))
             _drifts = [_each[_i].copy() for _i in range(_nused.value)]
             if verbose:
                 for _i, _dft in enumerate(_drifts):

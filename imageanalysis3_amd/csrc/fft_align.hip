@@ -781,6 +781,337 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
   return IA3_OK;
 }
 
+}  // extern "C"  (reopened below)
+
+// ---- align_image's crop loop without host round trips inside a crop ------------------------------------------------
+// correction_tools/alignment.py:617-662 runs phase_cross_correlation(ref crop, src crop) crop after crop, and every
+// image of a run is aligned to the SAME reference bead image (classes/batch_functions.py:169-206).  Three things follow:
+//  * the reference crop's half spectrum is a run constant: a DriftRef keeps it (105 MB per 50 x 512 x 512 crop) and a crop
+//    costs two transforms instead of three;
+//  * a crop is read out of the full stack straight into the transform's float64 input (crop_to_real_k): no crop copies;
+//  * the coarse peak never goes to the host: a one-block kernel turns it into the offsets of the upsampled DFT's kernel
+//    matrices, so the whole chain of a crop — D2Z, cross-power, Z2D, argmax, three contractions, argmax — is queued at
+//    once, and the first crops of an image (align_image needs three anyway) are queued back to back with ONE wait for
+//    their three shifts.  (ia3_phase_xcorr3d_dev waits twice per crop: ~0.1 ms of idle device each time.)
+// Same arithmetic as ia3_phase_xcorr3d_dev on the same operands; shifts agree to the last bit (tests).
+namespace {
+
+template <class T>
+__global__ void crop_to_real_k(const T* __restrict__ im, int X, int Y, int z0, int x0, int y0, int cz, int cx, int cy,
+                               double* __restrict__ o) {
+  const size_t n = (size_t)cz * cx * cy;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int y = (int)(i % (size_t)cy);
+  const size_t r = i / (size_t)cy;
+  const int x = (int)(r % (size_t)cx), z = (int)(r / (size_t)cx);
+  o[i] = (double)im[((size_t)(z0 + z) * X + (size_t)(x0 + x)) * Y + (size_t)(y0 + y)];
+}
+// out-of-place form of half_power_k: prod := A conj(B) (optionally phase-normalised), cj := conj(prod); A stays
+__global__ __launch_bounds__(256) void half_power2_k(const cplx* __restrict__ a, const cplx* __restrict__ b, size_t n, int Yh, int Y,
+                                                     int phase_norm, cplx* __restrict__ prod, cplx* __restrict__ cj,
+                                                     double* __restrict__ part_a, double* __restrict__ part_b) {
+  __shared__ double sha[256], shb[256];
+  double sa = 0, sb = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)ABS2_BLOCKS * 256) {
+    const int ky = (int)(i % (size_t)Yh);
+    const double wgt = (ky == 0 || 2 * ky == Y) ? 1.0 : 2.0;
+    const cplx x = a[i], y = b[i];
+    sa += wgt * (x.x * x.x + x.y * x.y);
+    sb += wgt * (y.x * y.x + y.y * y.y);
+    double re = x.x * y.x + x.y * y.y, im = x.y * y.x - x.x * y.y;
+    if (phase_norm) {
+      double m = hypot(re, im);
+      const double lim = 100.0 * 2.220446049250313e-16;
+      m = m > lim ? m : lim;
+      re /= m; im /= m;
+    }
+    prod[i] = cplx{re, im};
+    cj[i] = cplx{re, -im};
+  }
+  sha[threadIdx.x] = sa; shb[threadIdx.x] = sb;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) { sha[threadIdx.x] += sha[threadIdx.x + k]; shb[threadIdx.x] += shb[threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_a[blockIdx.x] = sha[0]; part_b[blockIdx.x] = shb[0]; }
+}
+// what the host does between the coarse peak and the upsampled DFT (ia3_phase_xcorr3d_dev), on the device
+struct CoarseRec { double sh[3]; double off[3]; };
+__global__ __launch_bounds__(256) void coarse_final_k(const double* __restrict__ pv, const long long* __restrict__ pi, int nb,
+                                                      int Z, int X, int Y, double u, double dftshift, CoarseRec* rec) {
+  __shared__ double sv[256];
+  __shared__ long long si[256];
+  double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    const double v = pv[k]; const long long i = pi[k];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    long long idx = si[0];
+    if (!(sv[0] >= 0.0)) idx = 0;
+    const int dims[3] = {Z, X, Y};
+    long long rem = idx;
+    int peak[3];
+    peak[2] = (int)(rem % Y); rem /= Y; peak[1] = (int)(rem % X); rem /= X; peak[0] = (int)rem;
+    for (int a = 0; a < 3; ++a) {
+      double sh = (double)peak[a];
+      if (sh > (double)(dims[a] / 2)) sh -= (double)dims[a];
+      sh = nearbyint(sh * u) / u;
+      rec->sh[a] = sh;
+      rec->off[a] = dftshift - sh * u;
+    }
+  }
+}
+// dft_kernel_k with the offset read from the coarse record
+__global__ void dft_kernel_dev_k(cplx* __restrict__ K, int R, int N, const double* __restrict__ off, double u) {
+  int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (n >= N) return;
+  int kf = n < (N + 1) / 2 ? n : n - N;
+  double turns = ((double)r - *off) * ((double)kf / ((double)N * u));
+  double s, c;
+  sincospi(-2.0 * turns, &s, &c);
+  K[(size_t)r * N + n] = cplx{c, s};
+}
+struct ShiftMail { unsigned seq, pad; double shift[3]; };
+__global__ __launch_bounds__(256) void fine_final_k(const double* __restrict__ pv, const long long* __restrict__ pi, int nb, int R,
+                                                    double u, double dftshift, const CoarseRec* __restrict__ rec, int Z, int X, int Y,
+                                                    volatile ShiftMail* mail, unsigned seq) {
+  __shared__ double sv[256];
+  __shared__ long long si[256];
+  double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    const double v = pv[k]; const long long i = pi[k];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = sv[threadIdx.x + s]; const long long oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    long long idx = si[0];
+    if (!(sv[0] >= 0.0)) idx = 0;
+    long long rem = idx;
+    int pk[3];
+    pk[2] = (int)(rem % R); rem /= R; pk[1] = (int)(rem % R); rem /= R; pk[0] = (int)rem;
+    const int dims[3] = {Z, X, Y};
+    for (int a = 0; a < 3; ++a) {
+      double sh = rec->sh[a] + ((double)pk[a] - dftshift) / u;
+      if (dims[a] == 1) sh = 0;
+      mail->shift[a] = sh;
+    }
+    __threadfence_system();
+    mail->seq = seq;
+  }
+}
+
+}  // namespace
+
+namespace ia3k {
+
+struct DriftRef {
+  const ia3_stack* ref = nullptr;
+  int dtype = 0, n = 0;
+  int box[8][6] = {};
+  void* spec[8] = {};       // half spectrum of the reference crop
+  bool have[8] = {};
+  bool cached[8] = {};      // spec[i] is a block of the scratch cache (a temporary reference) rather than a hipMalloc
+  std::mutex mu;            // a lazily made spectrum (temporary refs are used by one thread; shared ones are made eagerly)
+};
+
+static int crop_spectrum(const ia3_stack* s, const int* b, cplx* out, double* rbuf, hipStream_t st) {
+  const int cz = b[1] - b[0], cx = b[3] - b[2], cy = b[5] - b[4];
+  const size_t n = (size_t)cz * cx * cy;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (s->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3(nb), dim3(256), 0, st, (const float*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
+  else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
+  PlanLease fwd;
+  { int prc = get_plan(HIPFFT_D2Z, cz, cx, cy, st, fwd); if (prc) return prc; }
+  IA3_FFT(hipfftExecD2Z(fwd.h, rbuf, out));
+  IA3_KCHECK();
+  IA3_HIP(hipStreamSynchronize(st));   // the plan goes back to the pool when this returns
+  return IA3_OK;
+}
+
+void drift_ref_free(DriftRef* r) {
+  if (!r) return;
+  for (int i = 0; i < 8; ++i)
+    if (r->spec[i]) { if (r->cached[i]) ws_put(r->spec[i]); else (void)hipFree(r->spec[i]); }
+  delete r;
+}
+
+int drift_ref_create(const ia3_stack* ref, const int* crops, int n_crops, bool eager, DriftRef** out) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!ref || !crops || !out || n_crops < 1 || n_crops > 8) return set_error(IA3_EINVAL, "bad drift reference arguments");
+  DriftRef* r = new DriftRef();
+  r->ref = ref; r->dtype = ref->dtype; r->n = n_crops;
+  for (int i = 0; i < n_crops; ++i) {
+    const int* c = crops + 6 * i;
+    if (c[0] < 0 || c[2] < 0 || c[4] < 0 || c[1] > ref->Z || c[3] > ref->X || c[5] > ref->Y || c[0] >= c[1] || c[2] >= c[3] || c[4] >= c[5]) {
+      drift_ref_free(r);
+      return set_error(IA3_EINVAL, "bad crop [%d:%d, %d:%d, %d:%d] of (%d,%d,%d)", c[0], c[1], c[2], c[3], c[4], c[5], ref->Z, ref->X, ref->Y);
+    }
+    for (int k = 0; k < 6; ++k) r->box[i][k] = c[k];
+  }
+  if (eager) {
+    hipStream_t st = stream();
+    for (int i = 0; i < n_crops && !rc; ++i) {
+      const int* b = r->box[i];
+      const int cz = b[1] - b[0], cx = b[3] - b[2], cy = b[5] - b[4];
+      if (cy < 8) continue;   // such crops take the complex-transform route (no cached spectrum)
+      const size_t n = (size_t)cz * cx * cy, nh = (size_t)cz * cx * (cy / 2 + 1);
+      if (hipMalloc(&r->spec[i], nh * sizeof(cplx)) != hipSuccess) { rc = set_error(IA3_ENOMEM, "reference spectrum of crop %d", i); break; }
+      Scratch rbuf(n * sizeof(double));
+      if (!rbuf.p) { rc = IA3_ENOMEM; break; }
+      rc = crop_spectrum(ref, b, (cplx*)r->spec[i], rbuf.as<double>(), st);
+      r->have[i] = !rc;
+    }
+    if (rc) { drift_ref_free(r); return rc; }
+  }
+  *out = r;
+  return IA3_OK;
+}
+
+// shifts of crops [first, first + count) of `src` against the reference; count <= 3; one wait for all of them
+int drift_crops(const ia3_stack* src, DriftRef* ref, int first, int count, int upsample, int normalization, double* shifts) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!src || !ref || !shifts || first < 0 || count < 1 || count > 3 || first + count > ref->n) return set_error(IA3_EINVAL, "bad crop range");
+  if (src->dtype != ref->dtype || src->Z != ref->ref->Z || src->X != ref->ref->X || src->Y != ref->ref->Y)
+    return set_error(IA3_EINVAL, "source and reference stacks differ in shape or dtype");
+  hipStream_t st = stream();
+  bool fast = !g_fft_c2c && upsample > 1;
+  for (int c = first; c < first + count; ++c) {
+    const int* b = ref->box[c];
+    if (b[5] - b[4] < 8) fast = false;
+    if (c > first && (b[1] - b[0] != ref->box[first][1] - ref->box[first][0] || b[3] - b[2] != ref->box[first][3] - ref->box[first][2] ||
+                      b[5] - b[4] != ref->box[first][5] - ref->box[first][4])) fast = false;   // (one set of buffers and plans per batch)
+  }
+  if (!fast) {   // the general route, crop by crop (complex transforms, upsample 1, tiny rows, crops of different sizes)
+    for (int c = first; c < first + count; ++c) {
+      const int* b = ref->box[c];
+      ia3_stack *sc = nullptr, *rcp = nullptr;
+      rc = ia3_stack_crop(src, b[0], b[1], b[2], b[3], b[4], b[5], &sc);
+      if (!rc) rc = ia3_stack_crop(ref->ref, b[0], b[1], b[2], b[3], b[4], b[5], &rcp);
+      if (!rc) rc = ia3_phase_xcorr3d_dev(rcp, sc, upsample, normalization, shifts + 3 * (c - first), nullptr, nullptr);
+      if (sc) ia3_stack_free(sc);
+      if (rcp) ia3_stack_free(rcp);
+      if (rc) return rc;
+    }
+    return IA3_OK;
+  }
+  const int* b0 = ref->box[first];
+  const int Z = b0[1] - b0[0], X = b0[3] - b0[2], Y = b0[5] - b0[4];
+  const size_t n = (size_t)Z * X * Y;
+  const int Yh = Y / 2 + 1;
+  const size_t nh = (size_t)Z * X * Yh;
+  // reference spectra that are not there yet (a temporary reference: made when a crop is first needed)
+  for (int c = first; c < first + count; ++c) {
+    std::lock_guard<std::mutex> lk(ref->mu);
+    if (ref->have[c]) continue;
+    ref->spec[c] = ws_get(nh * sizeof(cplx));   // (a temporary reference lives for one call of one thread: cache blocks)
+    if (!ref->spec[c]) return IA3_ENOMEM;
+    ref->cached[c] = true;
+    Scratch rb(n * sizeof(double));
+    if (!rb.p) return IA3_ENOMEM;
+    rc = crop_spectrum(ref->ref, ref->box[c], (cplx*)ref->spec[c], rb.as<double>(), st); if (rc) return rc;
+    ref->have[c] = true;
+  }
+  const double u = (double)upsample;
+  const int R = (int)ceil(u * 1.5);
+  const double dftshift = trunc(R / 2.0);
+  const int maxN = Y > X ? (Y > Z ? Y : Z) : (X > Z ? X : Z);
+  const int NB = 512;
+  Scratch rbuf(n * sizeof(double)), fb(nh * sizeof(cplx)), fp(nh * sizeof(cplx)), parts(2 * ABS2_BLOCKS * sizeof(double)),
+      pv(NB * sizeof(double)), pi(NB * sizeof(long long)), rec(3 * sizeof(CoarseRec)),
+      K((size_t)R * maxN * sizeof(cplx)), t1((size_t)R * Z * X * sizeof(cplx)), t2((size_t)R * R * Z * sizeof(cplx)),
+      t3((size_t)R * R * R * sizeof(cplx)), tp((size_t)R * Z * X * sizeof(cplx));
+  if (!rbuf.p || !fb.p || !fp.p || !parts.p || !pv.p || !pi.p || !rec.p || !K.p || !t1.p || !t2.p || !t3.p || !tp.p) return IA3_ENOMEM;
+  void *mh = nullptr, *md = nullptr;
+  constexpr size_t OFF = 1280;   // the seed stage uses the first 64 bytes of the mailbox, the peak record 1024.., the fit 2048 and up
+  if (host_mailbox(4096, &mh, &md) != IA3_OK) return IA3_ENOMEM;
+  static thread_local unsigned t_seq = 0;
+  unsigned seqs[3];
+  PlanLease fwd, inv;
+  { int prc = get_plan(HIPFFT_D2Z, Z, X, Y, st, fwd); if (prc) return prc; }
+  { int prc = get_plan(HIPFFT_Z2D, Z, X, Y, st, inv); if (prc) return prc; }
+  auto matmul = [&](const cplx* Kmat, const cplx* in, cplx* out, int M, int cols, int ldk, int ldi) {
+    if (g_dft_valu)
+      hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+    else
+      hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+  };
+  for (int c = first; c < first + count; ++c) {
+    const int* b = ref->box[c];
+    CoarseRec* cr = rec.as<CoarseRec>() + (c - first);
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    {
+    ProfScope ps_fft("xcorr_fft");   // crop -> float64, D2Z, cross-power, Z2D, coarse peak
+    if (src->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
+    else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3(nblk), dim3(256), 0, st, (const uint16_t*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
+    IA3_FFT(hipfftExecD2Z(fwd.h, rbuf.as<double>(), fb.as<cplx>()));
+    // fp := prod, fb := conj(prod) (the data of the upsampled DFT); the power sums are not needed for the shift
+    hipLaunchKernelGGL(half_power2_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)ref->spec[c], (const cplx*)fb.as<cplx>(), nh, Yh, Y, normalization,
+                       fp.as<cplx>(), fb.as<cplx>(), parts.as<double>(), parts.as<double>() + ABS2_BLOCKS);
+    IA3_FFT(hipfftExecZ2D(inv.h, fp.as<cplx>(), rbuf.as<double>()));
+    hipLaunchKernelGGL(real_argmax_part_k, dim3(NB), dim3(256), 0, st, (const double*)rbuf.as<double>(), n, pv.as<double>(), pi.as<long long>());
+    hipLaunchKernelGGL(coarse_final_k, dim3(1), dim3(256), 0, st, (const double*)pv.as<double>(), (const long long*)pi.as<long long>(), NB, Z, X, Y, u, dftshift, cr);
+    }
+    ProfScope ps_dft("xcorr_dft");   // upsampled DFT (three contractions on the f64 matrix cores) + fine peak
+    // upsampled DFT around the coarse peak: axes Y (half spectrum + Hermitian completion), X, Z
+    hipLaunchKernelGGL(dft_kernel_dev_k, dim3((Y + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, Y, (const double*)&cr->off[2], u);
+    const int inner = (Y - 1) / 2;
+    matmul((const cplx*)K.as<cplx>() + 1, (const cplx*)fb.as<cplx>() + 1, tp.as<cplx>(), Z * X, inner, Y, Yh);
+    hipLaunchKernelGGL(half_combine_k, dim3((unsigned)(((size_t)R * Z * X + 255) / 256)), dim3(256), 0, st, (const cplx*)tp.as<cplx>(),
+                       (const cplx*)fb.as<cplx>(), (const cplx*)K.as<cplx>(), Y, R, Z, X, Yh, Y, t1.as<cplx>());
+    hipLaunchKernelGGL(dft_kernel_dev_k, dim3((X + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, X, (const double*)&cr->off[1], u);
+    matmul((const cplx*)K.as<cplx>(), (const cplx*)t1.as<cplx>(), t2.as<cplx>(), R * Z, X, X, X);
+    hipLaunchKernelGGL(dft_kernel_dev_k, dim3((Z + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, Z, (const double*)&cr->off[0], u);
+    matmul((const cplx*)K.as<cplx>(), (const cplx*)t2.as<cplx>(), t3.as<cplx>(), R * R, Z, Z, Z);
+    hipLaunchKernelGGL(abs_argmax_part_k, dim3(NB), dim3(256), 0, st, (const cplx*)t3.as<cplx>(), (size_t)R * R * R, pv.as<double>(), pi.as<long long>());
+    seqs[c - first] = ++t_seq ? t_seq : ++t_seq;
+    hipLaunchKernelGGL(fine_final_k, dim3(1), dim3(256), 0, st, (const double*)pv.as<double>(), (const long long*)pi.as<long long>(), NB, R, u, dftshift,
+                       (const CoarseRec*)cr, Z, X, Y, (volatile ShiftMail*)((char*)md + OFF + (size_t)(c - first) * sizeof(ShiftMail)), seqs[c - first]);
+    IA3_KCHECK();
+  }
+  for (int k = 0; k < count; ++k) {
+    volatile ShiftMail* mb = (volatile ShiftMail*)((char*)mh + OFF + (size_t)k * sizeof(ShiftMail));
+    SpinWait sw;
+    while (mb->seq != seqs[k]) {
+      sw.relax();
+      if (((sw.n & 0xfffff) == 0 || (sw.n > 40400 && (sw.n & 0x3ff) == 0)) && hipStreamQuery(st) != hipErrorNotReady) {
+        if (mb->seq == seqs[k]) break;
+        IA3_HIP(hipStreamSynchronize(st));
+        if (mb->seq != seqs[k]) return set_error(IA3_EHIP, "drift of crop %d did not reach the host mailbox", first + k);
+        break;
+      }
+    }
+    for (int a = 0; a < 3; ++a) shifts[3 * k + a] = mb->shift[a];
+  }
+  // the plans and the scratch go back now: everything queued above has finished (the last mailbox word is written by the
+  // last kernel of the last crop)
+  IA3_HIP(hipStreamSynchronize(st));
+  return IA3_OK;
+}
+
+}  // namespace ia3k
+
+extern "C" {
+
 int ia3_phase_xcorr3d(const void* ref, const void* mov, int dtype, int Z, int X, int Y, int upsample,
                       int normalization, double* shift, double* err, double* phasediff) {
   ia3_stack *a = nullptr, *b = nullptr;

@@ -1053,7 +1053,10 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
 // block index: tickets are handed out in the order waves actually get to them, so everything a wave may wait for is
 // held by a wave that is running (or done) whatever order the dispatcher picks — no co-residency assumption.  (One block
 // per position, the first form, spent 0.14 ms per 10 000 positions on block launches alone.)
-__global__ __launch_bounds__(64, 2) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
+#ifndef IA3_FIT_LB
+#define IA3_FIT_LB 2   // waves per SIMD the fit kernel is built for (256 registers at 2); scripts/ab_fit2.sh builds others
+#endif
+__global__ __launch_bounds__(64, IA3_FIT_LB) void fit_stages_k(FitArgs fa, int n, int stage0, int stage1, StageCtl* ctl,
                                                       int* done) {
   __shared__ WaveLds wl;
   IA3_LDS WaveLds* L = (IA3_LDS WaveLds*)&wl;
@@ -1526,7 +1529,7 @@ namespace ia3k {
 void set_fit_nblist(int cap) { g_nb_cap = cap < 0 ? 0 : (cap > MAXNB ? MAXNB : cap); }
 void set_fit_fuse(int on) { g_fit_fuse = on ? 1 : 0; }
 void set_fit_maxfev(int n) { g_fit_maxfev = n; }
-void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > 2 ? 2 : n); }
+void set_fit_waves(int n) { g_fit_waves = n < 1 ? 1 : (n > IA3_FIT_LB ? IA3_FIT_LB : n); }
 void set_fit_merge(int on) { g_fit_merge = on != 0; }
 int set_fit_waitbound(int polls) {
   int rc = ia3rt::ensure_init(); if (rc) return rc;
@@ -1658,6 +1661,7 @@ static int fetch_block(ia3_fitter* f, bool with_rows) {
 // Exact Voronoi ties (nbr_build_k flagged them, the first launch left without fitting anything): build the seed tree with
 // cKDTree's layout on the host (kdtree.cpp), hand it to voronoi_ties_k, which leaves per seed the lane masks of the tie
 // voxels it loses.  Fields without ties — every isolated-spot field — never come here.
+static int resolve_ties_host(ia3_fitter* f);
 static int resolve_ties(ia3_fitter* f) {
   hipStream_t st = stream();
   const int n = f->n, nf = (int)f->ims.size();
@@ -1706,7 +1710,13 @@ static int resolve_ties(ia3_fitter* f) {
     }
   }
   IA3_KCHECK();
+  // did a query run out of queue entries?  (The next fit launch re-arms the control record, so this is the place to
+  // look; fields with ties are the rare case and pay one more small read-back.)
+  int ab = 0;
+  IA3_HIP(hipMemcpyAsync(&ab, &((StageCtl*)f->d_ctl)->abort, sizeof(int), hipMemcpyDeviceToHost, st));
+  IA3_HIP(hipStreamSynchronize(st));
   f->ties_resolved = true;
+  if (ab == 3) return resolve_ties_host(f);
   return IA3_OK;
 }
 
@@ -1799,11 +1809,6 @@ static int run_sweeps(ia3_fitter* f, int stage, bool fresh, int last = -1) {
       rc = resolve_ties(f); if (rc) return rc;
       fresh = true;
       continue;   // the same stages again, now with the tie masks
-    }
-    if (hc.abort == 3 && f->ties_resolved && !f->ties_host) {
-      rc = resolve_ties_host(f); if (rc) return rc;
-      fresh = true;
-      continue;   // the same stages again, with the host's tie masks
     }
     rc = check_ctl(hc); if (rc) return rc;
     fresh = false;

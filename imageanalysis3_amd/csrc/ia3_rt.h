@@ -155,6 +155,12 @@ int fit_create_multi(const ia3_stack* const* ims, const double* const* d_centers
                      const ia3_fit_params* p, ia3_fitter** out);
 int fit_fov_results(ia3_fitter* f, int* n_iter, long long* counters3);
 const int* fit_fov_starts(const ia3_fitter* f);
+// drift of an image against a reference bead image whose crop spectra are kept (fft_align.hip): crops = n x 6 ints
+// [z0, z1, x0, x1, y0, y1]; eager = all spectra now (a reference shared by several threads), else each when first needed
+struct DriftRef;
+int drift_ref_create(const ia3_stack* ref, const int* crops, int n_crops, bool eager, DriftRef** out);
+void drift_ref_free(DriftRef* r);
+int drift_crops(const ia3_stack* src, DriftRef* ref, int first, int count, int upsample, int normalization, double* shifts);
 // fits run / model evaluations / voxel evaluations / shader cycles in dependency waits / wave cycles of a fitter, as of its
 // last ia3_fit_results(_ex)
 void fit_host_counters(const ia3_fitter* f, long long out[5]);

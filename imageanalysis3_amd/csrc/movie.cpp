@@ -92,6 +92,32 @@ void closest_three(const double* d, int n, double out[3]) {
 
 }  // namespace
 
+// align_image's loop over the crops of a DriftRef: the first min_good crops (at most three) in one batch — the rule
+// cannot stop before it has that many — then crop by crop until enough of them agree
+static int align_with_ref(const ia3_stack* src, ia3k::DriftRef* dr, int n_crops, int upsample, int normalization, int min_good_drifts,
+                          double drift_diff_th, double* drift, int* flag, double* drifts_out, int* n_used) {
+  std::vector<double> d;
+  bool agreed = false;
+  int done = 0;
+  while (done < n_crops && !agreed) {
+    int count = done == 0 ? (min_good_drifts < 3 ? (min_good_drifts < 1 ? 1 : min_good_drifts) : 3) : 1;
+    if (count > n_crops - done) count = n_crops - done;
+    double sh[9];
+    int rc = ia3k::drift_crops(src, dr, done, count, upsample, normalization, sh); if (rc) return rc;
+    for (int k = 0; k < count && !agreed; ++k) {   // the reference looks at the rule after every crop
+      d.insert(d.end(), sh + 3 * k, sh + 3 * k + 3);
+      agreed = consensus(d.data(), (int)(d.size() / 3), min_good_drifts, drift_diff_th, drift);
+    }
+    done += count;
+  }
+  const int n = (int)(d.size() / 3);
+  if (!agreed) closest_three(d.data(), n, drift);
+  if (flag) *flag = agreed ? 0 : 1;
+  if (drifts_out) memcpy(drifts_out, d.data(), d.size() * sizeof(double));
+  if (n_used) *n_used = n;
+  return IA3_OK;
+}
+
 extern "C" int ia3_align_image_dev(const ia3_stack* src, const ia3_stack* ref, const int* crops, int n_crops, int upsample,
                                    int normalization, int min_good_drifts, double drift_diff_th, double* drift, int* flag,
                                    double* drifts_out, int* n_used) {
@@ -100,27 +126,33 @@ extern "C" int ia3_align_image_dev(const ia3_stack* src, const ia3_stack* ref, c
   if (src->Z != ref->Z || src->X != ref->X || src->Y != ref->Y)
     return set_error(IA3_EINVAL, "shape of target image and reference image doesnt match");
   if (src->dtype != ref->dtype) return set_error(IA3_EINVAL, "source and reference stacks differ in dtype");
-  std::vector<double> d;
-  bool agreed = false;
-  for (int i = 0; i < n_crops && !agreed; ++i) {
-    const int* c = crops + 6 * i;
-    ia3_stack *sc = nullptr, *rcp = nullptr;
-    rc = ia3_stack_crop(src, c[0], c[1], c[2], c[3], c[4], c[5], &sc);
-    if (!rc) rc = ia3_stack_crop(ref, c[0], c[1], c[2], c[3], c[4], c[5], &rcp);
-    double sh[3] = {0, 0, 0};
-    if (!rc) rc = ia3_phase_xcorr3d_dev(rcp, sc, upsample, normalization, sh, nullptr, nullptr);
-    if (sc) ia3_stack_free(sc);
-    if (rcp) ia3_stack_free(rcp);
-    if (rc) return rc;
-    d.insert(d.end(), sh, sh + 3);
-    agreed = consensus(d.data(), i + 1, min_good_drifts, drift_diff_th, drift);
-  }
-  const int n = (int)(d.size() / 3);
-  if (!agreed) closest_three(d.data(), n, drift);
-  if (flag) *flag = agreed ? 0 : 1;
-  if (drifts_out) memcpy(drifts_out, d.data(), d.size() * sizeof(double));
-  if (n_used) *n_used = n;
+  if (n_crops > 8) return set_error(IA3_EINVAL, "at most 8 drift crops");
+  ia3k::DriftRef* dr = nullptr;
+  rc = ia3k::drift_ref_create(ref, crops, n_crops, false, &dr); if (rc) return rc;   // spectra of the crops that get used
+  rc = align_with_ref(src, dr, n_crops, upsample, normalization, min_good_drifts, drift_diff_th, drift, flag, drifts_out, n_used);
+  ia3k::drift_ref_free(dr);
+  return rc;
+}
+
+struct ia3_drift_ref { ia3k::DriftRef* r; int n_crops; };
+
+extern "C" int ia3_drift_ref_create(const ia3_stack* ref, const int* crops, int n_crops, ia3_drift_ref** out) {
+  if (!out) return set_error(IA3_EINVAL, "null argument");
+  ia3k::DriftRef* r = nullptr;
+  int rc = ia3k::drift_ref_create(ref, crops, n_crops, true, &r); if (rc) return rc;
+  *out = new ia3_drift_ref{r, n_crops};
   return IA3_OK;
+}
+extern "C" void ia3_drift_ref_free(ia3_drift_ref* r) {
+  if (!r) return;
+  ia3k::drift_ref_free(r->r);
+  delete r;
+}
+extern "C" int ia3_align_image_ref(const ia3_stack* src, ia3_drift_ref* ref, int upsample, int normalization, int min_good_drifts,
+                                   double drift_diff_th, double* drift, int* flag, double* drifts_out, int* n_used) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (!src || !ref || !drift) return set_error(IA3_EINVAL, "null argument");
+  return align_with_ref(src, ref->r, ref->n_crops, upsample, normalization, min_good_drifts, drift_diff_th, drift, flag, drifts_out, n_used);
 }
 
 // ---- the movie pipeline -------------------------------------------------------------------------------------------
@@ -149,6 +181,7 @@ struct Pipe {
   int n_jobs;
   const ia3_movie_params* p;
   double t0;
+  ia3_drift_ref* dref = nullptr;     // reference crop spectra (the caller's, or made for this call)
   std::mutex mu;
   std::condition_variable cv;
   std::vector<ia3_stack*> raw;       // uploaded movies waiting for a corrector
@@ -198,7 +231,7 @@ void uploader(Pipe& P) {
 }
 
 // io_tools/load.py:303-498 on resident stacks: raw movie -> the selected, corrected channels (sel_out), drift and flag
-int correct_movie(const ia3_movie_params& p, ia3_movie_job& j, ia3_stack* raw, ia3_stack** sel_out) {
+int correct_movie(const ia3_movie_params& p, ia3_drift_ref* dref, ia3_movie_job& j, ia3_stack* raw, ia3_stack** sel_out) {
   std::vector<ia3_stack*> ch((size_t)p.n_load, nullptr);
   std::vector<ia3_stack*> extra;   // replaced stacks (inputs of the bleedthrough mix, unwarped images)
   int rc = IA3_OK;
@@ -236,9 +269,9 @@ int correct_movie(const ia3_movie_params& p, ia3_movie_job& j, ia3_stack* raw, i
   double drift[3] = {j.drift_in[0], j.drift_in[1], j.drift_in[2]};
   int flag = 0;
   if (!rc && j.measure_drift && p.drift_idx >= 0) {
-    if (!p.ref_bead) rc = set_error(IA3_EINVAL, "no reference bead stack");
-    else rc = ia3_align_image_dev(ch[(size_t)p.drift_idx], p.ref_bead, &p.crops[0][0][0], p.n_crops, p.precision_fold, p.normalization,
-                                  p.min_good_drifts, p.drift_diff_th, drift, &flag, nullptr, nullptr);
+    if (!dref) rc = set_error(IA3_EINVAL, "no reference bead stack");
+    else rc = ia3_align_image_ref(ch[(size_t)p.drift_idx], dref, p.precision_fold, p.normalization, p.min_good_drifts, p.drift_diff_th,
+                                  drift, &flag, nullptr, nullptr);
   }
   if (rc) { cleanup(false); return rc; }
   memcpy(j.drift, drift, sizeof(drift));
@@ -311,7 +344,7 @@ void corrector(Pipe& P) {
     const double ta = now_ms();
     ia3_stack* sel[IA3_MOVIE_MAXCH] = {};
     int rc = ok ? init_rc : IA3_EINVAL;
-    if (ok && !rc) rc = correct_movie(p, j, raw, sel);
+    if (ok && !rc) rc = correct_movie(p, P.dref, j, raw, sel);
     if (raw) ia3_stack_free(raw);
     if (ok && rc) fail(P, k, rc);
     std::vector<Image*> ims;
@@ -472,12 +505,26 @@ extern "C" int ia3_process_movies(ia3_movie_job* jobs, int n_jobs, const ia3_mov
   if (NC > n_jobs) NC = n_jobs;
   // the reference bead stack (and profiles) may still be in production on the caller's stream
   rc = stream_wait_spin(stream()); if (rc) return rc;
+  bool any_measure = false;
+  for (int k = 0; k < n_jobs; ++k) any_measure = any_measure || jobs[k].measure_drift;
+  ia3_drift_ref* own_ref = nullptr;
+  if (p->drift_idx >= 0 && any_measure) {
+    if (p->drift_ref) P.dref = p->drift_ref;
+    else {
+      if (!p->ref_bead) return set_error(IA3_EINVAL, "no reference bead stack");
+      if (p->ref_bead->Z != p->Z || p->ref_bead->X != p->X || p->ref_bead->Y != p->Y || p->ref_bead->dtype != IA3_U16)
+        return set_error(IA3_EINVAL, "the reference bead stack must be a uint16 stack of the image size");
+      rc = ia3_drift_ref_create(p->ref_bead, &p->crops[0][0][0], p->n_crops, &own_ref); if (rc) return rc;
+      P.dref = own_ref;
+    }
+  }
   ia3pipe::pool_run(NC + 2, [&]() {
     const int r = P.role.fetch_add(1);
     if (r == 0) fitter(P);
     else if (r == 1) uploader(P);
     else corrector(P);
   });
+  if (own_ref) ia3_drift_ref_free(own_ref);
   for (int k = 0; k < n_jobs; ++k)
     if (jobs[k].rc) return set_error(jobs[k].rc, "movie %d: %s", k, P.errs[(size_t)k].c_str());
   return IA3_OK;

@@ -216,11 +216,19 @@ void* ws_get(size_t bytes) {
   return p;
 }
 // idle blocks above this total go back to the driver (largest first): stacks of many different sizes would otherwise
-// pile up in a long-running process.  IA3_CACHE_GB overrides the default of 64 GB (the device has 288).
+// pile up in a long-running process.  IA3_CACHE_GB overrides the default of half the device's memory (144 GB of 288; it
+// was 64 GB until round 4: the movie pipeline — three movies in correction, twelve images waiting for their group fit —
+// parks 40-60 GB of blocks between uses, and every trim is a hipFree that synchronises the device and is followed by a
+// hipMalloc of the same size a moment later: a 200 ms stall of all streams in the timeline of profiles/r04f).
 static size_t ws_idle_limit() {
   static const size_t lim = [] {
     const char* e = getenv("IA3_CACHE_GB");
-    const double gb = e ? atof(e) : 64.0;
+    double gb = e ? atof(e) : 0.0;
+    if (!e) {
+      size_t fr = 0, tot = 0;
+      gb = hipMemGetInfo(&fr, &tot) == hipSuccess ? (double)tot / 1073741824.0 * 0.5 : 64.0;
+      if (gb < 16.0) gb = 16.0;
+    }
     return (size_t)((gb > 0 ? gb : 0) * 1073741824.0);
   }();
   return lim;

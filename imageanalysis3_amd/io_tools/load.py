@@ -717,6 +717,10 @@ class MoviePlan(object):
                 raise TypeError("the resident reference bead stack must be uint16 of the image size")
             self._keep.append(ref_image)
             p.ref_bead = ref_image._h
+            # the reference crops' spectra, once for every run() of this plan
+            from ..correction_tools.alignment import DriftReference
+            self.drift_reference = DriftReference(ref_image, crop_list)
+            p.drift_ref = self.drift_reference._h
         # seeding + fitting (spot_tools/fitting.py:169-262 through classes/batch_functions.py:248-300)
         p.fit_spots = 1 if fit_spots else 0
         fa = dict(fitting_args)

@@ -366,6 +366,16 @@ int ia3_align_image_dev(const ia3_stack* src, const ia3_stack* ref, const int* c
                         int normalization, int min_good_drifts, double drift_diff_th, double* drift, int* flag,
                         double* drifts_out, int* n_used);
 
+/* Many images against ONE reference bead image (every movie of a run: classes/batch_functions.py:169-206): the half
+ * spectra of the reference crops are computed once and kept on the device (105 MB per 50 x 512 x 512 crop), so a crop
+ * costs two transforms instead of three.  ia3_align_image_ref = ia3_align_image_dev with such a reference; drifts are
+ * identical.  A drift reference may be shared by several host threads; free it after their calls have returned. */
+typedef struct ia3_drift_ref ia3_drift_ref;
+int ia3_drift_ref_create(const ia3_stack* ref, const int* crops, int n_crops, ia3_drift_ref** out);
+void ia3_drift_ref_free(ia3_drift_ref* r);
+int ia3_align_image_ref(const ia3_stack* src, ia3_drift_ref* ref, int upsample, int normalization, int min_good_drifts,
+                        double drift_diff_th, double* drift, int* flag, double* drifts_out, int* n_used);
+
 /* ---- warp -------------------------------------------------------------------------------------
  * correction_tools/translate.py:5-31 warp_3d_image and its inlined twins (io_tools/load.py:438-453,
  * classes/preprocess.py:918-946): out = map_coordinates(im, grid (+ field) - drift, order, mode, cval).
@@ -408,6 +418,7 @@ typedef struct ia3_movie_params {
   const void* illum_profile[IA3_MOVIE_MAXCH]; int illum_dtype[IA3_MOVIE_MAXCH];   /* per loaded channel, NULL = none (:373-384) */
   int drift_idx;                       /* loaded channel holding the beads; < 0: no drift measurement */
   const ia3_stack* ref_bead;           /* corrected reference bead stack, resident */
+  ia3_drift_ref* drift_ref;            /* optional: a drift reference made from ref_bead and `crops` (else made per call) */
   int n_crops; int crops[8][3][2];     /* generate_drift_crops */
   int precision_fold, normalization, min_good_drifts; double drift_diff_th;
   int warp;                            /* 0: images are never resampled (warp_image=False, or a silent call: :434-436) */

@@ -62,9 +62,13 @@ def main():
                              correct_threads=nc, fit_group_images=grp, upload_ahead=ahead)
             plan.run([raws[k % 3] for k in range(max(4, nc + 2))])
             L.check(lib.ia3_sync())
-            t0 = time.perf_counter()
-            out = plan.run([raws[k % 3] for k in range(n_mov)])
-            dt = time.perf_counter() - t0
+            reps = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                out = plan.run([raws[k % 3] for k in range(n_mov)])
+                reps.append(time.perf_counter() - t0)
+            print("   runs:", [round(r / n_mov, 4) for r in reps], flush=True)
+            dt = sorted(reps)[1]
             ms = {k_: float(np.mean([o["ms"][k_] for o in out])) for k_ in ("upload", "correct", "fit")}
             key = "correct%d_group%d_ahead%d" % (nc, grp, ahead)
             res[key] = {"s_per_movie": dt / n_mov, "stage_ms": ms, "rows": [len(t) for t in out[0]["tables"]],

@@ -442,6 +442,48 @@ def test_align_image_resident_inputs_equal_host_inputs():
         a.free(); b.free()
 
 
+def test_drift_reference_and_batched_crops_equal_the_per_crop_function():
+    """align_image's phase-correlation path queues the whole chain of a crop without a host round trip (coarse peak ->
+    DFT offsets on the device), the first three crops back to back, and with a DriftReference the reference crops'
+    spectra are made once: all of it must give the per-crop function's shifts (phase_cross_correlation on the crops, two
+    waits per crop) bit for bit, for uint16 and float32 stacks, both normalisations, and when the rule needs more than
+    three crops."""
+    from imageanalysis3_amd import synth, _lib as L
+    from imageanalysis3_amd.correction_tools import alignment as A
+    shape = (24, 256, 256)
+    ref, src, c, h = synth.make_bead_pair(shape, 60, 9, (0.4, -2.3, 3.1), margin=(4, 12, 12), min_sep=10.0)
+    crops = A.generate_drift_crops(shape)
+    for dtype in (np.uint16, np.float32):
+        r, s_ = ref.astype(dtype), src.astype(dtype)
+        with L.DeviceStack.upload(r) as dr, L.DeviceStack.upload(s_) as ds:
+            for norm in (None, "phase"):
+                old = A.DEFAULT_NORMALIZATION
+                A.DEFAULT_NORMALIZATION = norm
+                try:
+                    per_crop = []
+                    for cr in crops:
+                        a, b = ds.crop(cr), dr.crop(cr)
+                        per_crop.append(A.phase_cross_correlation(b, a, upsample_factor=100, normalization=norm)[0])
+                        a.free(); b.free()
+                    d0, f0 = A.align_image(ds, dr, use_autocorr=True, verbose=False)
+                    # drift_diff_th = 0: no three crops agree exactly -> all eight are measured, then the closest three
+                    d8, f8 = A.align_image(ds, dr, use_autocorr=True, drift_diff_th=0., verbose=False)
+                    dref = A.DriftReference(dr)
+                    try:
+                        d1, f1 = A.align_image(ds, dref, use_autocorr=True, verbose=False)
+                        d9, f9 = A.align_image(ds, dref, use_autocorr=True, drift_diff_th=0., verbose=False)
+                    finally:
+                        dref.free()
+                finally:
+                    A.DEFAULT_NORMALIZATION = old
+                want, agree = A._consensus_drift(per_crop[:3], 3, 1.)
+                if want is not None:
+                    assert f0 == 0 and np.array_equal(d0, want), (dtype, norm, d0, want)
+                assert f1 == f0 and np.array_equal(d1, d0), (dtype, norm)
+                assert f8 == 1 and np.array_equal(d8, A._closest_three_drift(per_crop)), (dtype, norm, d8)
+                assert f9 == 1 and np.array_equal(d9, d8), (dtype, norm)
+
+
 def test_pairing_golden():
     from imageanalysis3_amd.spot_tools.matching import find_paired_centers, check_paired_centers
     g = load_golden("drift.npz")
