@@ -55,7 +55,8 @@ struct SeedState {
   int success;    // GaussianFit.success of the last attempt
   int has_rec;    // a reconstruction exists (ims_rec[ic] is an array, not NaN)
   int conv;       // converged flag of repeatfit (:680)
-  int pad;
+  int ver;        // how often this record has been rewritten (store_result with a fit made): what a refit of a NEIGHBOUR
+                  // saw of this seed is unchanged as long as this number is
 };
 
 // One fitter may hold the seeds of SEVERAL fields of view (same shape and dtype; ia3_fit_fovs): the seeds of FOV f are
@@ -82,6 +83,11 @@ struct FitArgs {
   int* nvox;                // n
   int* nfev;                // n (accumulated function evaluations)
   unsigned char* conv;      // n
+  // n: bit 63 = this seed has been refitted by a repeat sweep, low bits = sum of its neighbours' SeedState::ver at that
+  // refit.  A repeat fit is a function of the image ball and of the neighbours' records alone (the start point is the
+  // seed, Fitting_v4.py:664-666; the data the image minus the neighbours' reconstructions), so a sweep that finds the sum
+  // unchanged would repeat the previous fit bit for bit: it is not run (stage_position).
+  unsigned long long* memo;
   int* n_iter;              // n_fov: sweeps made per field (max over its seeds)
   unsigned long long* counters;  // [0] fits run, [1] function evaluations, [2] voxel evaluations (sum of nfev x voxels)
   unsigned long long* fov_counters;   // n_fov x 4: the same three per field; [3]: its seeds with neighbours (nbr_build_k)
@@ -554,7 +560,8 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, IA3_LDS W
                                              double delta, bool ok, int n, int nfev, bool write_conv, bool cv) {
   const int lane = threadIdx.x & 63;
   static_assert(sizeof(SeedState) == 26 * 4 && offsetof(SeedState, delta) == 80 && offsetof(SeedState, success) == 88 &&
-                offsetof(SeedState, has_rec) == 92 && offsetof(SeedState, conv) == 96, "store_result writes SeedState by dwords");
+                offsetof(SeedState, has_rec) == 92 && offsetof(SeedState, conv) == 96 && offsetof(SeedState, ver) == 100,
+                "store_result writes SeedState by dwords");
   unsigned v = 0u;
   bool act = false;
   if (lane < 20) { v = ((const IA3_LDS unsigned*)L->w.x)[lane]; act = ok; }
@@ -562,6 +569,7 @@ __device__ __forceinline__ void store_result(const FitArgs& fa, int i, IA3_LDS W
   else if (lane == 22) { v = ok ? 1u : 0u; act = true; }
   else if (lane == 23) { v = 1u; act = ok; }
   else if (lane == 24) { v = cv ? 1u : 0u; act = write_conv; }
+  else if (lane == 25) { v = (unsigned)LDH(&fa.state[i].ver) + 1u; act = ok; }   // only this wave ever writes the record
   else if (lane >= 32 && lane < 43) { v = ((const IA3_LDS unsigned*)L->p)[lane - 32]; act = ok; }
   unsigned* dst = lane < 32 ? (unsigned*)&fa.state[i] + lane : (unsigned*)&fa.ps[(size_t)i * 11] + (lane - 32);
   if (act) st_sc1(dst, v);
@@ -999,6 +1007,7 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
   // run_position (the fit) has ONE call site below: the kernel is instruction-cache bound, a second copy of the
   // solver costs more than the branches around this one.
   int mode;
+  unsigned long long ver_sum = 0ull;
   if (k == 0) {
     // sweep 1 is part of this launch and nothing overlaps this seed: both of its fits from this wave (run_position)
     const bool fused = fa.fuse && stage1 >= 2 && fa.nbr_cnt[i] == 0;
@@ -1024,9 +1033,27 @@ __device__ __forceinline__ bool stage_position(const FitArgs& fa, IA3_LDS WaveLd
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (lane == 0) L->tally_wait += __builtin_readcyclecounter() - t_wait;   // cycles this wave sat in dependency waits
     mode = 1;
+    // What this refit would see of its neighbours (their records are final for this position: the waits above).  Unchanged
+    // since this seed's previous refit = the same voxels, the same data, the same start point: the fit would return the
+    // row it returned then, the centre would not move, the seed would be marked converged (:677-680).  That is what
+    // happens here, without the fit — the last sweep of a plateau twin that refits noise to maxfev (15 ms for one wave
+    // while the device idles: a lone uint16 FOV), of every seed whose neighbours had settled a sweep earlier.
+    each_neighbour(fa, i, [&](int j) { ver_sum += (unsigned long long)(unsigned)LDH(&fa.state[j].ver); return true; });
+    ver_sum |= 1ull << 63;
+    if (k >= 2 && fa.memo && __builtin_amdgcn_readfirstlane((int)(LDH(&fa.memo[i]) == ver_sum))) {
+      tally_field(fa, L, fa.fov_of[i]);
+      if (lane == 0) {
+        st_sc1(&fa.state[i].conv, 1);
+        if (k > L->tally_iter) L->tally_iter = k;
+        L->tally_conv += 1;
+      }
+      publish(done, i, k + 1);
+      return true;
+    }
   }
   IA3_STAMP(L, 13);   // admission (dependency waits)
   const bool cv = run_position(fa, L, i, mode);
+  if (mode != 0 && lane == 0 && fa.memo) st_sc1(&fa.memo[i], mode == 2 ? (1ull << 63) : ver_sum);   // (mode 2: no neighbours)
   if (mode == 0) {
     publish(done, i, 1);
     return true;
@@ -1272,7 +1299,7 @@ struct ia3_fitter {
   std::vector<char> meta_stage;      // source of the asynchronous upload of the three tables above
   void* pool;          // one device block from the scratch cache holding every array below
   size_t pool_bytes;
-  void *d_seeds, *d_nbr_cnt, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_conv, *d_niter,
+  void *d_seeds, *d_nbr_cnt, *d_nbr_idx, *d_ball, *d_state, *d_ps, *d_nvox, *d_nfev, *d_memo, *d_conv, *d_niter,
       *d_counters, *d_done, *d_ctl, *d_nbr_overflow;
   bool pristine;       // the block is as fit_init_k left it: the first fit launch needs no further resets
   bool first_done;
@@ -1305,6 +1332,7 @@ int g_fit_fuse = 1;     // IA3_TUNE_FIT_FUSE: 1 = a seed without neighbours gets
 int g_fit_maxfev = 0;   // IA3_DEBUG_FIT_MAXFEV: profiling only (splits the kernel time into a fixed and a per-evaluation part)
 int g_fit_waves = 2;    // IA3_TUNE_FIT_WAVES: persistent waves per SIMD (the kernel's 256 registers allow two)
 int g_fit_merge = 1;    // IA3_TUNE_FIT_MERGE: sweeps after the first pair in one launch when few seeds are left (run_sweeps)
+int g_fit_memo = 1;    // IA3_TUNE_FIT_MEMO: a refit whose neighbours have not changed since the seed's previous refit is not run
 int g_fit_kdq = KDQ_CAP;   // IA3_TUNE_FIT_KDQ: queue entries per voxel of the device tie queries
 
 FitArgs make_args(const ia3_fitter* f) {
@@ -1317,6 +1345,7 @@ FitArgs make_args(const ia3_fitter* f) {
   a.ball = (const int*)f->d_ball; a.nball = f->nball; a.radius = f->prm.radius_fit;
   a.tie_lost = f->ties_resolved ? (const unsigned long long*)f->d_tie_lost : nullptr;
   a.state = (SeedState*)f->d_state; a.ps = (float*)f->d_ps; a.nvox = (int*)f->d_nvox; a.nfev = (int*)f->d_nfev;
+  a.memo = g_fit_memo ? (unsigned long long*)f->d_memo : nullptr;
   a.conv = (unsigned char*)f->d_conv; a.n_iter = (int*)f->d_niter; a.counters = (unsigned long long*)f->d_counters;
   a.min_ws = f->prm.min_w * f->prm.min_w; a.max_ws = f->prm.max_w * f->prm.max_w; a.init_w = f->prm.init_w;
   a.delta_first = f->prm.min_delta_center; a.delta_repeat = f->prm.max_delta_center;
@@ -1412,7 +1441,8 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
   const size_t b_state = al(sizeof(SeedState) * (size_t)n), b_nvox = al(sizeof(int) * (size_t)n), b_nfev = b_nvox,
                b_conv = al((size_t)n), b_niter = 256, b_cnt = 256, b_done = al(sizeof(int) * (size_t)n), b_ctl = al(sizeof(StageCtl)),
                b_ovf = 256, b_fties = al(sizeof(int) * (size_t)n_fov), b_fcnt = al(4 * sizeof(unsigned long long) * (size_t)n_fov);
-  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf + b_fties + b_fcnt;
+  const size_t b_memo = al(sizeof(unsigned long long) * (size_t)n);
+  const size_t zero_bytes = b_state + b_nvox + b_nfev + b_memo + b_conv + b_niter + b_cnt + b_done + b_ctl + b_ovf + b_fties + b_fcnt;
   const size_t b_ps = al(sizeof(float) * 11 * (size_t)n);
   const size_t b_ncnt = al(sizeof(int) * (size_t)n), b_nidx = al(sizeof(int) * MAXNB * (size_t)n);
   const size_t b_tflag = al(sizeof(int) * (size_t)n), b_tlost = al(sizeof(unsigned long long) * SLOTS * (size_t)n);
@@ -1431,6 +1461,7 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
   f->d_state = base + o; o += b_state;
   f->d_nvox = base + o; o += b_nvox;
   f->d_nfev = base + o; o += b_nfev;
+  f->d_memo = base + o; o += b_memo;
   f->d_conv = base + o; o += b_conv;
   f->d_done = base + o; o += b_done;
   f->d_fov_ties = base + o; o += b_fties;
@@ -1537,6 +1568,7 @@ int set_fit_waitbound(int polls) {
   IA3_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_wait_bound), &v, sizeof(v)));
   return IA3_OK;
 }
+void set_fit_memo(int on) { g_fit_memo = on != 0; }
 void set_fit_kdq(int cap) { g_fit_kdq = cap < 1 ? 1 : (cap > KDQ_CAP ? KDQ_CAP : cap); }
 void fit_host_counters(const ia3_fitter* f, long long out[5]) {
   for (int k = 0; k < 5; ++k) out[k] = (long long)f->host_counters[k];
@@ -1841,6 +1873,7 @@ int ia3_fit_repeat(ia3_fitter* f, int* n_iter) {
     hipStream_t st = stream();
     IA3_HIP(hipMemset2DAsync((char*)f->d_state + offsetof(SeedState, conv), sizeof(SeedState), 0, sizeof(int), (size_t)f->n, st));
     IA3_HIP(hipMemsetAsync(f->d_niter, 0, sizeof(int), st));
+    IA3_HIP(hipMemsetAsync(f->d_memo, 0, sizeof(unsigned long long) * (size_t)f->n, st));   // a new repeatfit() refits every seed
     IA3_HIP(hipMemsetD32Async((hipDeviceptr_t)f->d_done, 1, (size_t)f->n, st));   // every seed has completed stage 0
     int rc = run_sweeps(f, 1, true); if (rc) return rc;
     if (n_iter) {   // callers that fetch results next pass NULL and read n_iter with them (one sync)

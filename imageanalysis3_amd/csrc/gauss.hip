@@ -905,6 +905,7 @@ int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_FIT_MERGE) { ia3k::set_fit_merge(value); return 0; }
   if (key == IA3_TUNE_WARP_ONEPASS) { ia3k::set_warp_onepass(value); return 0; }
   if (key == IA3_TUNE_FIT_KDQ) { ia3k::set_fit_kdq(value); return 0; }
+  if (key == IA3_TUNE_FIT_MEMO) { ia3k::set_fit_memo(value); return 0; }
   if (key == IA3_DEBUG_FIT_MAXFEV) { ia3k::set_fit_maxfev(value); return 0; }
   if (key == IA3_DEBUG_FIT_WAITBOUND) return ia3k::set_fit_waitbound(value);
   return set_error(IA3_EINVAL, "unknown tuning key");

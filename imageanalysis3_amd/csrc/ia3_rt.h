@@ -107,7 +107,7 @@ void gaussian_taps(double sigma, double truncate, std::vector<double>& w, int& r
 
 // ---- stage entry points implemented in the .hip files (device pointers, library stream) ------
 namespace ia3k { void set_dft_valu(int on); void set_fft_c2c(int on); void set_seed_dense(int on);
-void set_seed_strips(int on); void set_fit_nblist(int cap); void set_fit_fuse(int on); void set_fit_waves(int n); void set_fit_maxfev(int n); void set_fit_merge(int on); void set_warp_onepass(int v); void set_fit_kdq(int cap); int set_fit_waitbound(int polls); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
+void set_seed_strips(int on); void set_fit_nblist(int cap); void set_fit_fuse(int on); void set_fit_waves(int n); void set_fit_maxfev(int n); void set_fit_merge(int on); void set_warp_onepass(int v); void set_fit_kdq(int cap); void set_fit_memo(int on); int set_fit_waitbound(int polls); }   // fft_align.hip: test knob, see IA3_TUNE_DFT_VALU
 namespace ia3k {
 // separable Gaussian along all three axes: src -> dst, tmp is a same-size scratch stack.  axes: bit 0 = the axis-0
 // pass (src -> dst), bit 1 = the axis-1 and axis-2 passes (dst -> tmp -> dst); radius <= 3 runs fused (axes == 3 only).

@@ -109,6 +109,11 @@ int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines 
  * that needs more is finished on the host with the same tree (tests lower it to drive fields through that path).  Tables
  * are identical bit for bit. */
 #define IA3_TUNE_FIT_KDQ 13
+/* IA3_TUNE_FIT_MEMO: 1 (default) = a repeat sweep does not run a refit whose inputs — the image ball and the records of
+ * the overlapping seeds — are what they were at the seed's previous refit: the fit would return the same row and the
+ * seed is marked converged, as the reference's loop does after repeating it (External/Fitting_v4.py:651-680); 0 = every
+ * refit is run.  Tables and sweep counts are identical bit for bit; the evaluation counters count the fits that ran. */
+#define IA3_TUNE_FIT_MEMO 14
 /* IA3_DEBUG_FIT_MAXFEV: PROFILING ONLY, changes results: > 0 caps the function evaluations of every fit (MINPACK's maxfev),
  * which splits the fit kernel's time into its fixed and its per-evaluation part; 0 (default) = the reference's limits. */
 #define IA3_DEBUG_FIT_MAXFEV 100

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4, first GPU call: the whole GPU suite (with the carve-out counts printed), the two-rank rehearsal of bench.py on
+# one GPU call: the whole GPU suite (with the carve-out counts printed), the two-rank rehearsal of bench.py on
 # one device, the default bench line
 set -e -o pipefail
-OUT=gpurun_out/r04a
+OUT=gpurun_out/${1:-r04a}
 mkdir -p $OUT
 python -m pytest tests -m gpu -x -q -s > $OUT/pytest.log 2>&1 || { tail -60 $OUT/pytest.log; exit 1; }
 tail -3 $OUT/pytest.log

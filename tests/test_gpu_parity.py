@@ -338,6 +338,37 @@ def test_dependency_wait_abort_is_reported_and_the_library_recovers():
     assert_rows_close(t, g["table"])
 
 
+def test_refit_with_unchanged_neighbours_is_not_repeated():
+    """A repeat fit is a function of the image ball and of the overlapping seeds' records; when those have not changed
+    since the seed's previous refit, the sweep would reproduce that fit bit for bit (centre unchanged -> converged), so it
+    is not run (IA3_TUNE_FIT_MEMO).  Same tables, same sweep counts with the shortcut on and off — isolated, crowded and
+    uint16 fields (plateau twins refitting noise to maxfev are what it is for) — and fewer evaluations with it."""
+    import ctypes as C
+    from imageanalysis3_amd import synth, _lib as L
+    shape = (30, 160, 160)
+    ims = [synth.make_fov(shape, 60 if k % 2 == 0 else 90, 20 + k, layout="isolated" if k % 2 == 0 else "clustered", n_territories=5)[0]
+           for k in range(4)]
+    ims += [im.astype(np.uint16) for im in ims] + [build_case("club_f32"), build_case("hot_u16")]
+    sp, keep = L.make_seed_params(600.0, max_num_seeds=None)
+    fp = L.make_fit_params()
+    res = {}
+    try:
+        for memo in (1, 0):
+            L.check(L.lib().ia3_set_tuning(C.c_int(14), C.c_int(memo)))
+            res[memo] = [L.fit_fovs([im], sp, fp, in_flight=1) for im in ims]
+            res[memo].append(L.fit_fovs(ims[4:8], sp, fp, in_flight=4))     # the uint16 ones as one group fit
+    finally:
+        L.check(L.lib().ia3_set_tuning(C.c_int(14), C.c_int(1)))
+    saved = 0
+    for (t1, i1), (t0, i0) in zip(res[1], res[0]):
+        for a, b, ia, ib in zip(t1, t0, i1, i0):
+            assert np.array_equal(a, b)
+            assert ia["n_iter"] == ib["n_iter"] and ia["n_seeds"] == ib["n_seeds"]
+            assert ia["nfev"] <= ib["nfev"] and ia["fits"] <= ib["fits"]
+            saved += ib["fits"] - ia["fits"]
+    assert saved > 0
+
+
 def test_gauss_seidel_order_mid_size_exact():
     """333 seeds in 16 territories (218 overlapping pairs, 6 sweeps): the dependency-ordered kernel must reproduce
     the sequential reference order exactly — same n_iter, float32-identical rows — and do so on every run."""
