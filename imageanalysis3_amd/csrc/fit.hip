@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256) void nbr_build_k(const double* __restrict__ se
   if (i >= n_all) return;   // whole wave leaves together
   const int fov = fov_of[i];
   const int first = fov_start[fov], n = fov_start[fov + 1];   // candidates: the seeds of the same field
+  if (i >= n) return;   // a grid sized for a capacity (the count was still on the device at launch time)
   const double cz = seeds[3 * i], cx = seeds[3 * i + 1], cy = seeds[3 * i + 2];
   const int iz = (int)cz, ix = (int)cx, iy = (int)cy;
   int c = 0;
@@ -1258,13 +1259,21 @@ struct InitArgs {
   unsigned long long* counters;         // head block: [counters | n_iter | ctl | overflow], 256 bytes each
   int* niter; StageCtl* ctl; int* ovf;
   double* seeds; const double* src;     // optional device-to-device copy of 3 n doubles
-  int n;
+  int n;                                // seeds — or, with n_dev, the capacity the block was laid out for
+  // the seed count is still on the device (the seed stage's finish kernel leaves it there; the host learns it while this
+  // kernel and the neighbour lists already run): seeds = min(*n_dev, n_cut if > 0), and nothing if that exceeds n
+  const unsigned* n_dev; int n_cut;
   // one field of view: its three small tables are written here instead of uploaded (a copy from pageable memory in
   // front of the first fit launch costs the host ~20 us while the device idles)
   const void** ims; int* fov_start; int* fov_of; const void* im0;
 };
 __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
-  const int n = a.n;
+  int n = a.n;
+  if (a.n_dev) {
+    long long m = (long long)*a.n_dev;
+    if (a.n_cut > 0 && m > a.n_cut) m = a.n_cut;
+    n = m <= (long long)a.n ? (int)m : 0;   // more seeds than the block holds: the host makes a fitter of the right size
+  }
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
   for (size_t i = t; i < a.zero_words; i += step) a.zero0[i] = uint4{0u, 0u, 0u, 0u};
   for (size_t i = t; i < a.row_words; i += step) a.rows[i] = uint4{~0u, ~0u, ~0u, ~0u};
@@ -1277,7 +1286,7 @@ __global__ __launch_bounds__(256) void fit_init_k(InitArgs a) {
     if (t == 36) a.ims[0] = a.im0;
     if (t == 37) a.fov_start[0] = 0;
     if (t == 38) a.fov_start[1] = n;
-    for (size_t i = t; i < (size_t)n; i += step) a.fov_of[i] = 0;
+    for (size_t i = t; i < (size_t)a.n; i += step) a.fov_of[i] = 0;   // (the whole capacity: nbr_build_k's grid covers it)
   }
 }
 
@@ -1405,7 +1414,8 @@ static int ball_table(int radius, const signed char** d_ball, int* nball) {
 constexpr int MAX_FOV = 64;   // fields of view per fitter (their sweep counters share one 256-byte slot)
 struct FovSeeds { const ia3_stack* im; const double* host_zxy; const double* dev_zxy; int n; };
 
-static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params* p, ia3_fitter** out) {
+static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params* p, ia3_fitter** out,
+                           const unsigned* n_dev = nullptr, int n_cut = 0) {
   int rc = ensure_init(); if (rc) return rc;
   dbg_stamp("fit_create enter");
   if (!fovs || n_fov < 1 || n_fov > MAX_FOV || !p || !out) return set_error(IA3_EINVAL, "bad argument");
@@ -1519,6 +1529,7 @@ static int fit_create_impl(const FovSeeds* fovs, int n_fov, const ia3_fit_params
     ia.ovf = (int*)f->d_nbr_overflow;
     ia.seeds = (double*)f->d_seeds; ia.src = (n_fov == 1 && !fovs[0].host_zxy) ? fovs[0].dev_zxy : nullptr;
     ia.n = n;
+    ia.n_dev = n_dev; ia.n_cut = n_cut;
     ia.ims = n_fov == 1 ? (const void**)f->d_ims : nullptr;
     ia.fov_start = (int*)f->d_fov_start; ia.fov_of = (int*)f->d_fov_of; ia.im0 = fovs[0].im->d;
     size_t words = ia.zero_words > ia.row_words ? ia.zero_words : ia.row_words;
@@ -1577,6 +1588,23 @@ int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, cons
   if (!im || n < 0 || (n > 0 && !d_centers_zxy)) return set_error(IA3_EINVAL, "bad argument");
   const FovSeeds one{im, nullptr, d_centers_zxy, n};
   return fit_create_impl(&one, 1, p, out);
+}
+// A fitter made BEFORE the host knows the seed count: laid out for `capacity` seeds, its set-up kernels (fit_init_k,
+// nbr_build_k) read the count the seed stage leaves on the device (min(*d_count, n_cut if > 0)) and are queued right
+// behind it; fit_set_count gives the host side the number once it has arrived.  (The host used to learn the count first
+// and queue the three launches afterwards: 45-70 us of idle device between the seed finish and the fit, kernel trace of
+// profiles/r04j.)  A count above the capacity: destroy this fitter and make one the ordinary way.
+int fit_create_ahead(const ia3_stack* im, const double* d_centers_zxy, int capacity, const unsigned* d_count, int n_cut,
+                     const ia3_fit_params* p, ia3_fitter** out) {
+  if (!im || capacity < 1 || !d_centers_zxy || !d_count) return set_error(IA3_EINVAL, "bad argument");
+  const FovSeeds one{im, nullptr, d_centers_zxy, capacity};
+  return fit_create_impl(&one, 1, p, out, d_count, n_cut);
+}
+int fit_set_count(ia3_fitter* f, int n) {
+  if (!f || n < 0 || n > f->n || f->ims.size() != 1) return set_error(IA3_EINVAL, "bad seed count");
+  f->n = n;
+  f->fov_start.assign({0, n});
+  return IA3_OK;
 }
 // one fitter over several fields of view (same shape and dtype, at most fit_max_fovs() of them): seeds resident per field
 int fit_max_fovs() { return MAX_FOV; }

@@ -2,6 +2,7 @@
 #pragma once
 #include "ia3_rt.h"
 #include <functional>
+struct ia3_fitter;
 #include <string>
 
 namespace ia3pipe {
@@ -14,6 +15,8 @@ int filter_rows(const ia3_stack* im, const float* ps, int n, float* out_rows, in
 // fit in stats5 (fits, evaluations, voxel evaluations, wait cycles, wave cycles) when not NULL
 int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, const ia3_fit_params* fp, float* out_rows,
                     int capacity, int* n_rows, int* n_iter, long long* stats5);
+
+int fit_with(ia3_fitter* f, const ia3_stack* im, int n, float* out_rows, int capacity, int* n_rows, int* n_iter, long long* stats5);
 
 // One image of a group fit: its resident stack, its n seeds (n x 3 float64 on the device) and where its table goes.
 struct FitItem {

@@ -141,12 +141,21 @@ struct SeedDev {
   const double* d_zxy = nullptr;
   const double* d_h = nullptr;
   void* hold = nullptr;     // scratch block that owns d_zxy / d_h; release with ws_put
+  // called (if set) when the device-side finish has been QUEUED and before the host waits for its count: d_zxy is where
+  // the seeds will be, *d_count how many survive (before the max_num_seeds cut), both valid once the stream gets there.
+  // ia3_fit_fov_dev queues the fitter's set-up kernels from here, behind the seed stage.
+  void (*ahead)(void* ctx, const double* d_zxy, const unsigned* d_count, int max_num_seeds) = nullptr;
+  void* ahead_ctx = nullptr;
   SeedOut host;
   ~SeedDev() { if (hold) ia3rt::ws_put(hold); }
 };
 int dog_seed_dev(const ia3_stack* im, const ia3_seed_params& p, SeedDev& out);
 // fitter from centres that are already resident (n x 3 float64)
 int fit_create_dev(const ia3_stack* im, const double* d_centers_zxy, int n, const ia3_fit_params* p, ia3_fitter** out);
+// the same before the host knows the count (see fit.hip): capacity seeds laid out, count = min(*d_count, n_cut if > 0)
+int fit_create_ahead(const ia3_stack* im, const double* d_centers_zxy, int capacity, const unsigned* d_count, int n_cut,
+                     const ia3_fit_params* p, ia3_fitter** out);
+int fit_set_count(ia3_fitter* f, int n);
 // one fitter over several resident fields of view (same shape and dtype; at most fit_max_fovs()): seeds of field k =
 // n_seeds[k] x 3 float64 at d_centers_zxy[k].  fit_fov_results (after ia3_fit_results(_ex)): per field its sweep count and
 // its fits / evaluations / voxel evaluations; fit_fov_starts: n_fov + 1 row offsets of the fields in the row table

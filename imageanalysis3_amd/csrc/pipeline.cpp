@@ -50,6 +50,12 @@ int fit_known_seeds(const ia3_stack* im, const ia3k::SeedDev& sd, int n, const i
     for (int i = 0; i < n; ++i) { c[3 * i] = sd.host.zxyh[4 * i]; c[3 * i + 1] = sd.host.zxyh[4 * i + 1]; c[3 * i + 2] = sd.host.zxyh[4 * i + 2]; }
     rc = ia3_fit_create(im, c.data(), n, fp, &f); if (rc) return rc;
   }
+  return fit_with(f, im, n, out_rows, capacity, n_rows, n_iter, stats5);
+}
+
+// firstfit + repeatfit + row filters with a fitter that is ready (destroyed here)
+int fit_with(ia3_fitter* f, const ia3_stack* im, int n, float* out_rows, int capacity, int* n_rows, int* n_iter, long long* stats5) {
+  int rc;
   static const bool dbg = getenv("IA3_DEBUG_TIMES") != nullptr;
   auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   const double t0 = dbg ? now() : 0;
@@ -82,13 +88,32 @@ extern "C" int ia3_fit_fov_dev(const ia3_stack* im, const ia3_seed_params* sp, c
   // images in flight because every fit launch then carries 16 k mostly empty blocks; profiles/r02b/ab_sync.log.)
   PutDefer defer_puts;   // the seed stage's scratch goes back to the cache behind the first fit launch, not in front of it
   ia3k::SeedDev sd;
+  // The fitter is made while the seed count is still on the device: its set-up kernels are queued right behind the seed
+  // stage's finish and run while the host waits for the count.  Laid out for 1.5 x the seeds of this thread's previous
+  // image (at least 8192); an image with more gets a fitter of the right size afterwards.
+  struct Ahead { const ia3_stack* im; const ia3_fit_params* fp; ia3_fitter* f; int cap; int rc; } ah{im, fp, nullptr, 0, 0};
+  static thread_local int t_last_n = 0;
+  ah.cap = t_last_n + t_last_n / 2 < 8192 ? 8192 : t_last_n + t_last_n / 2;
+  sd.ahead_ctx = &ah;
+  sd.ahead = [](void* ctx, const double* d_zxy, const unsigned* d_count, int max_num_seeds) {
+    Ahead* a = (Ahead*)ctx;
+    if (a->f) { ia3_fit_destroy(a->f); a->f = nullptr; }   // the seed stage started over (dense filter after an overflow)
+    a->rc = ia3k::fit_create_ahead(a->im, d_zxy, a->cap, d_count, max_num_seeds, a->fp, &a->f);
+    if (a->rc) a->f = nullptr;
+  };
   dbg_stamp("fit_fov_dev enter");
-  rc = ia3k::dog_seed_dev(im, *sp, sd); if (rc) return rc;
+  rc = ia3k::dog_seed_dev(im, *sp, sd);
+  if (rc) { if (ah.f) ia3_fit_destroy(ah.f); return rc; }
   dbg_stamp("seed stage returned");
   const int n = sd.on_device ? sd.n : (int)(sd.host.zxyh.size() / 4);
   if (n_seeds) *n_seeds = n;
+  t_last_n = n;
+  if (ah.f && (!sd.on_device || n == 0 || n > ah.cap)) { ia3_fit_destroy(ah.f); ah.f = nullptr; }   // not the common case
   if (n == 0) return IA3_OK;  // fitting.py:206-207
-  return ia3pipe::fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter, nullptr);
+  if (!ah.f) return ia3pipe::fit_known_seeds(im, sd, n, fp, out_rows, capacity, n_rows, n_iter, nullptr);
+  rc = ia3k::fit_set_count(ah.f, n);
+  if (rc) { ia3_fit_destroy(ah.f); return rc; }
+  return ia3pipe::fit_with(ah.f, im, n, out_rows, capacity, n_rows, n_iter, nullptr);
 }
 
 extern "C" int ia3_fit_fov_wait_share(int64_t* wait_cycles, int64_t* wave_cycles) {

@@ -1091,6 +1091,7 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       FinCtl hfc;
       fe = hipGetLastError();
       dbg_stamp("seed stage queued");
+      if (fe == hipSuccess && dev->ahead) dev->ahead(dev->ahead_ctx, (const double*)(fb + o_zxy), (const unsigned*)&fc->n_alive, p.max_num_seeds);
       if (fe == hipSuccess && mail_host) {
         // the count arrives in the pinned mailbox microseconds after the kernel's store: poll it (a copy into pageable
         // memory + a sleeping synchronise cost 30-50 us of idle device between the detector and the fit)
