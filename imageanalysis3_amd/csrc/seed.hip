@@ -660,13 +660,18 @@ void launch_detect(int W, const void* mx, const void* mn, int Z, int X, int Y, i
 namespace {
 
 // ---- tail of get_seeds on the device (fitting.py:113-150) ---------------------------------------------------------
-// level pick, hot-column vote, sort by height and truncation for up to FIN_CAP candidates, as four small kernels
-// of all-pairs work (n = 5 000 ... 13 000 in production: 25 ... 170 M comparisons spread over 160 ... 400 blocks; blocks past
-// the last candidate leave at once): no sort network, no hash table,
-// and the seed list never leaves HBM between the detector and the fitter.
-constexpr unsigned FIN_CAP = 32768;   // (8192 until round 4: illumination-corrected production images leave ~13 k candidates at the lowest dynamic level)
-constexpr int FIN_S = 8;   // slices of the all-pairs loops (grid.y)
-struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; unsigned done, pad[3]; };   // n_cand / overflow mirror SeedCtl: one read-back; done: blocks of fin_scatter_k that have stored their seeds
+// level pick, hot-column vote, sort by height and truncation as four small kernels: one block picks the level and packs
+// the candidates that pass it (a corrected production image leaves ~13 000 at the lowest dynamic level and ~5 000 at the
+// one that is taken), then all-pairs work over those (n = 5 000: 25 M comparisons spread over 160 blocks; unique 64-bit
+// keys => rank = position): no sort network, no hash table, and the seed list never leaves HBM between the detector and
+// the fitter.  More candidates than FIN_CAP, or more than FIN_KEYS at the chosen level: the host's finish takes over.
+// (Round 4 also built the whole tail as ONE single-block kernel — keys in 128 KB of LDS, two bitonic sorts — and measured
+// it at 163-173 us against 46-60 us for these four launches: 182 compare-exchange stages of a 16-wave block, each with
+// its barrier, cost ~0.9 us apiece.)
+constexpr unsigned FIN_CAP = 32768;    // candidates the first kernel looks at
+constexpr unsigned FIN_KEYS = 16384;   // ... of which at most this many may pass the chosen level
+constexpr int FIN_S = 8;               // slices of the all-pairs loops (grid.y)
+struct FinCtl { unsigned n_alive; int chosen; unsigned n_cand, overflow; unsigned done, n_kept, pad[2]; };   // n_cand / overflow mirror SeedCtl
 
 __device__ __forceinline__ unsigned fin_n(const SeedCtl* sctl) { return sctl->n_cand < FIN_CAP ? sctl->n_cand : FIN_CAP; }
 __device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h desc, then z, x, y desc (finish_seeds)
@@ -675,67 +680,87 @@ __device__ __forceinline__ unsigned long long fin_key(const Cand& k) {   // h de
   return ((unsigned long long)u << 32) | ((unsigned long long)k.z << 24) | ((unsigned long long)k.x << 12) | (unsigned long long)k.y;
 }
 
+// one block: dynamic threshold (first level whose count reaches min_dynamic_seeds, else the last one, :113-125), the
+// candidates that pass it packed into kc[] (any order), the work arrays of the next kernels cleared
 __global__ __launch_bounds__(1024) void fin_levels_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
-                                                     int min_dyn, FinCtl* __restrict__ fc) {
+                                                     int min_dyn, FinCtl* __restrict__ fc, Cand* __restrict__ kc,
+                                                     unsigned* __restrict__ hotcnt, unsigned* __restrict__ rank) {
   __shared__ unsigned cnt[MAXLEV];
-  if (threadIdx.x < MAXLEV) cnt[threadIdx.x] = 0;
+  __shared__ unsigned nk;
+  __shared__ int chosen_s;
+  const unsigned tid = threadIdx.x;
+  if (tid < MAXLEV) cnt[tid] = 0;
+  if (tid == 0) nk = 0;
   __syncthreads();
   const unsigned n = fin_n(sctl);
-  for (unsigned i = threadIdx.x; i < n; i += 1024) {
+  for (unsigned i = tid; i < n; i += 1024) {
     const double h = (double)c[i].h;
     for (int l = 0; l < lev.n; ++l) if (h >= lev.th[l]) atomicAdd(&cnt[l], 1u);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     int chosen = lev.n - 1;
     for (int l = 0; l < lev.n; ++l) if ((long long)cnt[l] >= (long long)min_dyn) { chosen = l; break; }
-    fc->chosen = chosen;
+    chosen_s = chosen;
   }
+  __syncthreads();
+  const double th = lev.th[chosen_s];
+  for (unsigned i0 = 0; i0 < n; i0 += 1024) {   // wave-aggregated append
+    const unsigned i = i0 + tid;
+    Cand k{0, 0, 0, 0.f};
+    if (i < n) k = c[i];
+    const bool keep = i < n && (double)k.h >= th;
+    const unsigned long long m = __ballot(keep);
+    unsigned base = 0;
+    if ((tid & 63) == 0 && m) base = atomicAdd(&nk, (unsigned)__popcll(m));
+    base = __shfl(base, 0, 64);
+    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+    if (keep && pos < FIN_KEYS) kc[pos] = k;
+  }
+  __syncthreads();
+  const unsigned kept = nk < FIN_KEYS ? nk : FIN_KEYS;
+  for (unsigned i = tid; i < kept; i += 1024) { hotcnt[i] = 0u; rank[i] = 0u; }
+  if (tid == 0) { fc->chosen = chosen_s; fc->n_kept = nk; fc->n_alive = 0u; fc->done = 0u; }
 }
+__device__ __forceinline__ unsigned fin_kept(const FinCtl* fc) { return fc->n_kept <= FIN_KEYS ? fc->n_kept : 0u; }   // too many: nothing to do
 
-// hotcnt[i] = number of kept candidates in the (x, y) column of kept candidate i
-__global__ __launch_bounds__(256) void fin_hot_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
-                                                 const FinCtl* __restrict__ fc, unsigned* __restrict__ hotcnt) {
+// hotcnt[i] = number of packed candidates in the (x, y) column of packed candidate i
+__global__ __launch_bounds__(256) void fin_hot_k(const Cand* __restrict__ kc, const FinCtl* __restrict__ fc, unsigned* __restrict__ hotcnt) {
   __shared__ int tx[256], ty[256];
-  const unsigned n = fin_n(sctl);
+  const unsigned n = fin_kept(fc);
   if (blockIdx.x * 256 >= n) return;   // whole block
-  const double th = lev.th[fc->chosen];
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  const bool mine = i < n && (double)c[i].h >= th;
-  const int xi = i < n ? c[i].x : -1, yi = i < n ? c[i].y : -1;
+  const int xi = i < n ? kc[i].x : -1, yi = i < n ? kc[i].y : -1;
   const unsigned per = (n + FIN_S - 1) / FIN_S, j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
   unsigned cnt = 0;
   for (unsigned jb = j0; jb < j1; jb += 256) {
     const unsigned j = jb + threadIdx.x;
     __syncthreads();
-    const bool kj = j < j1 && (double)c[j].h >= th;
-    tx[threadIdx.x] = kj ? c[j].x : -2;
-    ty[threadIdx.x] = kj ? c[j].y : -2;
+    tx[threadIdx.x] = j < j1 ? kc[j].x : -2;
+    ty[threadIdx.x] = j < j1 ? kc[j].y : -2;
     __syncthreads();
     const unsigned m = j1 - jb < 256 ? j1 - jb : 256;
     for (unsigned t = 0; t < m; ++t) cnt += (tx[t] == xi && ty[t] == yi);
   }
-  if (mine && cnt) atomicAdd(&hotcnt[i], cnt);
+  if (i < n && cnt) atomicAdd(&hotcnt[i], cnt);
 }
 
-// rank[i] = number of surviving candidates that sort before candidate i; fc->n_alive = survivors
-__global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
-                                                  FinCtl* __restrict__ fc, const unsigned* __restrict__ hotcnt, int hot_th,
-                                                  unsigned* __restrict__ rank) {
+// rank[i] = number of surviving candidates that sort before packed candidate i; fc->n_alive = survivors
+__global__ __launch_bounds__(256) void fin_rank_k(const Cand* __restrict__ kc, FinCtl* __restrict__ fc, const unsigned* __restrict__ hotcnt,
+                                                  int hot_th, unsigned* __restrict__ rank) {
   __shared__ unsigned long long tk[256];
-  const unsigned n = fin_n(sctl);
+  const unsigned n = fin_kept(fc);
   if (blockIdx.x * 256 >= n) return;   // whole block
-  const double th = lev.th[fc->chosen];
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  const bool alive = i < n && (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
-  const unsigned long long ki = i < n ? fin_key(c[i]) : ~0ull;
+  const bool alive = i < n && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
+  const unsigned long long ki = i < n ? fin_key(kc[i]) : ~0ull;
   const unsigned per = (n + FIN_S - 1) / FIN_S, j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
   unsigned r = 0;
   for (unsigned jb = j0; jb < j1; jb += 256) {
     const unsigned j = jb + threadIdx.x;
     __syncthreads();
-    const bool aj = j < j1 && (double)c[j].h >= th && (hot_th <= 0 || hotcnt[j] < (unsigned)hot_th);
-    tk[threadIdx.x] = aj ? fin_key(c[j]) : 0ull;   // 0 sorts after every real key (a real key has bit 63 or a positive h)
+    const bool aj = j < j1 && (hot_th <= 0 || hotcnt[j] < (unsigned)hot_th);
+    tk[threadIdx.x] = aj ? fin_key(kc[j]) : 0ull;   // 0 sorts after every real key (a real key has bit 63 or a positive h)
     __syncthreads();
     const unsigned m = j1 - jb < 256 ? j1 - jb : 256;
     for (unsigned t = 0; t < m; ++t) r += tk[t] > ki;
@@ -746,21 +771,20 @@ __global__ __launch_bounds__(256) void fin_rank_k(const SeedCtl* __restrict__ sc
   }
 }
 
-__global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ c, Levels lev,
-                                                     const FinCtl* fc, const unsigned* __restrict__ hotcnt,
-                                                     int hot_th, const unsigned* __restrict__ rank, int max_num,
-                                                     double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw,
+__global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__ sctl, const Cand* __restrict__ kc, const FinCtl* fc,
+                                                     const unsigned* __restrict__ hotcnt, int hot_th, const unsigned* __restrict__ rank,
+                                                     int max_num, double* __restrict__ zxy, double* __restrict__ hh, FinCtl* fcw,
                                                      const SeedCtl* __restrict__ lazy, unsigned cap0,
                                                      volatile unsigned* __restrict__ mail, unsigned seq) {
-  const unsigned n = fin_n(sctl);
+  const unsigned n = fin_kept(fc);
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
-    const double th = lev.th[fc->chosen];
-    const bool alive = (double)c[i].h >= th && (hot_th <= 0 || hotcnt[i] < (unsigned)hot_th);
+    const bool alive = hot_th <= 0 || hotcnt[i] < (unsigned)hot_th;
     const unsigned r = alive ? rank[i] : 0u;
     if (alive && !(max_num > 0 && r >= (unsigned)max_num)) {
-      zxy[3 * r] = c[i].z; zxy[3 * r + 1] = c[i].x; zxy[3 * r + 2] = c[i].y;
-      hh[r] = (double)c[i].h;
+      const Cand k = kc[i];
+      zxy[3 * r] = k.z; zxy[3 * r + 1] = k.x; zxy[3 * r + 2] = k.y;
+      hh[r] = (double)k.h;
     }
   }
   // The host polls the mailbox and may hand the seed list to ANOTHER stream (the group fitter of ia3_fit_fovs) as soon as
@@ -771,9 +795,10 @@ __global__ __launch_bounds__(256) void fin_scatter_k(const SeedCtl* __restrict__
   if (threadIdx.x != 0) return;
   if (atomicAdd(&fcw->done, 1u) != gridDim.x - 1) return;
   __threadfence();
-  // bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter)
+  // overflow bit 1: the lazy path's first-stage list overflowed (the caller falls back to the dense filter); bit 2: more
+  // candidates at the chosen level than FIN_KEYS (the host's finish takes over; n_alive is 0 then)
   const unsigned nc = sctl->n_cand;
-  const unsigned ov = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u);
+  const unsigned ov = sctl->overflow | ((lazy && (lazy->overflow || lazy->n_cand > cap0)) ? 2u : 0u) | (fc->n_kept > FIN_KEYS ? 4u : 0u);
   fcw->n_cand = nc;
   fcw->overflow = ov;
   if (mail) {   // the four control words straight into the host's pinned mailbox, then the sequence number it polls
@@ -956,8 +981,9 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
   Scratch buf0(HDR + (size_t)capacity * sizeof(Cand));
   if (!buf0.p) return IA3_ENOMEM;
   const bool dev_finish = dev && Z <= 256 && X <= 4096 && Y <= 4096;
-  const size_t o_hot = sizeof(FinCtl), o_rank = o_hot + 4 * (size_t)FIN_CAP, o_zxy = o_rank + 4 * (size_t)FIN_CAP,
-               o_h = o_zxy + 24 * (size_t)FIN_CAP, fin_bytes = o_h + 8 * (size_t)FIN_CAP;
+  // [FinCtl | hot | rank | zxy | h | packed candidates]
+  const size_t o_hot = 256, o_rank = o_hot + 4 * (size_t)FIN_KEYS, o_zxy = o_rank + 4 * (size_t)FIN_KEYS,
+               o_h = o_zxy + 24 * (size_t)FIN_KEYS, o_kc = o_h + 8 * (size_t)FIN_KEYS, fin_bytes = o_kc + sizeof(Cand) * (size_t)FIN_KEYS;
   void* fin = nullptr;
   if (dev_finish) {
     fin = ws_get(fin_bytes);
@@ -970,7 +996,6 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
     cleared = true;
     const hipStream_t cs = stream();   // the auxiliary stream inside an AuxResume
     IA3_HIP(hipMemsetAsync(buf0.p, 0, HDR, cs));
-    if (fin) IA3_HIP(hipMemsetAsync(fin, 0, o_zxy, cs));
     return IA3_OK;
   };
   // The two filters are independent: the front (short, memory/LDS-bound) one runs on the auxiliary stream next to the
@@ -1071,8 +1096,6 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       char* fb = (char*)fin;
       hipError_t fe;
       FinCtl* fc = (FinCtl*)fb;
-      unsigned* hot = (unsigned*)(fb + o_hot);
-      unsigned* rank = (unsigned*)(fb + o_rank);
       const int hot_th = p.remove_hot_pixel ? p.hot_pixel_th : 0;
       void *mail_host = nullptr, *mail_dev = nullptr;
       static thread_local unsigned t_seq = 0;
@@ -1080,11 +1103,14 @@ static int dog_seed_impl(const ia3_stack* im, const ia3_seed_params& p, SeedOut&
       if (host_mailbox(64, &mail_host, &mail_dev) != IA3_OK) { mail_host = mail_dev = nullptr; }
       {
         ProfScope pf("seed_finish");
-        hipLaunchKernelGGL(fin_levels_k, dim3(1), dim3(1024), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, p.min_dynamic_seeds, fc);
+        unsigned* hot = (unsigned*)(fb + o_hot);
+        unsigned* rank = (unsigned*)(fb + o_rank);
+        Cand* kc = (Cand*)(fb + o_kc);
+        hipLaunchKernelGGL(fin_levels_k, dim3(1), dim3(1024), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, p.min_dynamic_seeds, fc, kc, hot, rank);
         if (hot_th > 0)
-          hipLaunchKernelGGL(fin_hot_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc, hot);
-        hipLaunchKernelGGL(fin_rank_k, dim3(FIN_CAP / 256, FIN_S), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, fc, (const unsigned*)hot, hot_th, rank);
-        hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_CAP / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)dcand, lev, (const FinCtl*)fc,
+          hipLaunchKernelGGL(fin_hot_k, dim3(FIN_KEYS / 256, FIN_S), dim3(256), 0, s, (const Cand*)kc, (const FinCtl*)fc, hot);
+        hipLaunchKernelGGL(fin_rank_k, dim3(FIN_KEYS / 256, FIN_S), dim3(256), 0, s, (const Cand*)kc, fc, (const unsigned*)hot, hot_th, rank);
+        hipLaunchKernelGGL(fin_scatter_k, dim3(FIN_KEYS / 256), dim3(256), 0, s, (const SeedCtl*)dctl, (const Cand*)kc, (const FinCtl*)fc,
                            (const unsigned*)hot, hot_th, (const unsigned*)rank, p.max_num_seeds, (double*)(fb + o_zxy), (double*)(fb + o_h), fc,
                            lazy ? (const SeedCtl*)dlazy : (const SeedCtl*)nullptr, LAZY_CAP, (volatile unsigned*)mail_dev, seq);
       }
