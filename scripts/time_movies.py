@@ -53,7 +53,7 @@ def main():
         bw = bench._pcie_GBps(L, raws[0])
         print("PCIe %.1f GB/s -> %.4f s per movie" % (bw, raws[0].nbytes / 1e9 / bw), flush=True)
         res["pcie_GBps"] = bw
-        shapes = ((3, 12, 2),) if os.environ.get('IA3_MOVIE_ONLY') else ((2, 12, 2), (3, 12, 2), (3, 9, 3), (2, 6, 2), (4, 12, 3))
+        shapes = ((3, 12, 2),) if os.environ.get('IA3_MOVIE_ONLY') else ((2, 12, 2), (3, 12, 2), (3, 24, 3), (3, 18, 3), (2, 24, 2), (4, 24, 3))
         for (nc, grp, ahead) in shapes:
             plan = MoviePlan(chs[:3], ref_image=dref, single_im_size=[Z, X, Y], all_channels=chs, num_buffer_frames=0,
                              num_empty_frames=0, calculate_drift=True, corr_channels=chs[:3], illumination_profile=illum,
