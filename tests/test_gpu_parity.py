@@ -1464,6 +1464,59 @@ def test_batch_process_images_to_spots_threads_equal_sequential(tmp_path, monkey
         _spot_tables_close(par['spots'][2 * r:2 * r + 2], gold['w_spots'][:2], "round %d" % r)
 
 
+@pytest.mark.parametrize("variant", ["full", "silent_no_warp", "highpass", "no_drift_647_only", "no_hot_f64_illum"])
+def test_movie_pipeline_options_equal_the_per_movie_calls(variant):
+    """ia3_process_movies (io_tools.load.MoviePlan) against correct_fov_image + fit_fov_image called movie by movie, over
+    the option sets of the chain fixtures (z shift, silent call = no warp, high-pass without bleedthrough / chromatic
+    correction, a single reference channel without drift, float64 illumination without hot-pixel removal) and over the
+    fit options the plan carries (seed cap, global and local background normalisation): corrected images, drifts and
+    tables identical; movies from host arrays, two per call; then the drift measured against a bead image."""
+    import contextlib, io
+    from conftest import build_chain_case, chain_kwargs
+    from imageanalysis3_amd.io_tools.load import correct_fov_image, MoviePlan
+    from imageanalysis3_amd.spot_tools.fitting import fit_fov_image
+    case = build_chain_case()
+    sel, kw = chain_kwargs(case, variant)
+    raw = case["raw"]
+    drift = kw.pop("drift")
+    th = {c: 300. for c in sel}
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_ims, ref_drift, ref_flag = correct_fov_image(raw, sel, drift=drift, return_drift=True, **kw)
+    for fit_kw in (dict(max_num_seeds=None), dict(max_num_seeds=20, normalize_local=True), dict(normalize_background=True)):
+        ref_tabs = [fit_fov_image(im, c, th_seed=300, verbose=False, **fit_kw) for im, c in zip(ref_ims, sel)]
+        plan = MoviePlan(sel, calculate_drift=False, seed_th=th, fitting_args=dict(fit_kw), frames=raw.shape[0], **kw)
+        out = plan.run([raw, raw.copy()], drifts_in=[drift, drift], measure_drift=False, want_images=True)
+        assert len(out) == 2
+        for o in out:
+            assert o["drift_flag"] == ref_flag
+            assert np.array_equal(o["drift"], np.asarray(ref_drift, dtype=np.float64))
+            for a, b in zip(o["images"], ref_ims):
+                assert np.array_equal(a, b)
+            for t, r, ns in zip(o["tables"], ref_tabs, o["n_seeds"]):
+                if ns == 0:
+                    assert len(r) == 0
+                else:
+                    assert t.shape == r.shape and np.array_equal(t, r)
+        plan2 = MoviePlan(sel, calculate_drift=False, seed_th=th, fitting_args=dict(fit_kw), frames=raw.shape[0], fit_spots=False, **kw)
+        o2 = plan2.run([raw], drifts_in=[drift], measure_drift=False, want_images=True)[0]
+        assert all(np.array_equal(a, b) for a, b in zip(o2["images"], ref_ims)) and all(len(t) == 0 for t in o2["tables"])
+    if variant != "full":
+        return
+    # measured drift: the bead channel against a moved copy of itself
+    nb, Z = case["nb"], case["Z"]
+    bead = np.ascontiguousarray(raw[nb + (3 - nb) % 4::4][:Z])
+    bead_ref = np.roll(bead, (1, -2), axis=(1, 2))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_ims, ref_drift, ref_flag = correct_fov_image(raw, sel, calculate_drift=True, ref_filename=bead_ref, return_drift=True, **kw)
+    plan = MoviePlan(sel, ref_image=bead_ref, calculate_drift=True, seed_th=th, fitting_args=dict(max_num_seeds=None),
+                     frames=raw.shape[0], **kw)
+    o = plan.run([raw], want_images=True)[0]
+    assert o["drift_flag"] == ref_flag and np.array_equal(o["drift"], ref_drift)
+    assert np.abs(o["drift"]).max() > 0.5
+    for a, b in zip(o["images"], ref_ims):
+        assert np.array_equal(a, b)
+
+
 def test_movie_file_streams_into_a_resident_stack(tmp_path):
     """ia3_stack_load_file: pieces larger and smaller than the staging buffers, an offset, big-endian files; equal to
     read_dax + upload."""
