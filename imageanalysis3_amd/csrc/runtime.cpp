@@ -37,6 +37,7 @@ struct ThreadCtx {
   void* mail_dev = nullptr;
   size_t mail_bytes = 0;
   hipEvent_t mail_ev = nullptr;  // for wait_event_spin
+  ~ThreadCtx();
 };
 static thread_local ThreadCtx t_ctx;
 
@@ -44,6 +45,20 @@ static thread_local ThreadCtx t_ctx;
 // recorded there at release time; a different stream that picks it up waits for that event first.
 struct WsEntry { void* p; size_t bytes; bool busy; hipStream_t last; hipEvent_t ev; };
 static std::vector<WsEntry> g_ws;
+
+// A host thread that ends hands its streams, events and mailbox back: callers that start a pool of threads per batch
+// (ThreadPoolExecutor around fit_fov_image) would otherwise leave two streams per dead thread multiplexed on the 16
+// hardware queues next to the live ones.  The process's first stream (g_stream) stays; after a fork nothing here is ours.
+ThreadCtx::~ThreadCtx() {
+  if (!main || pid != getpid() || main == g_stream) return;
+  (void)hipStreamSynchronize(main);
+  if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+  (void)hipStreamDestroy(main);
+  if (fork) (void)hipEventDestroy(fork);
+  if (join) (void)hipEventDestroy(join);
+  if (mail_ev) (void)hipEventDestroy(mail_ev);
+  if (mail_host) (void)hipHostFree(mail_host);
+}
 
 int set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -190,6 +205,11 @@ void dbg_stamp(const char* what) {
 }
 int num_cus() { return g_cus; }
 
+// how often the cache went to the driver (ia3_workspace_stats): a steady-state loop should show none
+static unsigned long long g_ws_mallocs = 0, g_ws_frees = 0;
+static double g_ws_ms = 0.0;
+static double ws_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 void* ws_get(size_t bytes) {
   if (bytes == 0) bytes = 256;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -207,26 +227,31 @@ void* ws_get(size_t bytes) {
     return e.p;
   }
   void* p = nullptr;
+  const double ta = ws_now_ms();
   if (hipMalloc(&p, bytes) != hipSuccess) {
-    for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+    for (auto& e : g_ws) if (!e.busy && e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; ++g_ws_frees; }
     if (hipMalloc(&p, bytes) != hipSuccess) { set_error(IA3_ENOMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
   }
+  ++g_ws_mallocs; g_ws_ms += ws_now_ms() - ta;
   for (auto& e : g_ws) if (!e.p) { e.p = p; e.bytes = bytes; e.busy = true; e.last = nullptr; return p; }
   g_ws.push_back(WsEntry{p, bytes, true, nullptr, nullptr});
   return p;
 }
 // idle blocks above this total go back to the driver (largest first): stacks of many different sizes would otherwise
-// pile up in a long-running process.  IA3_CACHE_GB overrides the default of half the device's memory (144 GB of 288; it
-// was 64 GB until round 4: the movie pipeline — three movies in correction, twelve images waiting for their group fit —
-// parks 40-60 GB of blocks between uses, and every trim is a hipFree that synchronises the device and is followed by a
-// hipMalloc of the same size a moment later: a 200 ms stall of all streams in the timeline of profiles/r04f).
+// pile up in a long-running process.  IA3_CACHE_GB overrides the default of three quarters of the device's memory (216 GB
+// of 288; it was 64 GB until round 4: the movie pipeline — three movies in correction, twelve images waiting for their
+// group fit — parks 40-60 GB of blocks between uses, and every trim is a hipFree that synchronises the device and is
+// followed by a hipMalloc of the same size a moment later: a 200 ms stall of all streams in the timeline of
+// profiles/r04f; with half the memory as the limit the same stalls came back inside bench.py, whose earlier legs leave
+// ~100 GB of blocks of other sizes behind, profiles/r04r).  A hipMalloc that fails frees every idle block and tries again
+// (ws_get), so the limit is a courtesy to other processes on the card, not a safety net.
 static size_t ws_idle_limit() {
   static const size_t lim = [] {
     const char* e = getenv("IA3_CACHE_GB");
     double gb = e ? atof(e) : 0.0;
     if (!e) {
       size_t fr = 0, tot = 0;
-      gb = hipMemGetInfo(&fr, &tot) == hipSuccess ? (double)tot / 1073741824.0 * 0.5 : 64.0;
+      gb = hipMemGetInfo(&fr, &tot) == hipSuccess ? (double)tot / 1073741824.0 * 0.75 : 64.0;
       if (gb < 16.0) gb = 16.0;
     }
     return (size_t)((gb > 0 ? gb : 0) * 1073741824.0);
@@ -241,7 +266,9 @@ static void ws_trim_locked() {
     for (size_t i = 0; i < g_ws.size(); ++i)
       if (!g_ws[i].busy && g_ws[i].p && (big < 0 || g_ws[i].bytes > g_ws[big].bytes)) big = (int)i;
     if (big < 0) break;
+    const double ta = ws_now_ms();
     (void)hipFree(g_ws[big].p);   // synchronises the device: rare by construction
+    ++g_ws_frees; g_ws_ms += ws_now_ms() - ta;
     idle -= g_ws[big].bytes;
     g_ws[big].p = nullptr; g_ws[big].bytes = 0; g_ws[big].last = nullptr;
   }
@@ -377,6 +404,14 @@ int ia3_sync(void) {
 }
 void* ia3_stream(void) { return ensure_init() ? nullptr : (void*)stream(); }
 int ia3_release_workspace(void) { ws_release_all(); return IA3_OK; }
+int ia3_workspace_stats(double* out6) {
+  if (!out6) return set_error(IA3_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(g_mu);
+  double idle = 0, busy = 0, blocks = 0;
+  for (auto& e : g_ws) if (e.p) { (e.busy ? busy : idle) += (double)e.bytes; blocks += 1; }
+  out6[0] = idle; out6[1] = busy; out6[2] = blocks; out6[3] = (double)g_ws_mallocs; out6[4] = (double)g_ws_frees; out6[5] = g_ws_ms;
+  return IA3_OK;
+}
 
 int ia3_profile_enable(int on) {
   int rc = ensure_init(); if (rc) return rc;

@@ -52,6 +52,9 @@ int ia3_device_name(char* buf, int len);
 int ia3_sync(void);                       /* hipStreamSynchronize on the library stream */
 void* ia3_stream(void);                   /* hipStream_t the kernels are launched on */
 int ia3_release_workspace(void);          /* drop cached device scratch buffers */
+/* the scratch cache: out6 = {idle bytes, bytes in use, blocks, hipMalloc calls, hipFree calls, ms spent in both} since
+   the library was loaded; a steady-state loop adds no calls (each hipFree synchronises the device) */
+int ia3_workspace_stats(double* out6);
 /* per-kernel timing with HIP events on the library stream (off by default) */
 int ia3_profile_enable(int on);
 int ia3_profile_collect(char* buf, int len); /* "kernel,count,total_ms\n" lines since last collect */

@@ -23,6 +23,10 @@ def main():
     t0 = time.time()
     arrs = bench.generate(jobs, 8)
     print("generated in %.0f s" % (time.time() - t0), flush=True)
+    if os.environ.get("IA3_WITH_TORCH"):   # as bench.py: torch imported and its device context made first
+        import torch
+        torch.cuda.set_device(0)
+        x = torch.zeros(1 << 20).sum().item()
     from imageanalysis3_amd import _lib as L
     from imageanalysis3_amd.io_tools.load import MoviePlan, DeviceBuffer
     lib = L.lib()
