@@ -183,6 +183,44 @@ __device__ __forceinline__ double row_sum16(double v) {   // every lane of a row
   v = v + lane_ror<1>(v);
   return v;
 }
+// The first two levels of row_sum16 for TWO registers at once, the way the half-wave swaps above fold the levels across
+// rows: after v + ror8(v) lane l and lane l ^ 8 of a row hold the same bits (a + b = b + a), so half of the row is
+// free for the partial sums of a second register.  DPP writes only the lanes its bank mask names (banks = groups of
+// four lanes of a row), the others keep the `old` operand:
+//   fold8(p, q)   lanes 0-7 of every row: p[l] + p[l + 8]        lanes 8-15: q[l] + q[l - 8]
+//   fold4(r, s)   lanes with bit 2 clear: r[l] + r[l + 4]        lanes with bit 2 set: s[l] + s[l - 4]
+// The pairs added are the pairs row_sum16 adds at these levels (l with l ^ 8, then l with l ^ 4 inside a half that is
+// 8-periodic), so every partial sum has the bits it had; 16 registers cost 102 vector instructions instead of 192.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double lane_dpp_into(double old, double src) {   // old with the lanes of BANKS replaced by the rotated src
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fold8(double p, double q) {
+  const double a = lane_dpp_into<0x128, 0xC>(p, q);   // l < 8: p[l]          l >= 8: q[l - 8]
+  const double b = lane_dpp_into<0x128, 0x3>(q, p);   // l < 8: p[l + 8]      l >= 8: q[l]
+  return a + b;
+}
+__device__ __forceinline__ double fold4(double r, double s) {
+  // row_ror:n moves data n lanes up (dst[l] = src[(l - n) mod 16]): s[l - 4] is ror 4, r[l + 4] is ror 12
+  const double a = lane_dpp_into<0x124, 0xA>(r, s);   // bit 2 clear: r[l]        bit 2 set: s[l - 4]
+  const double b = lane_dpp_into<0x12C, 0x5>(s, r);   // bit 2 clear: r[l + 4]    bit 2 set: s[l]
+  return a + b;
+}
+// the last two levels, inside each bank (the neighbouring banks now belong to other registers): l with l ^ 2, then
+// l with l ^ 1 — the operands row_sum16's rotations by 2 and by 1 meet, since the level-4 sums are 4-periodic
+template <int CTRL>
+__device__ __forceinline__ double lane_quad(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum4(double v) {
+  v = v + lane_quad<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v = v + lane_quad<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  return v;
+}
 
 // geom_scalars (ia3_model.h) across the lanes of the wave.  Its ~20 exponentials, ~20 divisions and 2 square roots are
 // independent library sequences of 20-35 dependent instructions each; a wave that owns its SIMD (every fit does: one
@@ -408,15 +446,25 @@ struct WaveEval {
       const int lane = ln, row = lane >> 4;
       // row r of register n holds value 4n + {0, 2, 1, 3}[r]
       const int sel = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
+      static_assert(N2 == 17, "16 registers folded four to one + one on its own");
+      double q2[N2];
 #pragma unroll
-      for (int n = 0; n < N2; ++n) {
-        const double tot = row_sum16(swap16_add(p1[2 * n], p1[2 * n + 1]));
-        const int vi = 4 * n + sel;
-        if ((lane & 15) == 0) {
-          if (vi < NTRI) ((IA3_LDS double*)A)[vi] = tot;
-          else if (vi < NV) ((IA3_LDS double*)g)[vi - NTRI] = tot;
-        }
+      for (int n = 0; n < N2; ++n) q2[n] = swap16_add(p1[2 * n], p1[2 * n + 1]);
+      // g follows A in the work area (LMWork): value vi lives at A + vi for every vi < NV
+      IA3_LDS double* dst = (IA3_LDS double*)A;
+      // inside the rows: registers 4k .. 4k+3 folded into one (fold8, fold4), whose lane l then holds the partial sum of
+      // register 4k + 2 * bit2(l) + bit3(l); after the last two levels the four lanes of a bank agree
+      const int vb = 4 * (2 * ((lane >> 2) & 1) + ((lane >> 3) & 1)) + sel;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double tot = row_sum4(fold4(fold8(q2[4 * k], q2[4 * k + 1]), fold8(q2[4 * k + 2], q2[4 * k + 3])));
+        if ((lane & 3) == 0) dst[16 * k + vb] = tot;      // 16 k + vb <= 63 < NV
       }
+      {
+        const double tot = row_sum16(q2[16]);
+        if ((lane & 15) == 0 && 64 + sel < NV) dst[64 + sel] = tot;
+      }
+      (void)g;
       __builtin_amdgcn_wave_barrier();   // A, g live in LDS: later reads by every lane follow these writes in order
     }
     // MINPACK's enorm (scaled sums) returns NaN, not inf, as soon as two components are infinite (inf/inf) or one
