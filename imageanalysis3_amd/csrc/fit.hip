@@ -406,19 +406,15 @@ struct WaveEval {
     for (int k = 0; k < NTRI; ++k) a[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) gg[k] = 0.0;
-    int nbad = 0;   // non-finite residuals, NaN counted twice (see below)
     const int ln = threadIdx.x & 63;
     // a rolled loop: one slot's exp -> Jacobian row -> 66 accumulations is a dependent chain that the SIMD's other
     // wave fills; unrolled, the allocator wants the whole register file
 #pragma unroll 1
     for (int s = 0; s < SLOTS; ++s) {
-      bool r_inf = false, r_nan = false;
       if (valid & (1u << s)) {
         double J[NP];
         double F = model_jac(gm, (double)bl->cz[s][ln], (double)bl->cx[s][ln], (double)bl->cy[s][ln], J);
         double r = (gm.ebk_f + F) - (double)bl->dat[s][ln];
-        r_nan = r != r;
-        r_inf = !r_nan && (r - r != 0.0);
         ss += r * r;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -427,7 +423,6 @@ struct WaveEval {
           for (int j = i; j < NP; ++j) a[tri(i, j)] += J[i] * J[j];
         }
       }
-      nbad += __popcll(__ballot(r_inf)) + 2 * __popcll(__ballot(r_nan));
     }
     IA3_STAMP(L, 7);   // voxel slots
     // sum the 65 partials over the wave: 65 -> 34 -> 17 registers by pairwise lane swaps, then inside the rows
@@ -473,6 +468,23 @@ struct WaveEval {
     // step sends bk past 709.
     const double fn = sqrt(wave_sum(ss));
     IA3_STAMP(L, 8);   // cross-lane sums
+    // A non-finite residual makes the sum of squares non-finite, so the count is only taken when that happened (the
+    // residuals are evaluated again, by the same code; an overflow of the squares alone counts nothing)
+    int nbad = 0;   // non-finite residuals, NaN counted twice
+    if (!(fn - fn == 0.0)) {
+#pragma unroll 1
+      for (int s = 0; s < SLOTS; ++s) {
+        bool r_inf = false, r_nan = false;
+        if (valid & (1u << s)) {
+          double J[NP];
+          const double F = model_jac(gm, (double)bl->cz[s][ln], (double)bl->cx[s][ln], (double)bl->cy[s][ln], J);
+          const double r = (gm.ebk_f + F) - (double)bl->dat[s][ln];
+          r_nan = r != r;
+          r_inf = !r_nan && (r - r != 0.0);
+        }
+        nbad += __popcll(__ballot(r_inf)) + 2 * __popcll(__ballot(r_nan));
+      }
+    }
     return nbad >= 2 ? NAN : fn;
   }
 };

@@ -194,11 +194,14 @@ IA3_HD double model_jac(const Geom& g, double vz, double vx, double vy, double* 
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     J[2 + k] = (double)(float)(F * (g.l[k][0] * xt + g.l[k][1] * yt + g.l[k][2] * zt));
+  // (four coefficients are zero by construction — m[1][3..5]: the second width does not enter the z cross terms,
+  // m[4][5]: the in-plane angle does not enter zt² — and their terms, ±0 for finite coordinates, leave every sum as it is)
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     double s = g.m[k][0] * mo[0];
 #pragma unroll
-    for (int a = 1; a < 6; ++a) s += g.m[k][a] * mo[a];
+    for (int a = 1; a < 6; ++a)
+      if (!((k == 1 && a >= 3) || (k == 4 && a == 5))) s += g.m[k][a] * mo[a];
     J[5 + k] = (double)(float)(F * s);
   }
   return F;
