@@ -3,6 +3,7 @@
 //   coords = grid (+ chromatic_profile) - drift ;  out = scipy.ndimage.map_coordinates(image, coords, order, mode)
 //
 // scipy semantics restated (verified bit-for-bit on the host against SciPy 1.15, see tests):
+//   order 0            the sample at floor(c + 0.5) per axis, index clamped; 'constant': cval as for order 1
 //   order 1            no prefilter; value = sum over the 2x2x2 corners, in C order, of ((c*w0)*w1)*w2 with
 //                      w = [1-y, y], y = cc - floor(cc).  mode 'constant': cc < 0 or cc > n-1 on any axis -> cval.
 //                      mode 'nearest': the coordinate is NOT clamped, out-of-range corner indices are.
@@ -10,6 +11,8 @@
 //                      (pole z = sqrt(3)-2 correctly rounded, gain (1-z)(1-1/z), half-sample-symmetric causal
 //                      initialisation, anticausal c[n-1] *= z/(z-1)), then the 4x4x4 weighted sum in C order with
 //                      weights w1=(y²(y-2)·3+4)/6, w2=(z²(z-2)·3+4)/6, w0=z³/6, w3=1-w0-w1-w2 (z=1-y).
+//   order 3 'constant' not padded; prefilter with the whole-sample-symmetric boundary; cval outside [0, n-1]; taps
+//                      mirrored about the first / last sample (section "order 3, mode 'constant'" below)
 //   outputs            float32: cast; uint16: floor(t+0.5) clamped to [0, 65535].
 // The coordinate grid (5 GB of float64 per FOV in the reference) is never materialised.
 // Compiled with -ffp-contract=off.  HBM-bound streaming passes + an L2-served 64-tap gather.
@@ -127,6 +130,9 @@ __device__ __forceinline__ double iir_start_strided(const double* __restrict__ c
 // back: [from, n) holds raw samples on entry and coefficients on exit.
 // The recursions are serial in `prev`, their loads are not: eight samples are fetched ahead of the eight dependent
 // updates, so a thread keeps eight loads in flight instead of one (the kernel ran at 1.6 TB/s, latency-bound).
+// MIRROR: the anticausal start of the whole-sample-symmetric boundary (mode 'constant', below) instead of the
+// half-sample-symmetric one; needs the causal values of the last TWO samples (from <= n - 2).
+template <bool MIRROR = false>
 __device__ __forceinline__ void iir_two_sweeps_strided(double* __restrict__ c, size_t stride, int from, int n, double first,
                                                        double z, double g) {
   constexpr int B = 8;   // 16 in flight: no faster (2.36 against 2.25 ms)
@@ -149,7 +155,8 @@ __device__ __forceinline__ void iir_two_sweeps_strided(double* __restrict__ c, s
     c[(size_t)i * stride] = v;
     prev = v;
   }
-  prev = prev * (z / (z - 1.0));
+  if (MIRROR) prev = ((z * c[(size_t)(n - 2) * stride] + prev) * z) / (z * z - 1.0);   // (c[n-2]: this thread's own store)
+  else prev = prev * (z / (z - 1.0));
   c[(size_t)(n - 1) * stride] = prev;
   i = n - 2;
   for (; i - (B - 1) >= from; i -= B) {
@@ -601,11 +608,103 @@ __device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
   return fdt == 1 ? (double)((const float*)f)[i] : ((const double*)f)[i];
 }
 
-// order 1 on the raw stack
+// ---- order 3, mode 'constant' (translate.py:5-31 called with warp_order=3 and its default border mode) --------------
+// SciPy's rules for this mode (restated in numpy and compared bit for bit, tests/test_host_logic_cpu.py): the input is
+// NOT padded; the prefilter runs with the whole-sample-symmetric ("mirror") boundary —
+//     c[0]   = (c[0] + z^(n-1) c[n-1] + sum_{i=1}^{n-2} z^i (c[i] + z^(n-1) c[n-1-i])) / (1 - z^(2n-2))      (same order)
+//     c[n-1] = ((z c[n-2] + c[n-1]) z) / (z² - 1)
+// — a coordinate below 0 or above n-1 on any axis gives cval, and taps that leave the array are mirrored about its
+// first / last sample.  Off the production path (the twins in io_tools/load.py and classes/preprocess.py use 'nearest'):
+// plain kernels, one thread per line with two sweeps, one output per thread.
+struct MirInit {
+  double z, gain, zn1, den;   // zn1 = z^(n-1), den = 1 - zn1²
+  int n_sum;                  // terms of the start sum that can matter: z^i (by repeated multiplication) is 0 from there on
+};
+template <class T>
+__global__ __launch_bounds__(256) void spline_cvt_k(const T* __restrict__ im, size_t n, double* __restrict__ P) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) P[i] = (double)im[i];
+}
+// line (o, p): element i at P + o * outer_stride + p * inner_stride + i * stride
+__global__ __launch_bounds__(256) void spline_mirror_k(double* __restrict__ P, int inner, size_t inner_stride, size_t stride, int n,
+                                                       size_t outer_stride, MirInit q) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= inner) return;
+  double* c = P + (size_t)blockIdx.y * outer_stride + (size_t)p * inner_stride;
+  const double z = q.z, g = q.gain;
+  double s = c[0] * g + q.zn1 * (c[(size_t)(n - 1) * stride] * g);
+  double zi = z;
+  if (q.zn1 != 0.0) {
+    for (int i = 1; i < n - 1; ++i) { s += zi * (c[(size_t)i * stride] * g + q.zn1 * (c[(size_t)(n - 1 - i) * stride] * g)); zi *= z; }
+  } else {   // c[i] + 0 * c[n-1-i] = c[i]; beyond n_sum every term is a zero
+    const int e = n - 1 < q.n_sum ? n - 1 : q.n_sum;
+    for (int i = 1; i < e; ++i) { s += zi * (c[(size_t)i * stride] * g); zi *= z; }
+  }
+  s /= q.den;
+  iir_two_sweeps_strided<true>(c, stride, 0, n, s, z, g);
+}
+__device__ __forceinline__ int mirror_idx(int i, int n) {   // SciPy's edge offsets: ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ...
+  const int s2 = 2 * n - 2;
+  if (i < 0) { i = s2 * (-i / s2) + i; i = i <= 1 - n ? i + s2 : -i; }
+  else if (i >= n) { i -= s2 * (i / s2); if (i >= n) i = s2 - i; }
+  return i;
+}
+template <class T>
+__global__ __launch_bounds__(256) void warp_cubic_mirror_k(const double* __restrict__ C, int Z, int X, int Y, double dz, double dx,
+                                                           double dy, const void* __restrict__ field, int fdt, double cval,
+                                                           T* __restrict__ out) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  if (y >= Y) return;
+  const int x = blockIdx.y, zq = blockIdx.z;
+  const size_t o = ((size_t)zq * X + x) * Y + y, V = (size_t)Z * X * Y;
+  double cc[3] = {(double)zq, (double)x, (double)y};
+  if (fdt & 16) {
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+  } else {
+    if (field) { cc[0] = cc[0] + field_at(field, fdt & 3, o); cc[1] = cc[1] + field_at(field, fdt & 3, V + o); cc[2] = cc[2] + field_at(field, fdt & 3, 2 * V + o); }
+    cc[0] = cc[0] - dz; cc[1] = cc[1] - dx; cc[2] = cc[2] - dy;
+  }
+  const int dims[3] = {Z, X, Y};
+  bool outside = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) outside = outside || !(cc[a] >= 0.0 && cc[a] <= (double)(dims[a] - 1));
+  if (outside) { out[o] = out_cvt<T>(cval); return; }
+  int idx[3][4]; double w[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double c = cc[a];
+    const double fl = floor(c);
+    const double yv = c - fl, zv = 1.0 - yv;
+    w[a][1] = div6(yv * yv * (yv - 2.0) * 3.0 + 4.0);
+    w[a][2] = div6(zv * zv * (zv - 2.0) * 3.0 + 4.0);
+    w[a][0] = div6(zv * zv * zv);
+    w[a][3] = 1.0 - w[a][0] - w[a][1] - w[a][2];
+    const int st = (int)fl - 1;   // 0 <= fl <= n - 1 here
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[a][k] = mirror_idx(st + k, dims[a]);
+  }
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double* row = C + ((size_t)idx[0][i] * X + idx[1][j]) * Y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double c = row[idx[2][k]];
+        c = c * w[0][i]; c = c * w[1][j]; c = c * w[2][k];
+        t = t + c;
+      }
+    }
+  out[o] = out_cvt<T>(t);
+}
+
+// orders 0 and 1 on the raw stack
 template <class T>
 __global__ __launch_bounds__(256) void warp_lin_k(const T* __restrict__ im, int Z, int X, int Y, double dz, double dx,
                                                   double dy, const void* __restrict__ field, int fdt, int mode,
-                                                  double cval, T* __restrict__ out) {
+                                                  double cval, T* __restrict__ out, int order) {
   const int y = blockIdx.x * 256 + threadIdx.x;
   if (y >= Y) return;
   const int x = blockIdx.y, zq = blockIdx.z;
@@ -624,6 +723,16 @@ __global__ __launch_bounds__(256) void warp_lin_k(const T* __restrict__ im, int 
 #pragma unroll
     for (int a = 0; a < 3; ++a) outside = outside || cc[a] < 0.0 || cc[a] > (double)(dims[a] - 1);
     if (outside) { out[o] = out_cvt<T>(cval); return; }
+  }
+  if (order == 0) {   // the nearest sample: index floor(c + 0.5), clamped to the array (label images, segmentation_tools/cell.py:589)
+    int id[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double r = floor(cc[a] + 0.5);
+      id[a] = (int)(r < 0.0 ? 0.0 : (r > (double)(dims[a] - 1) ? (double)(dims[a] - 1) : r));
+    }
+    out[o] = im[((size_t)id[0] * X + id[1]) * Y + id[2]];
+    return;
   }
   int st[3]; double w[3][2];
 #pragma unroll
@@ -921,10 +1030,42 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   hipStream_t st = stream();
   const int Z = im->Z, X = im->X, Y = im->Y;
   dim3 g((unsigned)((Y + 255) / 256), (unsigned)X, (unsigned)Z);
-  if (order == 1) {
+  if (order <= 1) {
     ProfScope ps("warp_linear");
     hipLaunchKernelGGL((warp_lin_k<T>), g, dim3(256), 0, st, (const T*)im->d, Z, X, Y, drift[0], drift[1], drift[2],
-                       field, fdt, mode, cval, (T*)out->d);
+                       field, fdt, mode, cval, (T*)out->d, order);
+    IA3_KCHECK();
+    return IA3_OK;
+  }
+  if (mode == IA3_MODE_CONSTANT) {
+    const size_t V = (size_t)Z * X * Y, plane = (size_t)X * Y;
+    Scratch P(V * sizeof(double));
+    if (!P.p) return IA3_ENOMEM;
+    auto init = [](int n) {
+      MirInit q;
+      q.z = IA3_POLE3;
+      q.gain = (1.0 - q.z) * (1.0 - 1.0 / q.z);
+      q.zn1 = pow(q.z, (double)(n - 1));
+      q.den = 1.0 - q.zn1 * q.zn1;
+      double zi = q.z;
+      int i = 1;
+      while (zi != 0.0 && i < n) { zi *= q.z; ++i; }
+      q.n_sum = i;
+      return q;
+    };
+    {
+      ProfScope ps("spline_mirror");
+      hipLaunchKernelGGL((spline_cvt_k<T>), dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, (const T*)im->d, V, P.as<double>());
+      hipLaunchKernelGGL(spline_mirror_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(), (int)plane,
+                         (size_t)1, plane, Z, (size_t)0, init(Z));
+      hipLaunchKernelGGL(spline_mirror_k, dim3((unsigned)((Y + 255) / 256), (unsigned)Z), dim3(256), 0, st, P.as<double>(), Y,
+                         (size_t)1, (size_t)Y, X, plane, init(X));
+      hipLaunchKernelGGL(spline_mirror_k, dim3((unsigned)((X + 255) / 256), (unsigned)Z), dim3(256), 0, st, P.as<double>(), X,
+                         (size_t)Y, (size_t)1, Y, plane, init(Y));
+    }
+    ProfScope ps("warp_cubic");
+    hipLaunchKernelGGL((warp_cubic_mirror_k<T>), g, dim3(256), 0, st, (const double*)P.as<double>(), Z, X, Y, drift[0], drift[1],
+                       drift[2], field, fdt, cval, (T*)out->d);
     IA3_KCHECK();
     return IA3_OK;
   }
@@ -1025,9 +1166,11 @@ int ia3_warp3d_dev(const ia3_stack* im, const double* drift, const void* field_d
   if (!im || !out || !drift) return set_error(IA3_EINVAL, "null argument");
   if (im->dtype != out->dtype || im->Z != out->Z || im->X != out->X || im->Y != out->Y || im->d == out->d)
     return set_error(IA3_EINVAL, "output stack must be a distinct stack of the same shape and dtype");
-  if (order != 1 && order != 3) return set_error(IA3_EUNSUPPORTED, "warp order %d (1 and 3 are implemented)", order);
-  if (order == 1 && mode != IA3_MODE_CONSTANT && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "border mode %d", mode);
-  if (order == 3 && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "order 3 is implemented for mode 'nearest'");
+  if (order != 0 && order != 1 && order != 3) return set_error(IA3_EUNSUPPORTED, "warp order %d (0, 1 and 3 are implemented)", order);
+  if (order <= 1 && mode != IA3_MODE_CONSTANT && mode != IA3_MODE_NEAREST) return set_error(IA3_EUNSUPPORTED, "border mode %d", mode);
+  if (order == 3 && mode != IA3_MODE_NEAREST && mode != IA3_MODE_CONSTANT) return set_error(IA3_EUNSUPPORTED, "border mode %d", mode);
+  if (order == 3 && mode == IA3_MODE_CONSTANT && (im->Z < 2 || im->X < 2 || im->Y < 2))
+    return set_error(IA3_EUNSUPPORTED, "order 3 with mode 'constant' needs at least two samples along every axis");
   if (field_dev && (field_dtype & ~16) != 1 && (field_dtype & ~16) != 2) return set_error(IA3_EINVAL, "field dtype must be float32 (1) or float64 (2), optionally + 16");
   if (im->dtype == IA3_F32) return warp_t<float>(im, drift, field_dev, field_dtype, order, mode, cval, out);
   return warp_t<uint16_t>(im, drift, field_dev, field_dtype, order, mode, cval, out);

@@ -387,7 +387,9 @@ int ia3_align_image_ref(const ia3_stack* src, ia3_drift_ref* ref, int upsample, 
 /* ---- warp -------------------------------------------------------------------------------------
  * correction_tools/translate.py:5-31 warp_3d_image and its inlined twins (io_tools/load.py:438-453,
  * classes/preprocess.py:918-946): out = map_coordinates(im, grid (+ field) - drift, order, mode, cval).
- * order 1 with mode constant|nearest, order 3 (B-spline prefilter) with mode nearest.
+ * orders 0 (nearest sample) and 1 with mode constant|nearest; order 3 (B-spline prefilter) with mode nearest (the production twins: padded by
+ * 12, tuned kernels) or constant (warp_3d_image's default border mode: no padding, mirror-boundary prefilter, cval outside,
+ * plain kernels; every axis >= 2 samples).
  * field: NULL or a (3,Z,X,Y) displacement field, field_dtype 1 = float32, 2 = float64; add 16 to form the
  * coordinates as (grid - drift) + field, the order of classes/preprocess.py:923-935 (DaxProcesser._warp_image),
  * instead of (grid + field) - drift. */

@@ -886,6 +886,68 @@ def warp_3d_image(image, drift, chromatic_profile=None, warp_order=1, border_mod
     return out.reshape(image.shape).astype(image.dtype)
 
 
+def spline3_mirror_line(c):
+    """scipy.ndimage's cubic B-spline prefilter of one line with the whole-sample-symmetric boundary it uses for
+    ``mode='constant'`` / ``'mirror'`` (ni_splines.c: _init_causal_mirror, _init_anticausal_mirror; SciPy 1.15.3 in
+    this image), operation for operation.  What csrc/warp.hip's spline_mirror_k runs; pinned against
+    ``spline_filter1d`` bit for bit in tests/test_host_logic_cpu.py."""
+    z = np.float64(-0.26794919243112270647)
+    c = np.array(c, dtype=np.float64)
+    n = len(c)
+    if n < 2:
+        return c
+    c *= (1.0 - z) * (1.0 - 1.0 / z)
+    zn1 = np.power(z, float(n - 1))
+    s = c[0] + zn1 * c[n - 1]
+    zi = z
+    for i in range(1, n - 1):
+        s += zi * (c[i] + zn1 * c[n - 1 - i])
+        zi *= z
+    c[0] = s / (1 - zn1 * zn1)
+    for i in range(1, n):
+        c[i] += z * c[i - 1]
+    c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1)
+    for i in range(n - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
+    return c
+
+
+def cubic_constant_1d(x, coords, cval):
+    """``map_coordinates(x, [coords], order=3, mode='constant', cval=cval)`` for a 1-D float64 ``x`` (ni_interpolation.c,
+    NI_GeometricTransform): a coordinate below 0 or above n-1 gives cval; taps that leave the array are mirrored about
+    its first / last sample; weights and summation order as in the 'nearest' path."""
+    n = len(x)
+    coef = spline3_mirror_line(x)
+    s2 = 2 * n - 2
+
+    def mirror(i):
+        if i < 0:
+            i = s2 * int(-i / s2) + i
+            i = i + s2 if i <= 1 - n else -i
+        elif i >= n:
+            i -= s2 * int(i / s2)
+            if i >= n:
+                i = s2 - i
+        return i
+    out = np.empty(len(coords), dtype=np.float64)
+    for q, cc in enumerate(coords):
+        if cc < 0 or cc > n - 1:
+            out[q] = cval
+            continue
+        fl = np.floor(cc)
+        y = cc - fl
+        zz = 1.0 - y
+        w1 = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w2 = (zz * zz * (zz - 2.0) * 3.0 + 4.0) / 6.0
+        w0 = zz * zz * zz / 6.0
+        w = [w0, w1, w2, 1.0 - w0 - w1 - w2]
+        t = 0.0
+        for k in range(4):
+            t = t + coef[mirror(int(fl) - 1 + k)] * w[k]
+        out[q] = t
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # (a13) elementwise stages of correct_fov_image, io_tools/load.py:337-384 (the reference's own NumPy
 # expressions, verbatim in structure; corrections.py:479-487 for the z-shift)

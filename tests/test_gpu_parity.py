@@ -595,11 +595,21 @@ def test_warp_identity_and_integer_shift():
     w = warp_3d_image(im, [1, -2, 3], warp_order=1, border_mode="nearest")
     assert np.array_equal(w, O.warp_3d_image(im, [1, -2, 3], None, 1, "nearest"))
     # large drifts: everything outside -> cval (constant) / edge (nearest, order 3)
-    for order, mode in ((1, "constant"), (3, "nearest")):
+    for order, mode in ((1, "constant"), (3, "nearest"), (3, "constant"), (0, "nearest"), (0, "constant")):
         w = warp_3d_image(im, [40.5, 100.25, -90.75], warp_order=order, border_mode=mode)
         assert np.array_equal(w, O.warp_3d_image(im, [40.5, 100.25, -90.75], None, order, mode))
+    # order 0 (the nearest sample; the reference warps label images this way, segmentation_tools/cell.py:589): half-integer
+    # coordinates, a field, both border modes, both dtypes
+    rng = np.random.RandomState(2)
+    lab = rng.randint(0, 40, size=(4, 30, 37)).astype(np.uint16)
+    zz, xx, yy = np.meshgrid(np.arange(4), np.arange(30), np.arange(37), indexing="ij")
+    fld = np.stack([0.5 * np.ones_like(zz), 1.5 * np.cos(yy / 5.0), 0.5 + 0.25 * xx]).astype(np.float32)
+    for a in (lab, lab.astype(np.float32)):
+        for mode in ("nearest", "constant"):
+            for drift, f in (([0.5, -1.5, 2.5], None), ([0.25, 3.5, -7.75], fld), ([0, 0, 0], fld)):
+                assert np.array_equal(warp_3d_image(a, drift, f, 0, mode), O.warp_3d_image(a, drift, f, 0, mode)), (mode, drift)
     with pytest.raises(NotImplementedError):
-        warp_3d_image(im, [0, 0, 0], warp_order=3, border_mode="constant")
+        warp_3d_image(im, [0, 0, 0], warp_order=2, border_mode="constant")
 
 
 def _start_sum_cases():
@@ -671,6 +681,34 @@ def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
                 assert np.array_equal(w.view(view), ref.view(view)), (drift, fld is not None, knob)
         finally:
             L.check(L.lib().ia3_set_tuning(12, 64))
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_warp_cubic_constant_mode_bit_exact(dtype):
+    """warp_3d_image(warp_order=3) with its DEFAULT border mode 'constant' (correction_tools/translate.py:5-31): SciPy
+    filters without padding and with the mirror boundary, returns cval = min(image) for coordinates outside the array
+    and mirrors taps that leave it.  Bit for bit against scipy: drift alone, drift + field (both dtypes of field, both
+    orders of applying them), a drift that pushes a third of the outputs outside, short axes (2 and 3 samples), an
+    axis longer than the 566 samples after which the boundary sum's power underflows."""
+    import np_oracle as O
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.correction_tools.translate import warp_3d_image
+    rng = np.random.RandomState(11)
+    view = np.uint32 if dtype == np.float32 else np.uint16
+    for shape in ((5, 40, 70), (2, 3, 640), (3, 33, 20)):
+        Z, X, Y = shape
+        im = rng.randint(90, 5000, size=shape).astype(dtype)
+        im[:, X // 2:X // 2 + 2, :] = 0
+        zz, xx, yy = np.meshgrid(np.arange(Z), np.arange(X), np.arange(Y), indexing="ij")
+        field = np.stack([0.4 * np.sin(yy / 17.0), 1.3 * np.cos(yy / 23.0) + 0.01 * xx, 0.9 * np.sin(yy / 9.0) + 0.004 * xx]).astype(np.float32)
+        for drift, fld in (([0.3, 1.7, -2.2], None), ([0.3, 1.7, -2.2], field), ([-0.4, 0.5, 0.25 * Y], field.astype(np.float64)),
+                           ([0.0, 0.0, 0.0], None), ([1e-9, -1e-9, 0.0], field)):
+            ref = O.warp_3d_image(im, drift, fld, 3, "constant")
+            w = warp_3d_image(im, drift, fld, 3, "constant")
+            assert w.dtype == ref.dtype
+            assert np.array_equal(w.view(view), ref.view(view)), (shape, drift, fld is not None)
+    with pytest.raises(RuntimeError):
+        warp_3d_image(np.zeros((1, 8, 8), dtype), [0, 0, 0], None, 3, "constant")
 
 
 def test_gaussianfit_class_vs_oracle():
