@@ -41,6 +41,7 @@ inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 void* ws_get(size_t bytes);
 void ws_put(void* p);
 void ws_release_all();
+void ws_reserve(size_t bytes, int count);   // at least `count` cached blocks that fit a request of `bytes` (best effort)
 
 struct Scratch {  // RAII
   void* p;

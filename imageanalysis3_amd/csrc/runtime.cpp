@@ -312,6 +312,25 @@ void ws_put_deferred_now() {
   ws_flush_deferred();
   t_ctx.defer_puts = d;
 }
+// Make sure the cache holds at least `count` blocks a request of `bytes` can take (in use or idle).  A pipeline whose
+// depth is bounded knows its peak demand before it starts; finding it out block by block costs a hipMalloc — 70 ms for a
+// 1.7 GB block, with every stream of the device stalled — at a moment nobody chose (profiles/r04u).  Best effort: a
+// failed allocation ends the reservation quietly.
+void ws_reserve(size_t bytes, int count) {
+  if (bytes == 0 || count <= 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int have = 0;
+  for (auto& e : g_ws) if (e.p && e.bytes >= bytes && e.bytes <= 2 * bytes + (1 << 20)) ++have;
+  for (; have < count; ++have) {
+    void* p = nullptr;
+    const double ta = ws_now_ms();
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    ++g_ws_mallocs; g_ws_ms += ws_now_ms() - ta;
+    bool placed = false;
+    for (auto& e : g_ws) if (!e.p) { e.p = p; e.bytes = bytes; e.busy = false; e.last = nullptr; placed = true; break; }
+    if (!placed) g_ws.push_back(WsEntry{p, bytes, false, nullptr, nullptr});
+  }
+}
 void ws_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);
   (void)hipDeviceSynchronize();
