@@ -234,7 +234,11 @@ __device__ __forceinline__ double row_sum4(double v) {
 // not-inlined evaluation would otherwise get because its pointers travel through memory)
 __device__ __forceinline__ void geom_scalars_wave(const IA3_LDS double* x, const IA3_LDS FitCfg& cfg, GeomScalars& q,
                                                   IA3_LDS double* sc) {
-  const int ln = threadIdx.x & 63;
+  // (opaque to the optimiser: the lane-range predicates below would otherwise be computed once per kernel, kept as 64-bit
+  // masks in scalar registers the geometry leaves no room for, and come back from their spill lanes with two
+  // v_readlane each at every use — a compare is one instruction)
+  int ln = threadIdx.x & 63;
+  asm volatile("" : "+v"(ln));
   const int variant = cfg.variant;
   const double delta = cfg.delta, min_ws = cfg.min_ws, max_ws = cfg.max_ws;
   // ---- stage 1: sc[i] = exp(arg_i) ------------------------------------------------------------------------------
