@@ -360,41 +360,98 @@ int g_dft_valu = 0;   // IA3_TUNE_DFT_VALU: 1 = the vector-unit contraction (tes
 // lines of K and of `in` straight from global memory (eight complex values each), no LDS, and eight MFMA steps consume
 // them.  Float64 accumulation in the matrix unit: the upsampled peak search is as accurate as with the vector kernel.
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void dft_contract_mfma_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
-                                                           cplx* __restrict__ out, int R, int M, int N, int ldk, int ldi) {
+// Round 4, second form.  The first one loaded a tile's eight samples behind eight bounds branches, waited for them and
+// only then issued its 32 matrix instructions: the loop alternated between a memory latency and 2 k cycles of MFMA, and
+// two waves per SIMD reached 0.31 of the matrix peak.  Now the loads run ahead of the matrix unit in registers: every
+// one of the four column tiles of a wave has a sample buffer of its own that is refilled for the NEXT chunk as soon as
+// its 32 instructions of this chunk are issued (three tiles = 6 k cycles of matrix work before it is needed again), the
+// K rows are double-buffered one chunk ahead, whole chunks are loaded without tests and the last, partial one through
+// clamped addresses with the missing samples zeroed.  320 registers (128 of them accumulators): one wave per SIMD.
+struct DftLd {
+  const cplx* krow; const cplx* drow[4]; int N, kq;
+  // eight samples of the whole chunk c for this lane's k slot: no tests, nothing computed on them until the matrix
+  // instructions read them
+  // Which of a chunk's 32 samples go to matrix step s and k slot q does not matter to the sum; n = 4 s + q makes the four
+  // k slots of a row read 64 contiguous bytes per load instruction — 16 cache lines per instruction instead of 64 with
+  // n = 8 q + s, which kept the vector L1 busier than the matrix unit (four waves x 40 loads x 64 lines against 8.2 k
+  // cycles of MFMA per chunk)
+  __device__ __forceinline__ void load(const cplx* row, int c, cplx (&v)[8]) const {
+    const cplx* p = row + 32 * c + kq;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = p[4 * s];
+  }
+  // the last, partial chunk: clamped addresses, missing samples zero
+  __device__ __forceinline__ void load_tail(const cplx* row, int c, cplx (&v)[8]) const {
+    const int nb = 32 * c + kq;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int n = nb + 4 * s;
+      const cplx x = row[n < N ? n : N - 1];
+      v[s] = n < N ? x : cplx{0, 0};
+    }
+  }
+};
+__global__ __launch_bounds__(256, 1) void dft_contract_mfma_k(const cplx* __restrict__ K, const cplx* __restrict__ in,
+                                                              cplx* __restrict__ out, int R, int M, int N, int ldk, int ldi) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int r0 = blockIdx.y * 16, m0 = (blockIdx.x * 4 + wv) * 64;
-  if (m0 >= M) return;                                  // whole wave
+  // The four waves of a block take two blocks of 16 rows x two groups of 64 columns: every `in` row a block reads is
+  // read by two of its waves at the same time (one trip to HBM), so the R / 16 = 10 row blocks re-read `in` five times,
+  // not ten — with four column groups per block the first contraction of a crop moved 1.05 GB and ran at the speed of
+  // that (198 us; 107 us of matrix work)
+  const int r0 = ((int)blockIdx.y * 2 + (wv & 1)) * 16, m0 = ((int)blockIdx.x * 2 + (wv >> 1)) * 64;
+  if (m0 >= M || r0 >= R) return;                       // whole wave
   const int rr = r0 + li < R ? r0 + li : R - 1;         // rows past the end repeat the last one and are not stored
-  const cplx* krow = K + (size_t)rr * ldk;
-  const cplx* drow[4];
+  DftLd L;
+  L.krow = K + (size_t)rr * ldk; L.N = N; L.kq = kq;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int mm = m0 + 16 * t + li;
-    drow[t] = in + (size_t)(mm < M ? mm : M - 1) * ldi;
+    L.drow[t] = in + (size_t)(mm < M ? mm : M - 1) * ldi;
   }
   v4d acc_rr[4], acc_ii[4], acc_ri[4], acc_ir[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { acc_rr[t] = v4d{0, 0, 0, 0}; acc_ii[t] = acc_rr[t]; acc_ri[t] = acc_rr[t]; acc_ir[t] = acc_rr[t]; }
-  for (int n0 = 0; n0 < N; n0 += 32) {
-    const int nb = n0 + 8 * kq;                          // this lane's run of eight samples
-    cplx kv[8];
+  const int nfull = N / 32;                             // whole chunks: pipelined
+  cplx ka[8], kb[8], dv[4][8];
+  auto tile = [&](const cplx (&kv)[8], int t) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) kv[s] = nb + s < N ? krow[nb + s] : cplx{0, 0};
+    for (int s = 0; s < 8; ++s) {
+      acc_rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[t][s].x, acc_rr[t], 0, 0, 0);
+      acc_ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[t][s].y, acc_ii[t], 0, 0, 0);
+      acc_ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[t][s].y, acc_ri[t], 0, 0, 0);
+      acc_ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[t][s].x, acc_ir[t], 0, 0, 0);
+    }
+  };
+  if (nfull > 0) {
+    L.load(L.krow, 0, ka);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      cplx dv[8];
+    for (int t = 0; t < 4; ++t) L.load(L.drow[t], 0, dv[t]);
+    if (nfull > 1) L.load(L.krow, 1, kb);
+    // four chunks per trip: the compiler drains every outstanding load where the loop closes (it cannot count loads
+    // across the back edge), so the trips are long
+#pragma unroll 1
+    for (int c = 0; c < nfull; c += 4) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) dv[s] = nb + s < N ? drow[t][nb + s] : cplx{0, 0};
+      for (int h = 0; h < 4; ++h) {
+        const int cc = c + h;
+        if (cc < nfull) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        acc_rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[s].x, acc_rr[t], 0, 0, 0);
-        acc_ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[s].y, acc_ii[t], 0, 0, 0);
-        acc_ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].x, dv[s].y, acc_ri[t], 0, 0, 0);
-        acc_ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[s].y, dv[s].x, acc_ir[t], 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            if (h % 2 == 0) tile(ka, t); else tile(kb, t);
+            if (cc + 1 < nfull) L.load(L.drow[t], cc + 1, dv[t]);
+          }
+          if (cc + 2 < nfull) { if (h % 2 == 0) L.load(L.krow, cc + 2, ka); else L.load(L.krow, cc + 2, kb); }
+        }
       }
     }
+  }
+  if (N % 32) {                                         // the partial chunk: all of its loads in flight together
+    L.load_tail(L.krow, nfull, ka);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) L.load_tail(L.drow[t], nfull, dv[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tile(ka, t);
   }
   // D[row = kq + 4 v][col = li]: row -> r, col -> m
 #pragma unroll
@@ -748,7 +805,7 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
       if (g_dft_valu)
         hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
       else
-        hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+        hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 127) / 128, (R + 31) / 32), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
     };
     auto contract = [&](const cplx* in, cplx* out, int M, int N, double o) {
       hipLaunchKernelGGL(dft_kernel_k, dim3((N + 255) / 256, R), dim3(256), 0, st, K.as<cplx>(), R, N, o, u);
@@ -1056,7 +1113,7 @@ int drift_crops(const ia3_stack* src, DriftRef* ref, int first, int count, int u
     if (g_dft_valu)
       hipLaunchKernelGGL(dft_contract_k, dim3((M + 63) / 64, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
     else
-      hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 255) / 256, (R + 15) / 16), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
+      hipLaunchKernelGGL(dft_contract_mfma_k, dim3((M + 127) / 128, (R + 31) / 32), dim3(256), 0, st, Kmat, in, out, R, M, cols, ldk, ldi);
   };
   for (int c = first; c < first + count; ++c) {
     const int* b = ref->box[c];
