@@ -49,8 +49,20 @@ static std::vector<WsEntry> g_ws;
 // A host thread that ends hands its streams, events and mailbox back: callers that start a pool of threads per batch
 // (ThreadPoolExecutor around fit_fov_image) would otherwise leave two streams per dead thread multiplexed on the 16
 // hardware queues next to the live ones.  The process's first stream (g_stream) stays; after a fork nothing here is ours.
+// the main streams of the host threads that are alive (under g_mu): a stack remembers the stream of the thread that made
+// it (ia3_stack_free), and that thread may be gone
+static std::vector<hipStream_t> g_live_streams;
+static bool stream_alive_locked(hipStream_t s) {
+  for (hipStream_t t : g_live_streams) if (t == s) return true;
+  return false;
+}
 ThreadCtx::~ThreadCtx() {
   if (!main || pid != getpid() || main == g_stream) return;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_live_streams.size(); ++i)
+      if (g_live_streams[i] == main) { g_live_streams[i] = g_live_streams.back(); g_live_streams.pop_back(); break; }
+  }
   (void)hipStreamSynchronize(main);
   if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
   (void)hipStreamDestroy(main);
@@ -71,7 +83,7 @@ int set_error(int code, const char* fmt, ...) {
 static int do_init(int device) {
   // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
   if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
-  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_device = -1; }
+  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_live_streams.clear(); g_device = -1; }
   // Every host thread drives two streams (ThreadCtx); the runtime multiplexes streams onto 4 hardware queues by
   // default, where a long-running fit kernel holds back unrelated work queued behind it.  Ask for more queues unless
   // the user chose a number (only effective when this is the first HIP call of the process).
@@ -87,10 +99,15 @@ static int do_init(int device) {
   }
   if (device >= n) return set_error(IA3_EINVAL, "device %d out of range (%d devices)", device, n);
   IA3_HIP(hipSetDevice(device));
-  if (g_stream && g_pid == getpid()) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  if (g_stream && g_pid == getpid()) {
+    for (size_t i = 0; i < g_live_streams.size(); ++i)
+      if (g_live_streams[i] == g_stream) { g_live_streams[i] = g_live_streams.back(); g_live_streams.pop_back(); break; }
+    (void)hipStreamDestroy(g_stream); g_stream = nullptr;
+  }
   IA3_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = device;
   g_pid = getpid();
+  g_live_streams.push_back(g_stream);   // (g_mu is held by the caller, ensure_init)
   t_ctx = ThreadCtx();
   t_ctx.pid = g_pid;
   t_ctx.main = g_stream;
@@ -106,6 +123,10 @@ static int thread_ctx() {
   IA3_HIP(hipSetDevice(g_device));   // the current device is per host thread
   IA3_HIP(hipStreamCreateWithFlags(&t_ctx.main, hipStreamNonBlocking));
   t_ctx.pid = g_pid;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live_streams.push_back(t_ctx.main);
+  }
   return IA3_OK;
 }
 
@@ -717,7 +738,9 @@ void ia3_stack_free(ia3_stack* s) {
     if (home && me && home != me && g_pid == getpid()) {
       static thread_local hipEvent_t ev = nullptr;
       if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-      if (ev && hipEventRecord(ev, home) == hipSuccess) (void)hipStreamWaitEvent(me, ev, 0);
+      // (a thread that has ended drained its stream on the way out and is no longer in the list)
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (ev && stream_alive_locked(home) && hipEventRecord(ev, home) == hipSuccess) (void)hipStreamWaitEvent(me, ev, 0);
     }
     ws_put(s->d);
   }

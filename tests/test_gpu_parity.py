@@ -711,6 +711,39 @@ def test_warp_cubic_constant_mode_bit_exact(dtype):
         warp_3d_image(np.zeros((1, 8, 8), dtype), [0, 0, 0], None, 3, "constant")
 
 
+def test_stack_outlives_the_thread_that_made_it():
+    """A host thread that ends returns its streams (csrc/runtime.cpp, ThreadCtx::~ThreadCtx).  Stacks it made stay valid:
+    another thread reads them, frees them — ia3_stack_free would otherwise record an event on the dead thread's stream —
+    and the blocks go back to the scratch cache; the cache's driver-call counters stay flat when the same work is repeated."""
+    import ctypes as C
+    import threading
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.correction_tools.filter import gaussian_high_pass_filter
+    rng = np.random.RandomState(0)
+    im = rng.randint(100, 4000, size=(6, 64, 80)).astype(np.uint16)
+    want = gaussian_high_pass_filter(im, 3, 2)
+    made = []
+
+    def worker():
+        src = L.DeviceStack.upload(im)
+        out = L.DeviceStack.empty(im.shape, im.dtype)
+        w, r = L.gaussian_taps(3, 2)
+        L.check(L.lib().ia3_gaussian_highpass_dev(src._h, C.c_double(3), C.c_double(2), L.dptr(w), int(r), out._h))
+        made.append((src, out))
+    stats = (C.c_double * 6)()
+    for rep in range(3):
+        t = threading.Thread(target=worker)
+        t.start(); t.join()                       # the thread (and its streams) are gone
+        src, out = made.pop()
+        assert np.array_equal(out.download(), want)
+        src.free(); out.free()
+        if rep == 1:
+            L.check(L.lib().ia3_workspace_stats(stats))
+            calls = (stats[3], stats[4])
+    L.check(L.lib().ia3_workspace_stats(stats))
+    assert (stats[3], stats[4]) == calls          # the third round took its blocks from the cache
+
+
 def test_gaussianfit_class_vs_oracle():
     """(a3) standalone GaussianFit on explicit voxel lists (Voronoi cells of the golden case)."""
     import np_oracle as O
