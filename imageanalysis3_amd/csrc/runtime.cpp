@@ -519,6 +519,13 @@ struct Staging {
   hipEvent_t ev[MAX_STAGE] = {};
   int n = 0;
   pid_t pid = 0;
+  ~Staging() {   // a host thread that ends gives its pinned ring back (16 MB a buffer); not ours after a fork
+    if (pid != getpid()) return;
+    for (int i = 0; i < MAX_STAGE; ++i) {
+      if (ev[i]) { (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
+      if (buf[i]) (void)hipHostFree(buf[i]);
+    }
+  }
 };
 thread_local Staging t_stage;
 std::atomic<int> g_upload_threads{-1};   // -1: from IA3_UPLOAD_THREADS (default 0)
