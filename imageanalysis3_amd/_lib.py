@@ -16,7 +16,7 @@ MODE_REFLECT, MODE_NEAREST, MODE_CONSTANT = 0, 1, 2
 
 EXPORTS = [
     "ia3_init", "ia3_last_error", "ia3_version", "ia3_device_name", "ia3_sync", "ia3_stream",
-    "ia3_release_workspace", "ia3_workspace_stats", "ia3_profile_enable", "ia3_profile_collect", "ia3_set_tuning",
+    "ia3_release_workspace", "ia3_workspace_stats", "ia3_prepare_depth", "ia3_profile_enable", "ia3_profile_collect", "ia3_set_tuning",
     "ia3_stack_upload", "ia3_stack_alloc", "ia3_stack_load_file", "ia3_stack_wrap", "ia3_stack_download", "ia3_stack_info",
     "ia3_stack_free",
     "ia3_gaussian_filter", "ia3_gaussian_filter_dev", "ia3_gaussian_highpass", "ia3_gaussian_highpass_dev",

@@ -887,6 +887,12 @@ using namespace ia3rt;
 
 extern "C" {
 
+// see include/ia3.h
+int ia3_prepare_depth(int dtype, int Z) {
+  int rc = ensure_init(); if (rc) return rc;
+  if (dtype != IA3_F32 && dtype != IA3_U16) return set_error(IA3_EINVAL, "dtype");
+  return ia3g::column_kernel_source(dtype == IA3_F32, Z);
+}
 int ia3_set_tuning(int key, int value) {
   if (key == IA3_TUNE_GAUSS_CERT) {
     if (value < -2) return set_error(IA3_EINVAL, "IA3_TUNE_GAUSS_CERT: value must be >= -2");

@@ -52,6 +52,13 @@ int ia3_device_name(char* buf, int len);
 int ia3_sync(void);                       /* hipStreamSynchronize on the library stream */
 void* ia3_stream(void);                   /* hipStream_t the kernels are launched on */
 int ia3_release_workspace(void);          /* drop cached device scratch buffers */
+/* The long Gaussian passes of get_seeds keep a whole z column in registers, one kernel per stack depth: the library is
+   built with the depths of FOLD_DEPTHS (25 30 33 35 40 45 50 60), any other depth from 16 to 64 planes is compiled at run
+   time (hiprtc: ~35 s once per depth, dtype and machine, kept in IA3_RTC_CACHE or <library dir>/_rtc; IA3_RTC=0 turns it
+   off) the first time it is used.  This call does that ahead of time.  Returns 1 = built in, 2 = compiled at run time (or
+   taken from the cache), 0 = not available (the sliding-window kernels run: same results, slower), < 0 = error.  The
+   reference takes any single_im_size (io_tools/load.py:166-180). */
+int ia3_prepare_depth(int dtype, int Z);
 /* the scratch cache: out6 = {idle bytes, bytes in use, blocks, hipMalloc calls, hipFree calls, ms spent in both} since
    the library was loaded; a steady-state loop adds no calls (each hipFree synchronises the device) */
 int ia3_workspace_stats(double* out6);

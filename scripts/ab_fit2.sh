@@ -8,7 +8,7 @@ cd "$REPO/imageanalysis3_amd/csrc"
 mkdir -p build
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -D'IA3_FOLD_DEPTHS(X)=X(50)' $FLAGS -c fit.hip -o build/fit_$TAG.o
 OBJS=$(make -s print-OBJS | grep -v "^build/fit.o$")
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libia3_$TAG.so build/fit_$TAG.o $OBJS -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libia3_$TAG.so build/fit_$TAG.o $OBJS -L/opt/rocm/lib -lhipfft -lhiprtc -ldl -Wl,-rpath,/opt/rocm/lib
 cd "$REPO"
 python3 scripts/ab_fit2.py "$@"
 IA3_LIB_PATH=$REPO/imageanalysis3_amd/libia3_$TAG.so python3 scripts/ab_fit2.py "$@"

@@ -1218,7 +1218,7 @@ def test_gaussian_long_filter_certified_fused_path_bit_exact():
 
 
 def test_gaussian_axis0_folded_column_pass_bit_exact():
-    """Stacks of the built depths (Makefile FOLD_DEPTHS: 25 30 33 35 40 45 50 60) run the axis-0 pass of a long filter with
+    """Stacks of the built depths (Makefile FOLD_DEPTHS: 25 30 33 35 40 45 50 60) and of a depth compiled at run time (48) run the axis-0 pass of a long filter with
     the whole column in registers and the border folded into the weights (IA3_TUNE_GAUSS_FOLD, a different summation order, certified like the fused path).
     Same bits as SciPy for both border modes, with the default guard, with every output sent through the reference
     sequence, with the guard forced wide open and with the folded form off, on inputs that sit on quantisation
@@ -1228,8 +1228,14 @@ def test_gaussian_axis0_folded_column_pass_bit_exact():
     from imageanalysis3_amd import _lib as L
     from imageanalysis3_amd.correction_tools.filter import gaussian_filter
     rng = np.random.RandomState(12)
+    # a depth without a translation unit of its own: its kernels come from the run-time compiler (hiprtc, the same kernel
+    # text and flags; csrc/gauss_col_dispatch.hip) — ~35 s per dtype the first time on a machine, then from the cache
+    for dt in (L.dtype_code(np.zeros(1, np.float32)), L.dtype_code(np.zeros(1, np.uint16))):
+        assert L.lib().ia3_prepare_depth(dt, 48) == 2
+        assert L.lib().ia3_prepare_depth(dt, 50) == 1
+    assert L.lib().ia3_prepare_depth(L.dtype_code(np.zeros(1, np.float32)), 70) == 0      # beyond 64 planes: window kernels
     try:
-        for Z in (25, 30, 33, 35, 40, 45, 50, 60):
+        for Z in (25, 30, 33, 35, 40, 45, 50, 60, 48):
             shape = (Z, 96, 192)
             blocks = np.zeros(shape, np.uint16)
             for i in range(2):
@@ -1262,7 +1268,7 @@ def test_gaussian_axis0_folded_column_pass_bit_exact():
 
 def test_dog_filter_pair_shared_axis0_launch_bit_exact():
     """ia3_dog_filters_dev: the seed detector's two filtered stacks.  On the built depths (25 ... 60) the two axis-0 passes come
-    from one launch (column in registers) and the short filter's other axes from the plane-wise kernel; other depths
+    from one launch (column in registers) and the short filter's other axes from the plane-wise kernel — so does a depth whose kernels are compiled at run time (48); depths outside 16 ... 64 (12)
     run the separate filters.  front == scipy gaussian_filter(im, 0.75), back == gaussian_filter1d(im, 7.5, axis=0),
     bit for bit, on ragged plane sizes, with the guard at its default, off and wide open."""
     import ctypes as C
@@ -1271,7 +1277,7 @@ def test_dog_filter_pair_shared_axis0_launch_bit_exact():
     lib = L.lib()
     rng = np.random.RandomState(13)
     try:
-        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (24, 80, 120), (45, 20, 96), (25, 40, 64),
+        for Z, X, Y in ((50, 150, 530), (30, 64, 248), (40, 37, 90), (50, 16, 8), (48, 80, 120), (12, 40, 64), (45, 20, 96), (25, 40, 64),
                         (33, 33, 128), (35, 48, 200), (60, 24, 160)):
             shape = (Z, X, Y)
             pos = rng.gamma(2.0, 300.0, size=shape).astype(np.float32)
