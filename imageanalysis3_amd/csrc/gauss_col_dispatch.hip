@@ -6,9 +6,6 @@
 // and only when that is not possible (IA3_RTC=0, no hiprtc, sources not beside the library) the sliding-window kernels
 // (same results, +0.65 ms per 2048 x 2048 x 50 stack).
 #include "ia3_gauss.h"
-#include <hip/hiprtc.h>
-#include <dlfcn.h>
-#include <sys/stat.h>
 #include <unistd.h>
 #include <cstring>
 #include <cstdio>
@@ -42,40 +39,8 @@ pid_t g_rtc_pid = 0;
 int g_rtc_dev = -1;
 constexpr int RTC_R = 30, RTC_RF = 3;   // the radii the translation units are built for (gauss_col.inc)
 
-bool read_file(const std::string& path, std::string& out) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return false;
-  char buf[65536];
-  size_t n;
-  out.clear();
-  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);
-  fclose(f);
-  return true;
-}
-unsigned long long fnv(const std::string& s, unsigned long long h = 1469598103934665603ull) {
-  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
-  return h;
-}
-std::string lib_dir() {
-  Dl_info info;
-  if (!dladdr((void*)&ia3g::folded_axis0_f32, &info) || !info.dli_fname) return std::string();
-  std::string p(info.dli_fname);
-  const size_t k = p.rfind('/');
-  return k == std::string::npos ? std::string(".") : p.substr(0, k);
-}
-std::string cache_dir(const std::string& lib) {
-  const char* e = getenv("IA3_RTC_CACHE");
-  std::string cand[3] = {e ? std::string(e) : std::string(), lib + "/_rtc", std::string("/tmp/ia3_rtc_") + std::to_string((long)getuid())};
-  for (const std::string& d : cand) {
-    if (d.empty()) continue;
-    (void)mkdir(d.c_str(), 0755);
-    if (access(d.c_str(), W_OK) == 0) return d;
-  }
-  return std::string();
-}
-
-// code object + the two kernels of (dtype, depth); nullptr when the run-time path is not available (the caller then
-// reports FOLD_NOT_COVERED and the sliding-window kernels run).  Called with g_rtc_mu held.
+// the two kernels of (dtype, depth); nullptr when the run-time path is not available (the caller then reports
+// FOLD_NOT_COVERED and the sliding-window kernels run).  Called with g_rtc_mu held.
 const RtcDepth* rtc_depth_locked(bool f32, int Z) {
   int dev = -1;
   (void)hipGetDevice(&dev);
@@ -83,82 +48,19 @@ const RtcDepth* rtc_depth_locked(bool f32, int Z) {
   RtcDepth& d = g_rtc[Z * 2 + (f32 ? 1 : 0)];
   if (d.tried) return d.axis0 ? &d : nullptr;
   d.tried = true;
-  const char* off = getenv("IA3_RTC");
-  if ((off && atoi(off) == 0) || Z < 16 || Z > 64) return nullptr;
-  const std::string lib = lib_dir();
-  std::string dev_h, kern;
-  if (lib.empty() || !read_file(lib + "/csrc/ia3_gauss_dev.h", dev_h) || !read_file(lib + "/csrc/gauss_col_kernel.inc", kern)) return nullptr;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
-  std::string arch(prop.gcnArchName);
-  { const size_t c = arch.find(':'); if (c != std::string::npos) arch.resize(c); }
+  if (Z < 16 || Z > 64) return nullptr;
   char pre[512];
   snprintf(pre, sizeof(pre),
            "#define IA3_MODE_REFLECT %d\n#define IA3_MODE_NEAREST %d\n#define IA3_MODE_CONSTANT %d\n"
            "namespace ia3k { constexpr int DOG_PAIR_ZGROUPS = %d; }\n",
            (int)IA3_MODE_REFLECT, (int)IA3_MODE_NEAREST, (int)IA3_MODE_CONSTANT, (int)ia3k::DOG_PAIR_ZGROUPS);
-  { const size_t po = dev_h.find("#pragma once"); if (po != std::string::npos) dev_h.replace(po, 12, ""); }
-  const std::string src = std::string(pre) + dev_h + "\n" + kern + "\n";
   const char* tname = f32 ? "float" : "unsigned short";
   char n0[160], n1[160];
   snprintf(n0, sizeof(n0), "ia3colk::gauss_axis0_folded<%s, %d, %d, 0>", tname, Z, RTC_R);
   snprintf(n1, sizeof(n1), "ia3colk::gauss_axis0_folded<%s, %d, %d, %d>", tname, Z, RTC_R, RTC_RF);
-  const std::string a_opt = "--offload-arch=" + arch;
-  const char* opts[] = {a_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
-  int rv = 0;
-  (void)hiprtcVersion(&rv, &rv);
-  const unsigned long long key = fnv(std::string(n0) + n1 + a_opt + std::to_string(rv), fnv(src));
-  const std::string cdir = cache_dir(lib);
-  char fname[64];
-  snprintf(fname, sizeof(fname), "/col_%016llx.bin", key);
-  std::string blob;   // [lowered name 0]\0[lowered name 1]\0[code object]
-  bool cached = !cdir.empty() && read_file(cdir + fname, blob) && blob.size() > 16;
-  if (!cached) {
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "gauss_col_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
-    bool ok = hiprtcAddNameExpression(prog, n0) == HIPRTC_SUCCESS && hiprtcAddNameExpression(prog, n1) == HIPRTC_SUCCESS &&
-              hiprtcCompileProgram(prog, 4, opts) == HIPRTC_SUCCESS;
-    const char *l0 = nullptr, *l1 = nullptr;
-    size_t cs = 0;
-    ok = ok && hiprtcGetLoweredName(prog, n0, &l0) == HIPRTC_SUCCESS && hiprtcGetLoweredName(prog, n1, &l1) == HIPRTC_SUCCESS &&
-         hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
-    if (ok) {
-      blob.assign(l0); blob.push_back('\0'); blob.append(l1); blob.push_back('\0');
-      const size_t at = blob.size();
-      blob.resize(at + cs);
-      ok = hiprtcGetCode(prog, &blob[at]) == HIPRTC_SUCCESS;
-    } else if (getenv("IA3_RTC_VERBOSE")) {
-      size_t ls = 0;
-      (void)hiprtcGetProgramLogSize(prog, &ls);
-      std::string log(ls, '\0');
-      if (ls) (void)hiprtcGetProgramLog(prog, &log[0]);
-      fprintf(stderr, "ia3: run-time compile of the depth-%d column kernel failed:\n%s\n", Z, log.c_str());
-    }
-    (void)hiprtcDestroyProgram(&prog);
-    if (!ok) return nullptr;
-    if (!cdir.empty()) {   // written under a private name, then moved into place (other processes compile the same depth)
-      const std::string tmp = cdir + fname + "." + std::to_string((long)getpid());
-      FILE* f = fopen(tmp.c_str(), "wb");
-      if (f) {
-        const bool w = fwrite(blob.data(), 1, blob.size(), f) == blob.size();
-        fclose(f);
-        if (!w || rename(tmp.c_str(), (cdir + fname).c_str()) != 0) (void)unlink(tmp.c_str());
-      }
-    }
-  }
-  const char* l0 = blob.c_str();
-  const size_t len0 = strlen(l0);
-  if (len0 + 2 >= blob.size()) return nullptr;
-  const char* l1 = l0 + len0 + 1;
-  const size_t len1 = strlen(l1);
-  if (len0 + len1 + 2 >= blob.size()) return nullptr;
-  const char* code = l1 + len1 + 1;
-  if (hipModuleLoadData(&d.mod, code) != hipSuccess) { (void)hipGetLastError(); d.mod = nullptr; return nullptr; }
-  if (hipModuleGetFunction(&d.axis0, d.mod, l0) != hipSuccess || hipModuleGetFunction(&d.pair, d.mod, l1) != hipSuccess) {
-    (void)hipGetLastError();
-    d.axis0 = d.pair = nullptr;
-    return nullptr;
-  }
+  std::vector<hipFunction_t> fns;
+  if (!ia3rt::rtc_kernels("col", {"ia3_gauss_dev.h", "gauss_col_kernel.inc"}, pre, {n0, n1}, fns)) return nullptr;
+  d.axis0 = fns[0]; d.pair = fns[1];
   return &d;
 }
 

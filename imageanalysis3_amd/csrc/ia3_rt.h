@@ -41,6 +41,10 @@ inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 void* ws_get(size_t bytes);
 void ws_put(void* p);
 void ws_release_all();
+// rtc.cpp: kernels compiled at run time from device-only files beside the library (csrc/<files>, preceded by `preamble`);
+// fns[i] is the kernel of name expression names[i].  false: not available (IA3_RTC=0, no sources, compile error)
+bool rtc_kernels(const char* tag, const std::vector<std::string>& files, const std::string& preamble,
+                 const std::vector<std::string>& names, std::vector<hipFunction_t>& fns);
 void ws_reserve(size_t bytes, int count);   // at least `count` cached blocks that fit a request of `bytes` (best effort)
 
 struct Scratch {  // RAII

@@ -18,12 +18,15 @@
 // Compiled with -ffp-contract=off.  HBM-bound streaming passes + an L2-served 64-tap gather.
 #include "ia3_rt.h"
 #include <math.h>
+#include <stdio.h>
 
 using namespace ia3rt;
 
+#include "warp_iir0_kernel.inc"
+using namespace ia3warpk;
+
 namespace {
 
-constexpr int NPAD = 12;
 // stack depths with an axis-0 pass of their own (the depths the column kernels of the filters are built for)
 #ifdef IA3_FOLD_DEPTHS
 #define IA3_WARP_DEPTHS(X) IA3_FOLD_DEPTHS(X)
@@ -40,7 +43,6 @@ template <> __device__ __forceinline__ uint16_t out_cvt<uint16_t>(double t) {
   return (uint16_t)(int)t;
 }
 
-__device__ __forceinline__ int clampi(int v, int n) { return min(max(v, 0), n - 1); }   // one v_med3_i32 (n >= 1)
 
 // x / 6.0, correctly rounded, without the division sequence (15-20 dependent instructions, nine of them per voxel in
 // the cubic weights): q = RN(x * RN(1/6)) is within an ulp of the quotient, the remainder r = x - 6q is exact in one
@@ -72,12 +74,6 @@ __global__ void spline_pad_k(const T* __restrict__ im, int Z, int X, int Y, doub
 // is made after 64 terms and every 64 terms from there; a line whose leading samples are zero simply reads on.  The
 // largest sample is 65535 for uint16 sources and is measured for float32 ones (absmax_f32_k); each pass of the
 // prefilter can raise it by at most a factor 3 (the absolute sum of its impulse response).
-struct IirInit {
-  double z, gain, zn, scale;  // zn = z^n ; scale = z / (1 - zn*zn)
-  int full;                   // 1: zn != 0: sum all n terms incl. the mirror terms; 0: zn == 0, provable cut as above
-  double bound;               // 1.001 * gain * (largest |sample|, or 3^k when amax_bits holds the source's)
-  const unsigned* amax_bits;  // float32 sources: bits of max |im| (inf / NaN compare above every finite value)
-};
 
 __device__ __forceinline__ double iir_bound(const IirInit& q) {
   return q.amax_bits ? q.bound * (double)__uint_as_float(*q.amax_bits) : q.bound;
@@ -300,49 +296,6 @@ __global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < ZMAX; ++i) if (i < n) P[(size_t)i * plane + p] = c[i];
-}
-
-// The same pass for a padded depth N known at compile time (N = Z + 24 for the depths of IA3_WARP_DEPTHS): the line is
-// loaded once, all N loads in flight together, and the start sum runs on registers.  The generic kernel above walks the
-// source three times and its start-sum loop (trip count unknown to the compiler) waits for one load per term: 2.1 ms
-// of memory latency on a 50 x 2048 x 2048 stack.
-template <class T, int N>
-__global__ __launch_bounds__(256, 2) void spline_pad_iir0_n_k(const T* __restrict__ im, int X, int Y, double* __restrict__ P,
-                                                           IirInit q) {
-  constexpr int Z = N - 2 * NPAD;
-  const int Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD;
-  const size_t plane = (size_t)Xp * Yp;
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= plane) return;
-  const int x = (int)(p / Yp), y = (int)(p - (size_t)x * Yp);
-  const T* col = im + (size_t)clampi(x - NPAD, X) * Y + clampi(y - NPAD, Y);
-  const double z = q.z, g = q.gain;
-  const size_t zs = (size_t)X * Y;
-  T raw[Z];
-#pragma unroll
-  for (int i = 0; i < Z; ++i) raw[i] = col[(size_t)i * zs];
-  double c[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) c[i] = (double)raw[i < NPAD ? 0 : (i - NPAD >= Z ? Z - 1 : i - NPAD)] * g;
-  const double c0 = c[0];
-  double s = c0 + q.zn * c[N - 1], zi = z;
-#pragma unroll
-  for (int i = 1; i < N; ++i) {
-    s += zi * (c[i] + q.zn * c[N - 1 - i]);
-    zi *= z;
-  }
-  s *= q.scale;
-  s += c0;
-  double prev = s;
-  c[0] = prev;
-#pragma unroll
-  for (int i = 1; i < N; ++i) { const double v = c[i] + z * prev; c[i] = v; prev = v; }
-  prev = prev * (z / (z - 1.0));
-  c[N - 1] = prev;
-#pragma unroll
-  for (int i = N - 2; i >= 0; --i) { const double v = z * (prev - c[i]); c[i] = v; prev = v; }
-#pragma unroll
-  for (int i = 0; i < N; ++i) P[(size_t)i * plane + p] = c[i];
 }
 
 // IIR along the contiguous axis: every wave owns LPW lines (lanes 0..LPW-1 run the recursions) and marches them in
@@ -1098,6 +1051,23 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
       IA3_WARP_DEPTHS(IA3_WARP_DEPTH)
 #undef IA3_WARP_DEPTH
       default: break;
+    }
+    if (!done0 && Z >= 8 && Z <= 64) {
+      // a depth without an instantiation of its own: the same kernel from the run-time compiler (rtc.cpp; under a second, once
+      // per depth, dtype and machine, then from the cache file); not available -> the generic kernels below
+      char name[96];
+      snprintf(name, sizeof(name), "ia3warpk::spline_pad_iir0_n_k<%s, %d>", sizeof(T) == 4 ? "float" : "unsigned short", Z + 2 * NPAD);
+      std::vector<hipFunction_t> fns;
+      if (rtc_kernels("warp0", {"warp_iir0_kernel.inc"}, "#include <stdint.h>\n", {name}, fns)) {
+        const T* a_im = (const T*)im->d;
+        int a_x = X, a_y = Y;
+        double* a_p = P.as<double>();
+        IirInit a_q = qz;
+        void* args[] = {(void*)&a_im, (void*)&a_x, (void*)&a_y, (void*)&a_p, (void*)&a_q};
+        if (hipModuleLaunchKernel(fns[0], (unsigned)((plane + 255) / 256), 1, 1, 256, 1, 1, 0, st, args, nullptr) != hipSuccess)
+          return set_error(IA3_EHIP, "launch of the run-time compiled prefilter kernel (depth %d) failed: %s", Z, hipGetErrorString(hipGetLastError()));
+        done0 = true;
+      }
     }
     if (done0) {
     } else if (Zp <= 80) {   // padded line fits in registers: pad + axis-0 recursion in one pass

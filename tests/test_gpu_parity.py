@@ -684,6 +684,23 @@ def test_warp_cubic_one_pass_prefilter_and_grouped_gather_bit_exact(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_warp_cubic_axis0_pass_by_depth_bit_exact(dtype):
+    """The spline prefilter's axis-0 pass keeps the padded z line in registers: depths of the build list (30) have an
+    instantiation of their own, other depths from 8 to 64 planes (18, 41) get theirs from the run-time compiler
+    (csrc/rtc.cpp), deeper stacks (70) take the generic kernels.  All bit for bit equal to scipy."""
+    import np_oracle as O
+    from imageanalysis3_amd.correction_tools.translate import warp_3d_image
+    rng = np.random.RandomState(21)
+    view = np.uint32 if dtype == np.float32 else np.uint16
+    for Z in (30, 18, 41, 70):
+        im = rng.randint(90, 5000, size=(Z, 24, 40)).astype(dtype)
+        im[Z // 3] = 0
+        ref = O.warp_3d_image(im, [0.4, -1.3, 2.6], None, 3, "nearest")
+        w = warp_3d_image(im, [0.4, -1.3, 2.6], None, 3, "nearest")
+        assert np.array_equal(w.view(view), ref.view(view)), Z
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
 def test_warp_cubic_constant_mode_bit_exact(dtype):
     """warp_3d_image(warp_order=3) with its DEFAULT border mode 'constant' (correction_tools/translate.py:5-31): SciPy
     filters without padding and with the mirror boundary, returns cval = min(image) for coordinates outside the array
