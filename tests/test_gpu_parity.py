@@ -1611,6 +1611,49 @@ def test_movie_pipeline_options_equal_the_per_movie_calls(variant):
         assert np.array_equal(a, b)
 
 
+def test_movie_pipeline_failures_are_reported_not_hidden(tmp_path):
+    """ia3_process_movies / MoviePlan when things are wrong: a movie of another shape is refused before anything runs; a
+    .dax file that is too short fails ITS movie with the library's message while the batch still drains (no thread left
+    waiting); options the pipelined entry does not carry raise NotImplementedError at plan time (the caller then goes
+    movie by movie); a row buffer that is too small comes back as a capacity error and the wrapper retries with room."""
+    import contextlib, io
+    from conftest import build_chain_case, chain_kwargs
+    from imageanalysis3_amd import _lib as L
+    from imageanalysis3_amd.io_tools.load import MoviePlan
+    case = build_chain_case()
+    sel, kw = chain_kwargs(case, "full")
+    raw = case["raw"]
+    drift = kw.pop("drift")
+    th = {c: 300. for c in sel}
+    plan = MoviePlan(sel, calculate_drift=False, seed_th=th, fitting_args=dict(max_num_seeds=None), frames=raw.shape[0], **kw)
+    with pytest.raises(TypeError):
+        plan.run([raw[:-4]], drifts_in=[drift], measure_drift=False)
+    with pytest.raises(TypeError):
+        plan.run([raw.astype(np.float32)], drifts_in=[drift], measure_drift=False)
+    # a truncated movie file among good ones
+    good = str(tmp_path / "good.dax")
+    bad = str(tmp_path / "bad.dax")
+    raw.tofile(good)
+    raw[: raw.shape[0] // 2].tofile(bad)
+    for name in (good, bad):
+        with open(name[:-4] + ".inf", "w") as f:
+            f.write("frame dimensions = %d x %d\nnumber of frames = %d\n" % (raw.shape[2], raw.shape[1], raw.shape[0]))
+    ok = plan.run([good], drifts_in=[drift], measure_drift=False)
+    with pytest.raises(ValueError) as ei:
+        plan.run([good, bad, good], drifts_in=[drift] * 3, measure_drift=False)
+    assert "movie 1" in str(ei.value) and "fewer than" in str(ei.value)
+    again = plan.run([good, raw], drifts_in=[drift, drift], measure_drift=False)      # the library is still usable
+    for t, r in zip(again[1]["tables"], ok[0]["tables"]):
+        assert np.array_equal(t, r)
+    # a row buffer too small for the tables: capacity error inside, retried by the wrapper
+    small = plan.run([raw], drifts_in=[drift], measure_drift=False, capacity=4)
+    for t, r in zip(small[0]["tables"], ok[0]["tables"]):
+        assert np.array_equal(t, r)
+    for bad_kw in (dict(warp_image=False), dict(normalization=True), dict(output_dtype=np.float32)):
+        with pytest.raises(NotImplementedError):
+            MoviePlan(sel, calculate_drift=False, seed_th=th, frames=raw.shape[0], **dict(kw, **bad_kw))
+
+
 def test_movie_file_streams_into_a_resident_stack(tmp_path):
     """ia3_stack_load_file: pieces larger and smaller than the staging buffers, an offset, big-endian files; equal to
     read_dax + upload."""
