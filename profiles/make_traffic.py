@@ -5,7 +5,7 @@ import csv, collections, json, os, sys
 
 
 def short(name):
-    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return name.replace("(anonymous namespace)::", "").replace("ia3colk::", "").replace("void ", "").split("(")[0]
 
 
 SCOPE = {"gauss_axis0_folded<float, 50, 30, 3>": "gauss_axis0_pair", "gauss_xy_short<float, 3>": "gauss_xy_R3",
