@@ -519,8 +519,8 @@ extern "C" int ia3_process_movies(ia3_movie_job* jobs, int n_jobs, const ia3_mov
     }
   }
   // The pipeline's depth is bounded (upload_ahead movies waiting, NC in correction, the fit queue three groups deep):
-  // for a batch that will reach that depth the blocks are taken from the driver now, not one by one in the middle of it
-  if (n_jobs >= 2 * (NC + 1)) {
+  // for a long batch, which will reach that depth, the blocks are taken from the driver now, not one by one in the middle of it
+  if (n_jobs >= 16) {   // (a short batch would pay more for the allocations than it can lose to a stall)
     const int ahead = p->upload_ahead > 0 ? p->upload_ahead : 2;
     ws_reserve((size_t)p->frames * p->X * p->Y * sizeof(uint16_t), ahead + NC + 1);
     const int chain = p->n_load + p->n_bleed + 2 * p->n_sel;                    // stacks one correction holds at its widest

@@ -97,6 +97,9 @@ bool rtc_kernels(const char* tag, const std::vector<std::string>& files, const s
   std::string blob;   // [lowered name]\0 ... [code object]
   const bool cached = !cdir.empty() && read_file(cdir + fname, blob) && blob.size() > 16;
   if (!cached) {
+    if (!getenv("IA3_RTC_QUIET"))   // the one place the library speaks unasked: the caller would otherwise sit through a silent half minute
+      fprintf(stderr, "ia3: compiling %s for this stack depth (once per depth, dtype and machine; kept in %s)\n", names[0].c_str(),
+              cdir.empty() ? "memory only" : cdir.c_str());
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "ia3_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
     bool ok = true;
