@@ -512,9 +512,21 @@ __global__ __launch_bounds__(256) void real_argmax_part_k(const double* __restri
   __shared__ double sv[256];
   __shared__ long long si[256];
   double bv = -1.0; long long bi = 0x7fffffffffffffffLL;
-  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+  // four consecutive values per thread and step, two 16-byte loads in flight (one 8-byte load per step left the pass at
+  // 3 TB/s); a thread still meets its values in ascending order, so the first of equal maxima wins as before
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const size_t n4 = n & ~(size_t)3;
+  for (size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; k < n4; k += (size_t)gridDim.x * 1024) {
+    const d2 p = *(const d2*)(a + k), q = *(const d2*)(a + k + 2);
+    const double v[4] = {p.x * p.x, p.y * p.y, q.x * q.x, q.y * q.y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] > bv) { bv = v[j]; bi = (long long)(k + j); }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < (unsigned)(n - n4)) {   // (the last n % 4 values)
+    const size_t k = n4 + threadIdx.x;
     const double v = a[k] * a[k];
-    if (v > bv) { bv = v; bi = (long long)k; }
+    if (v > bv || (v == bv && (long long)k < bi)) { bv = v; bi = (long long)k; }
   }
   sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
   __syncthreads();
@@ -856,16 +868,21 @@ int ia3_phase_xcorr3d_dev(const ia3_stack* ref, const ia3_stack* mov, int upsamp
 // Same arithmetic as ia3_phase_xcorr3d_dev on the same operands; shifts agree to the last bit (tests).
 namespace {
 
+// (a row of the crop per block row: no 64-bit divisions per value, two values per thread)
 template <class T>
-__global__ void crop_to_real_k(const T* __restrict__ im, int X, int Y, int z0, int x0, int y0, int cz, int cx, int cy,
-                               double* __restrict__ o) {
-  const size_t n = (size_t)cz * cx * cy;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int y = (int)(i % (size_t)cy);
-  const size_t r = i / (size_t)cy;
-  const int x = (int)(r % (size_t)cx), z = (int)(r / (size_t)cx);
-  o[i] = (double)im[((size_t)(z0 + z) * X + (size_t)(x0 + x)) * Y + (size_t)(y0 + y)];
+__global__ __launch_bounds__(256) void crop_to_real_k(const T* __restrict__ im, int X, int Y, int z0, int x0, int y0, int cz, int cx, int cy,
+                                                      double* __restrict__ o) {
+  const int x = (int)blockIdx.y, z = (int)blockIdx.z;
+  const size_t r = (size_t)z * cx + x;                    // row of the crop
+  const T* src = im + ((size_t)(z0 + z) * X + (size_t)(x0 + x)) * Y + (size_t)y0;
+  double* dst = o + (size_t)r * cy;
+  const int y = (int)(blockIdx.x * 256 + threadIdx.x) * 2;
+  if (y + 1 < cy) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = {(double)src[y], (double)src[y + 1]};
+    if ((((size_t)r * cy + y) & 1) == 0) *(d2*)(dst + y) = v;   // 16-byte aligned
+    else { dst[y] = v.x; dst[y + 1] = v.y; }
+  } else if (y < cy) dst[y] = (double)src[y];
 }
 // out-of-place form of half_power_k: prod := A conj(B) (optionally phase-normalised), cj := conj(prod); A stays
 __global__ __launch_bounds__(256) void half_power2_k(const cplx* __restrict__ a, const cplx* __restrict__ b, size_t n, int Yh, int Y,
@@ -998,8 +1015,8 @@ static int crop_spectrum(const ia3_stack* s, const int* b, cplx* out, double* rb
   const int cz = b[1] - b[0], cx = b[3] - b[2], cy = b[5] - b[4];
   const size_t n = (size_t)cz * cx * cy;
   const unsigned nb = (unsigned)((n + 255) / 256);
-  if (s->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3(nb), dim3(256), 0, st, (const float*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
-  else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
+  if (s->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3((unsigned)((cy + 511) / 512), (unsigned)cx, (unsigned)cz), dim3(256), 0, st, (const float*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
+  else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3((unsigned)((cy + 511) / 512), (unsigned)cx, (unsigned)cz), dim3(256), 0, st, (const uint16_t*)s->d, s->X, s->Y, b[0], b[2], b[4], cz, cx, cy, rbuf);
   PlanLease fwd;
   { int prc = get_plan(HIPFFT_D2Z, cz, cx, cy, st, fwd); if (prc) return prc; }
   IA3_FFT(hipfftExecD2Z(fwd.h, rbuf, out));
@@ -1121,8 +1138,8 @@ int drift_crops(const ia3_stack* src, DriftRef* ref, int first, int count, int u
     const unsigned nblk = (unsigned)((n + 255) / 256);
     {
     ProfScope ps_fft("xcorr_fft");   // crop -> float64, D2Z, cross-power, Z2D, coarse peak
-    if (src->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3(nblk), dim3(256), 0, st, (const float*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
-    else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3(nblk), dim3(256), 0, st, (const uint16_t*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
+    if (src->dtype == IA3_F32) hipLaunchKernelGGL((crop_to_real_k<float>), dim3((unsigned)((Y + 511) / 512), (unsigned)X, (unsigned)Z), dim3(256), 0, st, (const float*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
+    else hipLaunchKernelGGL((crop_to_real_k<uint16_t>), dim3((unsigned)((Y + 511) / 512), (unsigned)X, (unsigned)Z), dim3(256), 0, st, (const uint16_t*)src->d, src->X, src->Y, b[0], b[2], b[4], Z, X, Y, rbuf.as<double>());
     IA3_FFT(hipfftExecD2Z(fwd.h, rbuf.as<double>(), fb.as<cplx>()));
     // fp := prod, fb := conj(prod) (the data of the upsampled DFT); the power sums are not needed for the shift
     hipLaunchKernelGGL(half_power2_k, dim3(ABS2_BLOCKS), dim3(256), 0, st, (const cplx*)ref->spec[c], (const cplx*)fb.as<cplx>(), nh, Yh, Y, normalization,
