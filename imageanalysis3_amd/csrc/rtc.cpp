@@ -95,7 +95,8 @@ bool rtc_kernels(const char* tag, const std::vector<std::string>& files, const s
   char fname[96];
   snprintf(fname, sizeof(fname), "/%s_%016llx.bin", tag, key);
   std::string blob;   // [lowered name]\0 ... [code object]
-  const bool cached = !cdir.empty() && read_file(cdir + fname, blob) && blob.size() > 16;
+  bool cached = !cdir.empty() && read_file(cdir + fname, blob) && blob.size() > 16;
+  for (int attempt = 0; attempt < 2; ++attempt) {   // (second round: a cache file that would not load is thrown away and made again)
   if (!cached) {
     if (!getenv("IA3_RTC_QUIET"))   // the one place the library speaks unasked: the caller would otherwise sit through a silent half minute
       fprintf(stderr, "ia3: compiling %s for this stack depth (once per depth, dtype and machine; kept in %s)\n", names[0].c_str(),
@@ -136,17 +137,23 @@ bool rtc_kernels(const char* tag, const std::vector<std::string>& files, const s
       }
     }
   }
-  std::vector<const char*> low(names.size());
+  std::vector<const char*> low(names.size(), "");
   size_t at = 0;
-  for (size_t i = 0; i < names.size(); ++i) {
-    if (at >= blob.size()) return false;
+  for (size_t i = 0; i < names.size() && at < blob.size(); ++i) {
     low[i] = blob.c_str() + at;
     at += strlen(low[i]) + 1;
   }
-  if (at >= blob.size()) return false;
-  if (hipModuleLoadData(&e.mod, blob.data() + at) != hipSuccess) { (void)hipGetLastError(); e.mod = nullptr; return false; }
-  for (size_t i = 0; i < names.size(); ++i)
-    if (hipModuleGetFunction(&e.fns[i], e.mod, low[i]) != hipSuccess) { (void)hipGetLastError(); e.fns.assign(names.size(), nullptr); return false; }
+  bool loaded = at < blob.size() && hipModuleLoadData(&e.mod, blob.data() + at) == hipSuccess;
+  for (size_t i = 0; loaded && i < names.size(); ++i) loaded = hipModuleGetFunction(&e.fns[i], e.mod, low[i]) == hipSuccess;
+  if (loaded) break;
+  (void)hipGetLastError();
+  if (e.mod) { (void)hipModuleUnload(e.mod); e.mod = nullptr; }
+  e.fns.assign(names.size(), nullptr);
+  if (!cached) return false;
+  (void)unlink((cdir + fname).c_str());
+  cached = false;
+  }
+  if (!e.mod) return false;
   e.ok = true;
   fns = e.fns;
   return true;
