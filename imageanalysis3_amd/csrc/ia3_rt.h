@@ -41,6 +41,9 @@ inline size_t esize(int dtype) { return dtype == IA3_U16 ? 2 : 4; }
 void* ws_get(size_t bytes);
 void ws_put(void* p);
 void ws_release_all();
+// runtime.cpp: a four-float device slot beside a buffer made by ia3_buffer_upload (constant over a run), see there
+float* const_note(const void* buf, bool* ready, bool* fill);
+void const_note_filled(const void* buf, bool ok);
 // rtc.cpp: kernels compiled at run time from device-only files beside the library (csrc/<files>, preceded by `preamble`);
 // fns[i] is the kernel of name expression names[i].  false: not available (IA3_RTC=0, no sources, compile error)
 bool rtc_kernels(const char* tag, const std::vector<std::string>& files, const std::string& preamble,

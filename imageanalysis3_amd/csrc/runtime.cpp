@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <map>
 #include <mutex>
 #include <atomic>
 #include <thread>
@@ -51,6 +52,8 @@ static std::vector<WsEntry> g_ws;
 // hardware queues next to the live ones.  The process's first stream (g_stream) stays; after a fork nothing here is ours.
 // the main streams of the host threads that are alive (under g_mu): a stack remembers the stream of the thread that made
 // it (ia3_stack_free), and that thread may be gone
+struct ConstNote { float* slot = nullptr; int state = 0; };
+static std::map<void*, ConstNote> g_const_bufs;   // buffers of ia3_buffer_upload and their notes (see there); under g_mu
 static std::vector<hipStream_t> g_live_streams;
 static bool stream_alive_locked(hipStream_t s) {
   for (hipStream_t t : g_live_streams) if (t == s) return true;
@@ -83,7 +86,7 @@ int set_error(int code, const char* fmt, ...) {
 static int do_init(int device) {
   // HIP state does not survive fork(): a child that inherits g_pid != getpid() starts over.
   if (g_stream && g_pid == getpid() && (device < 0 || device == g_device)) return IA3_OK;
-  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_live_streams.clear(); g_device = -1; }
+  if (g_pid != getpid()) { g_stream = nullptr; g_ws.clear(); g_live_streams.clear(); g_const_bufs.clear(); g_device = -1; }
   // Every host thread drives two streams (ThreadCtx); the runtime multiplexes streams onto 4 hardware queues by
   // default, where a long-running fit kernel holds back unrelated work queued behind it.  Ask for more queues unless
   // the user chose a number (only effective when this is the first HIP call of the process).
@@ -714,7 +717,34 @@ int ia3_stack_deinterleave(const ia3_stack* raw, int start, int step, int Z, ia3
   }
   return IA3_OK;
 }
-// plain device buffers for data that stays constant over a run (illumination / bleedthrough / chromatic profiles)
+// Buffers made by ia3_buffer_upload hold data that stays constant over a run (illumination / bleedthrough / chromatic
+// profiles): a consumer may keep a small summary of one beside it — the cubic warp keeps the range of a displacement
+// field's z component (warp.hip), 0.2 ms to compute, needed by every warp with that field.  One slot of four floats per
+// buffer, made on first request; state 0 = empty, 1 = being filled by some thread, 2 = filled and visible to every stream.
+}  // extern "C"
+namespace ia3rt {
+// slot of `buf` if it is such a buffer, else nullptr.  *fill = true: the caller computes the summary into the slot on its
+// stream, synchronises that stream and calls const_note_filled; *ready = true: the slot can be read by any stream.
+float* const_note(const void* buf, bool* ready, bool* fill) {
+  *ready = *fill = false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_const_bufs.find((void*)buf);
+  if (it == g_const_bufs.end()) return nullptr;
+  ConstNote& n = it->second;
+  if (n.state == 2) { *ready = true; return n.slot; }
+  if (n.state == 1) return nullptr;                        // another thread is at it: this call works without the note
+  if (!n.slot && hipMalloc((void**)&n.slot, 4 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); n.slot = nullptr; return nullptr; }
+  n.state = 1;
+  *fill = true;
+  return n.slot;
+}
+void const_note_filled(const void* buf, bool ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_const_bufs.find((void*)buf);
+  if (it != g_const_bufs.end()) it->second.state = ok ? 2 : 0;
+}
+}  // namespace ia3rt
+extern "C" {
 int ia3_buffer_upload(const void* host, size_t bytes, void** devptr) {
   int rc = ensure_init(); if (rc) return rc;
   if (!host || !devptr || bytes == 0) return set_error(IA3_EINVAL, "bad buffer arguments");
@@ -724,10 +754,24 @@ int ia3_buffer_upload(const void* host, size_t bytes, void** devptr) {
   if (e == hipSuccess) e = hipStreamSynchronize(stream());
   if (e != hipSuccess) { (void)hipFree(d); return set_error(IA3_EHIP, "H2D copy failed: %s", hipGetErrorString(e)); }
   *devptr = d;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_const_bufs[d] = ConstNote();
+  }
   return IA3_OK;
 }
 void ia3_buffer_free(void* devptr) {
-  if (devptr && g_pid == getpid()) { (void)hipStreamSynchronize(stream()); (void)hipFree(devptr); }
+  if (devptr && g_pid == getpid()) {
+    (void)hipStreamSynchronize(stream());
+    float* slot = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      auto it = g_const_bufs.find(devptr);
+      if (it != g_const_bufs.end()) { slot = it->second.slot; g_const_bufs.erase(it); }
+    }
+    if (slot) (void)hipFree(slot);
+    (void)hipFree(devptr);
+  }
 }
 int ia3_stack_wrap(void* devptr, int dtype, int Z, int X, int Y, ia3_stack** out) {
   int rc = ensure_init(); if (rc) return rc;

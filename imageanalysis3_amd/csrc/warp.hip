@@ -175,9 +175,10 @@ __device__ __forceinline__ void iir_two_sweeps_strided(double* __restrict__ c, s
 
 // IIR along a strided axis: line p (lane along the contiguous axis), element i at base + i*stride
 __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__ P, int inner, size_t stride, int n,
-                                                            size_t outer_stride, IirInit q) {
+                                                            size_t outer_stride, IirInit q, const int* __restrict__ zr) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= inner) return;
+  if (zr && ((int)blockIdx.y < zr[0] || (int)blockIdx.y > zr[1])) return;   // (blockIdx.y = plane: not read by the gather)
   double* c = P + (size_t)blockIdx.y * outer_stride + p;
   iir_two_sweeps_strided(c, stride, 0, n, iir_start_strided(c, stride, n, q), q.z, q.gain);
 }
@@ -199,10 +200,11 @@ __global__ __launch_bounds__(256) void spline_iir_strided_k(double* __restrict__
 // thread marches along the line.  The window of T + K causal values lives in registers.
 template <int T, int K, int OCC>
 __global__ __launch_bounds__(64, OCC) void spline_iir_strided_1p_k(double* __restrict__ P, int inner, size_t stride, int n,
-                                                                   size_t outer_stride, IirInit q, int warm) {
+                                                                   size_t outer_stride, IirInit q, int warm, const int* __restrict__ zr) {
   constexpr int W = T + K;
   const int p = blockIdx.x * 64 + threadIdx.x;
   if (p >= inner) return;
+  if ((int)blockIdx.y < zr[0] || (int)blockIdx.y > zr[1]) return;   // a plane the gather will not read
   double* c = P + (size_t)blockIdx.y * outer_stride + p;
   const double z = q.z, g = q.gain;
   const double bound = iir_bound(q);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64, OCC) void spline_iir_strided_1p_k(double* __res
 // same order as spline_pad_k followed by spline_iir_strided_k with the faithful (full) start sum.
 template <class T, int ZMAX>
 __global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict__ im, int Z, int X, int Y, double* __restrict__ P,
-                                                         IirInit q) {
+                                                         IirInit q, const int* __restrict__ zr) {
   const int Xp = X + 2 * NPAD, Yp = Y + 2 * NPAD, n = Z + 2 * NPAD;
   const size_t plane = (size_t)Xp * Yp;
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -294,8 +296,9 @@ __global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict_
     if (i == n - 1) c[i] = prev;
     else if (i < n - 1) { const double v = z * (prev - c[i]); c[i] = v; prev = v; }
   }
+  const int p_lo = zr[0], p_hi = zr[1];   // (planes the gather will not read are not stored, see zrange_k)
 #pragma unroll
-  for (int i = 0; i < ZMAX; ++i) if (i < n) P[(size_t)i * plane + p] = c[i];
+  for (int i = 0; i < ZMAX; ++i) if (i < n && i >= p_lo && i <= p_hi) P[(size_t)i * plane + p] = c[i];
 }
 
 // IIR along the contiguous axis: every wave owns LPW lines (lanes 0..LPW-1 run the recursions) and marches them in
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void spline_pad_iir0_k(const T* __restrict_
 // and written once.  If the chains of any line disagree the wave finishes its lines with the two sweeps from the
 // first tile that is still raw in memory.
 template <int TW, int LPW, int OCC>
-__global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q, int warm) {
+__global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restrict__ P, size_t n_lines, int n, IirInit q, int warm,
+                                                                const int* __restrict__ zr, int lines_per_plane) {
   constexpr int RPI = 64 / TW;   // rows moved per wave instruction
   constexpr int NR = LPW / RPI;  // wave instructions per tile
   constexpr int SC = 16;         // samples of a line in registers at a time
@@ -319,6 +323,11 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
   const int wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   const size_t l0 = ((size_t)blockIdx.x * 4 + wv) * LPW;
   if (l0 >= n_lines) return;                 // whole wave
+  {   // all of this wave's lines in planes the gather will not read (zrange_k): nothing to do
+    const size_t l1 = l0 + LPW - 1 < n_lines ? l0 + LPW - 1 : n_lines - 1;
+    const int pa = (int)(l0 / (size_t)lines_per_plane), pb = (int)(l1 / (size_t)lines_per_plane);
+    if (pb < zr[0] || pa > zr[1]) return;
+  }
   const bool mine = t < LPW && l0 + t < n_lines;
   const int lt = t < LPW ? t : 0;            // row of the tile this lane's recursion runs on
   const int col = t % TW, rsub = t / TW;
@@ -559,6 +568,87 @@ __global__ __launch_bounds__(256, OCC) void spline_iir_contig_k(double* __restri
 
 __device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
   return fdt == 1 ? (double)((const float*)f)[i] : ((const double*)f)[i];
+}
+
+// ---- the padded planes a cubic warp reads ------------------------------------------------------------------------------
+// SciPy pads every axis by 12 samples and filters the padded volume; a stack of 50 planes becomes 74, and the passes along
+// x and y and the stores of the z pass spend a third of their time on planes no tap ever reaches: output plane z reads the
+// coefficient planes floor(z - drift_z + field_z + 12) - 1 ... + 2.  zrange_k turns the drift and the range of the field's
+// z component (field_zminmax_k; nothing to scan without a field) into the first and last padded plane that can be read, one
+// plane of margin on either side; the prefilter kernels take the two words from device memory — no host round trip — and
+// leave the other planes alone.  The coefficients of the planes that are computed do not change (the z recursion runs over
+// the whole padded line in registers; x and y lines lie inside a plane).
+constexpr int ZR_BLOCKS = 2048;
+// per block: [smallest value, largest value, 1 if a value was not finite] of fz[0 .. n)
+template <class F>
+__global__ __launch_bounds__(256) void field_zminmax_k(const F* __restrict__ fz, size_t n, float* __restrict__ part) {
+  float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+  bool bad = false;
+  auto take = [&](F v) {
+    bad = bad || !(v - v == (F)0);                         // NaN / inf: every plane is kept
+    const float f = (float)v;                              // (float64 fields: rounded to nearest; zrange_k's margin covers half an ulp)
+    lo = fminf(lo, f); hi = fmaxf(hi, f);
+  };
+  constexpr int PER = 16 / (int)sizeof(F);                 // values per 16-byte load
+  typedef F vec __attribute__((ext_vector_type(PER)));
+  const size_t nv = n / PER;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    const vec q = ((const vec*)fz)[i];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) take(q[k]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - nv * PER)) take(fz[nv * PER + threadIdx.x]);
+  __shared__ float slo[256], shi[256];
+  __shared__ int sbad[256];
+  slo[threadIdx.x] = lo; shi[threadIdx.x] = hi; sbad[threadIdx.x] = bad ? 1 : 0;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      slo[threadIdx.x] = fminf(slo[threadIdx.x], slo[threadIdx.x + k]);
+      shi[threadIdx.x] = fmaxf(shi[threadIdx.x], shi[threadIdx.x + k]);
+      sbad[threadIdx.x] |= sbad[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[3 * blockIdx.x] = slo[0]; part[3 * blockIdx.x + 1] = shi[0]; part[3 * blockIdx.x + 2] = sbad[0] ? 1.f : 0.f; }
+}
+// the partials of field_zminmax_k folded into one triple (kept beside a constant field, runtime.cpp: const_note)
+__global__ __launch_bounds__(256) void zminmax_fold_k(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float slo[256], shi[256], sb[256];
+  float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf(), bad = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 256) { lo = fminf(lo, part[3 * b]); hi = fmaxf(hi, part[3 * b + 1]); bad = fmaxf(bad, part[3 * b + 2]); }
+  slo[threadIdx.x] = lo; shi[threadIdx.x] = hi; sb[threadIdx.x] = bad;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      slo[threadIdx.x] = fminf(slo[threadIdx.x], slo[threadIdx.x + k]);
+      shi[threadIdx.x] = fmaxf(shi[threadIdx.x], shi[threadIdx.x + k]);
+      sb[threadIdx.x] = fmaxf(sb[threadIdx.x], sb[threadIdx.x + k]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = slo[0]; out[1] = shi[0]; out[2] = sb[0]; }
+}
+__global__ void zrange_k(const float* __restrict__ part, int nb, double dz, int Z, int* __restrict__ zr) {
+  double lo = 0.0, hi = 0.0;
+  bool bad = false;
+  for (int b = 0; b < nb; ++b) {
+    lo = b == 0 ? (double)part[0] : fmin(lo, (double)part[3 * b]);
+    hi = b == 0 ? (double)part[1] : fmax(hi, (double)part[3 * b + 1]);
+    bad = bad || part[3 * b + 2] != 0.f;
+  }
+  const int Zp = Z + 2 * NPAD;
+  // coordinates 0 - dz + lo ... (Z - 1) - dz + hi (the two orders of adding drift and field differ by rounding only: the
+  // margin covers it); first tap floor(c + 12) - 1, last tap floor(c + 12) + 2
+  lo = floor(lo) - 1.0; hi = ceil(hi) + 1.0;               // (float-rounded extremes of a float64 field; the two orders of the sums)
+  const double cmin = -dz + lo + (double)NPAD, cmax = (double)(Z - 1) - dz + hi + (double)NPAD;
+  int p_lo = 0, p_hi = Zp - 1;
+  if (!bad && cmin - cmin == 0.0 && cmax - cmax == 0.0) {
+    const double a = floor(cmin) - 1.0, b = floor(cmax) + 2.0;   // first tap floor(c) - 1, last tap floor(c) + 2
+    p_lo = a < 0.0 ? 0 : (a > (double)(Zp - 1) ? Zp - 1 : (int)a);
+    p_hi = b < 0.0 ? 0 : (b > (double)(Zp - 1) ? Zp - 1 : (int)b);
+  }
+  zr[0] = p_lo; zr[1] = p_hi;
 }
 
 // ---- order 3, mode 'constant' (translate.py:5-31 called with warp_order=3 and its default border mode) --------------
@@ -1028,8 +1118,43 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
   if (!P.p) return IA3_ENOMEM;
   const size_t plane = (size_t)Xp * Yp;
   const unsigned* amax = nullptr;
+  Scratch zrs((3 * ZR_BLOCKS + 8) * sizeof(float));   // partials of the field scan | zr[2]
+  if (!zrs.p) return IA3_ENOMEM;
+  int* zr = (int*)((float*)zrs.p + 3 * ZR_BLOCKS);
   {
     ProfScope ps("spline_axis0");
+    {   // the planes this warp's gather can read (zrange_k)
+      const size_t V = (size_t)Z * X * Y;
+      const float* src3 = (const float*)zrs.p;   // [lo, hi, bad] triples
+      int nb = 1;
+      auto scan = [&]() {
+        nb = (int)((V / 4 + 255) / 256 < (size_t)ZR_BLOCKS ? (V / 4 + 255) / 256 : (size_t)ZR_BLOCKS);
+        if (nb < 1) nb = 1;
+        if ((fdt & 3) == 1) hipLaunchKernelGGL((field_zminmax_k<float>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)field, V, (float*)zrs.p);
+        else hipLaunchKernelGGL((field_zminmax_k<double>), dim3((unsigned)nb), dim3(256), 0, st, (const double*)field, V, (float*)zrs.p);
+      };
+      if (!field) {
+        IA3_HIP(hipMemsetAsync(zrs.p, 0, 3 * sizeof(float), st));   // one triple: lo = hi = 0, nothing bad
+      } else {
+        // a field that lives in a buffer of ia3_buffer_upload is constant over the run: its range is computed once and kept
+        // beside it (the scan reads 0.84 GB for a 50 x 2048 x 2048 float32 field: 0.2 ms of every warp otherwise)
+        bool ready = false, fill = false;
+        float* note = const_note(field, &ready, &fill);
+        if (note && ready) src3 = note;
+        else {
+          scan();
+          float* folded = note && fill ? note : (float*)zrs.p + 3 * ZR_BLOCKS + 4;   // (behind the two words of zr)
+          hipLaunchKernelGGL(zminmax_fold_k, dim3(1), dim3(256), 0, st, (const float*)zrs.p, nb, folded);
+          src3 = folded;
+          nb = 1;
+          if (note && fill) {
+            const bool ok = hipStreamSynchronize(st) == hipSuccess;   // once per field: other streams may read the note from now on
+            const_note_filled(field, ok);
+          }
+        }
+      }
+      hipLaunchKernelGGL(zrange_k, dim3(1), dim3(1), 0, st, src3, nb, drift[0], Z, zr);
+    }
     // largest |sample| of the source, for the cut of the start sums along long axes (IirInit)
     if (sizeof(T) == 4) {
       unsigned* slot = (unsigned*)((char*)P.p + coef_bytes);
@@ -1045,7 +1170,7 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
 #define IA3_WARP_DEPTH(D)                                                                                              \
       case D:                                                                                                          \
         hipLaunchKernelGGL((spline_pad_iir0_n_k<T, D + 2 * NPAD>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, \
-                           (const T*)im->d, X, Y, P.as<double>(), qz);                                                 \
+                           (const T*)im->d, X, Y, P.as<double>(), qz, (const int*)zr);                                 \
         done0 = true;                                                                                                  \
         break;
       IA3_WARP_DEPTHS(IA3_WARP_DEPTH)
@@ -1063,7 +1188,8 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
         int a_x = X, a_y = Y;
         double* a_p = P.as<double>();
         IirInit a_q = qz;
-        void* args[] = {(void*)&a_im, (void*)&a_x, (void*)&a_y, (void*)&a_p, (void*)&a_q};
+        const int* a_zr = zr;
+        void* args[] = {(void*)&a_im, (void*)&a_x, (void*)&a_y, (void*)&a_p, (void*)&a_q, (void*)&a_zr};
         if (hipModuleLaunchKernel(fns[0], (unsigned)((plane + 255) / 256), 1, 1, 256, 1, 1, 0, st, args, nullptr) != hipSuccess)
           return set_error(IA3_EHIP, "launch of the run-time compiled prefilter kernel (depth %d) failed: %s", Z, hipGetErrorString(hipGetLastError()));
         done0 = true;
@@ -1072,12 +1198,12 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     if (done0) {
     } else if (Zp <= 80) {   // padded line fits in registers: pad + axis-0 recursion in one pass
       hipLaunchKernelGGL((spline_pad_iir0_k<T, 80>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const T*)im->d, Z, X, Y,
-                         P.as<double>(), qz);
+                         P.as<double>(), qz, (const int*)zr);
     } else {
       hipLaunchKernelGGL((spline_pad_k<T>), dim3((unsigned)((Yp + 255) / 256), (unsigned)Xp, (unsigned)Zp), dim3(256), 0, st,
                          (const T*)im->d, Z, X, Y, P.as<double>());
       hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((plane + 255) / 256), 1), dim3(256), 0, st, P.as<double>(),
-                         (int)plane, plane, Zp, (size_t)0, qz);
+                         (int)plane, plane, Zp, (size_t)0, qz, (const int*)nullptr);
     }
   }
   {   // axis 1: lines = (z,y), stride = Yp
@@ -1089,17 +1215,17 @@ int warp_t(const ia3_stack* im, const double* drift, const void* field, int fdt,
     constexpr int T1 = 12, K1 = 52;
     if (g_warp_warm > 0 && Xp >= 2 * (T1 + K1))
       hipLaunchKernelGGL((spline_iir_strided_1p_k<T1, K1, 3>), dim3((unsigned)((Yp + 63) / 64), (unsigned)Zp), dim3(64), 0, st,
-                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1);
+                         P.as<double>(), Yp, (size_t)Yp, Xp, plane, qx, g_warp_warm < K1 ? g_warp_warm : K1, (const int*)zr);
     else
       hipLaunchKernelGGL(spline_iir_strided_k, dim3((unsigned)((Yp + 255) / 256), (unsigned)Zp), dim3(256), 0, st, P.as<double>(),
-                         Yp, (size_t)Yp, Xp, plane, qx);
+                         Yp, (size_t)Yp, Xp, plane, qx, (const int*)zr);
   }
   {   // axis 2: contiguous lines (z,x)
     ProfScope ps("spline_axis2");
     IirInit qy = make_init(Yp, 2, 65535.0, amax);
     const size_t nl = (size_t)Zp * Xp;
     hipLaunchKernelGGL((spline_iir_contig_k<64, 8, 3>), dim3((unsigned)((nl + 31) / 32)), dim3(256), 0, st, P.as<double>(), nl,
-                       Yp, qy, g_warp_warm);
+                       Yp, qy, g_warp_warm, (const int*)zr, Xp);
   }
   {
     ProfScope ps("warp_cubic");
