@@ -574,8 +574,8 @@ __device__ __forceinline__ double field_at(const void* f, int fdt, size_t i) {
 // SciPy pads every axis by 12 samples and filters the padded volume; a stack of 50 planes becomes 74, and the passes along
 // x and y and the stores of the z pass spend a third of their time on planes no tap ever reaches: output plane z reads the
 // coefficient planes floor(z - drift_z + field_z + 12) - 1 ... + 2.  zrange_k turns the drift and the range of the field's
-// z component (field_zminmax_k; nothing to scan without a field) into the first and last padded plane that can be read, one
-// plane of margin on either side; the prefilter kernels take the two words from device memory — no host round trip — and
+// z component (field_zminmax_k; nothing to scan without a field) into the first and last padded plane that can be read;
+// the prefilter kernels take the two words from device memory — no host round trip — and
 // leave the other planes alone.  The coefficients of the planes that are computed do not change (the z recursion runs over
 // the whole padded line in registers; x and y lines lie inside a plane).
 constexpr int ZR_BLOCKS = 2048;
@@ -640,7 +640,9 @@ __global__ void zrange_k(const float* __restrict__ part, int nb, double dz, int 
   const int Zp = Z + 2 * NPAD;
   // coordinates 0 - dz + lo ... (Z - 1) - dz + hi (the two orders of adding drift and field differ by rounding only: the
   // margin covers it); first tap floor(c + 12) - 1, last tap floor(c + 12) + 2
-  lo = floor(lo) - 1.0; hi = ceil(hi) + 1.0;               // (float-rounded extremes of a float64 field; the two orders of the sums)
+  // (the extremes of a float64 field were rounded to float, 6e-8 relative; the two orders of adding drift and field differ
+  // by an ulp of the coordinate: a margin of 1e-4 + 1e-6 |value| voxels is orders of magnitude more than either)
+  lo = lo - (1e-4 + 1e-6 * fabs(lo)); hi = hi + (1e-4 + 1e-6 * fabs(hi));
   const double cmin = -dz + lo + (double)NPAD, cmax = (double)(Z - 1) - dz + hi + (double)NPAD;
   int p_lo = 0, p_hi = Zp - 1;
   if (!bad && cmin - cmin == 0.0 && cmax - cmax == 0.0) {
